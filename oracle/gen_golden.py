@@ -1,0 +1,199 @@
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and the installed `transformers`);
+the fixtures (inputs + expected outputs, weights identified by seed) are what travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The reference classes are imported unmodified through the compatibility shim of SURVEY.md
+Appendix B (transformers 5.15.0 vs the pinned 4.1.1: `init_weights`/`post_init`, and the
+`LxmertPreTrainingHeads(config, weight)` ctor signature).  Weights come from
+`lxmert_oracle.make_state_dict(cfg, seed)` (numpy PCG64), loaded into the reference model with
+`load_state_dict`, so a fixture only has to record the seed.
+"""
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference/x-lxmert/src")
+
+import numpy as np
+import torch
+
+import lxrt.modeling as M                                   # the reference
+from transformers import LxmertConfig
+from transformers.modeling_utils import PreTrainedModel
+
+import lxmert_oracle as O
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+class Shim(M.XLxmertForPretraining):
+    def init_weights(self):
+        if not getattr(self, "_in_post", False):
+            self._in_post = True
+            self.post_init()
+        else:
+            PreTrainedModel.init_weights(self)
+
+
+_h = M.LxmertPreTrainingHeads
+M.LxmertPreTrainingHeads = lambda cfg, w=None: _h(cfg)
+
+
+def build_reference(cfg: O.OracleConfig, seed: int, perturb=True):
+    hf = LxmertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                      num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                      max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                      l_layers=cfg.l_layers, x_layers=cfg.x_layers, r_layers=cfg.r_layers,
+                      visual_feat_dim=cfg.visual_feat_dim, visual_pos_dim=cfg.visual_pos_dim,
+                      visual_attr_loss=False, task_qa=False)
+    m = Shim(hf, num_clusters=cfg.num_clusters)
+    sd = O.make_state_dict(cfg, seed, perturb=perturb)
+    m.set_visual_embedding(sd["vis_emb.weight"].clone())
+    m.config.n_centroids = cfg.num_clusters                  # reference defect 9
+    res = m.load_state_dict({k: v for k, v in sd.items() if k != "vis_emb.weight"
+                             and k != "obj_predict_head.out_cluster.weight"}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    missing = [k for k in res.missing_keys if not k.startswith("cls.") and "vis_emb" not in k
+               and "out_cluster.weight" not in k]
+    assert not missing, missing
+    m.eval()
+    return m, sd
+
+
+def run_reference(m, inp, with_grad=True):
+    fl = m.vis_emb(inp["cluster_ids"])
+    out = m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+            cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], token_type_ids=inp["token_type_ids"],
+            return_dict=True, label_dict={"obj_labels": inp["obj_labels"], "feat_labels": fl}, task="vis_mask")
+    grads = {}
+    if with_grad:
+        m.zero_grad(set_to_none=True)
+        out["total_loss"].backward()
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                grads[k] = p.grad.detach().clone()
+    with torch.no_grad():
+        feats = m.vis_emb(inp["cluster_ids"])
+        B, V, _ = feats.shape
+        feats = torch.where(inp["vis_mask"].view(B, V, 1), m.mask_feat.view(1, 1, -1), feats)
+        bo = m.bert(input_ids=inp["input_ids"], visual_feats=feats, visual_pos=inp["visual_pos"],
+                    attention_mask=inp["attention_mask"], token_type_ids=inp["token_type_ids"],
+                    output_hidden_states=True, return_dict=True)
+        head = m.obj_predict_head(bo.vision_output, out_keys=["obj", "feat"])
+    return out, grads, bo, head
+
+
+def np_inputs(inp):
+    return {"in_" + k: v.numpy() for k, v in inp.items()}
+
+
+def cfg_fields(cfg):
+    return {"cfg_" + k: np.array(v) for k, v in cfg.__dict__.items()}
+
+
+def gen_tiny(name, cfg, seed, B, L, grid, store_grads=True):
+    torch.manual_seed(0)
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    out, grads, bo, head = run_reference(m, inp)
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp))
+    d.update(lang=bo.language_output.numpy(), vis=bo.vision_output.numpy(), pooled=bo.pooled_output.numpy(),
+             feat=head["feat"].numpy(), obj=head["obj"].numpy())
+    for i, h in enumerate(bo.language_hidden_states):
+        d[f"lang_h{i}"] = h.numpy()
+    for i, h in enumerate(bo.vision_hidden_states):
+        d[f"vis_h{i}"] = h.numpy()
+    for k in ("obj_loss", "feat_loss", "vis_loss", "total_loss"):
+        d[k] = out[k].detach().numpy()
+    d["grad_names"] = np.array(sorted(grads.keys()))
+    for k, g in grads.items():
+        if store_grads:
+            d["grad:" + k] = g.numpy()
+        d["gnorm:" + k] = np.array(g.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, {k: float(out[k]) for k in ("obj_loss", "feat_loss")}, "n_grads", len(grads))
+
+
+def gen_config1(seed=9595, B=2):
+    cfg = O.OracleConfig(l_layers=1, x_layers=1, r_layers=1)
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, 20, 8)
+    out, grads, bo, head = run_reference(m, inp)
+    obj = head["obj"].reshape(B * 64, -1)
+    rows = np.arange(0, B * 64, 16)
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp))
+    d.update(lang=bo.language_output.numpy(), vis=bo.vision_output.numpy(), pooled=bo.pooled_output.numpy(),
+             feat_rows=head["feat"].reshape(B * 64, -1)[rows].numpy(),
+             feat_rowsum=head["feat"].reshape(B * 64, -1).double().sum(1).numpy(),
+             obj_rows_idx=rows, obj_rows=obj[rows].numpy(),
+             obj_lse=torch.logsumexp(obj.double(), 1).numpy(), obj_max=obj.max(1).values.numpy(),
+             obj_argmax=obj.argmax(1).numpy(), obj_rowsum=obj.double().sum(1).numpy())
+    for k in ("obj_loss", "feat_loss", "vis_loss", "total_loss"):
+        d[k] = out[k].detach().numpy()
+    d["grad_names"] = np.array(sorted(grads.keys()))
+    for k, g in grads.items():
+        d["gnorm:" + k] = np.array(g.double().norm().item())
+        if g.numel() <= 3072:
+            d["grad:" + k] = g.numpy()
+    np.savez_compressed(os.path.join(OUT, "config1.npz"), **d)
+    print("config1", {k: float(out[k]) for k in ("obj_loss", "feat_loss")}, "n_grads", len(grads))
+
+
+def gen_blocks(seed=77):
+    """Reference sub-modules called directly on random activations (localises a failure)."""
+    cfg = O.OracleConfig(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
+                         max_position_embeddings=32, l_layers=1, x_layers=1, r_layers=1,
+                         visual_feat_dim=32, num_clusters=50)
+    m, sd = build_reference(cfg, seed)
+    g = torch.Generator().manual_seed(seed)
+    B, L, V = 3, 7, 16
+    lang = torch.randn(B, L, 64, generator=g)
+    vis = torch.randn(B, V, 64, generator=g)
+    am = torch.ones(B, L)
+    am[1, 4:] = 0
+    am[2, 2:] = 0
+    mask_add = (1.0 - am[:, None, None, :]) * torch.finfo(torch.float32).min
+    enc = m.bert.encoder
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), lang=lang.numpy(), vis=vis.numpy(), am=am.numpy())
+    with torch.no_grad():
+        xl = enc.x_layers[0]
+        d["att_ll"] = enc.layer[0].attention.self(lang, lang, mask_add)[0].numpy()
+        d["att_vv"] = enc.r_layers[0].attention.self(vis, vis, None)[0].numpy()
+        d["att_lv"] = xl.visual_attention.att(lang, vis, None)[0].numpy()
+        d["att_vl"] = xl.visual_attention.att(vis, lang, mask_add)[0].numpy()
+        d["selfatt_l"] = enc.layer[0].attention(lang, mask_add)[0].numpy()
+        d["inter_l"] = enc.layer[0].intermediate(lang).numpy()
+        d["layer_l"] = enc.layer[0](lang, mask_add)[0].numpy()
+        d["layer_v"] = enc.r_layers[0](vis, None)[0].numpy()
+        xo = xl(lang, mask_add, vis, None)
+        d["x_lang"], d["x_vis"] = xo[0].numpy(), xo[1].numpy()
+        feats = torch.randn(B, V, 32, generator=g).relu()
+        pos = torch.from_numpy(O.box_position(4))[None].expand(B, -1, -1)
+        d["feats"], d["pos"] = feats.numpy(), pos.numpy()
+        d["visn_fc"] = enc.visn_fc(feats, pos).numpy()
+        ids = torch.randint(0, 100, (B, L), generator=g)
+        d["ids"] = ids.numpy()
+        d["emb"] = m.bert.embeddings(ids, torch.zeros_like(ids)).numpy()
+        d["pooler"] = m.bert.pooler(lang).numpy()
+        ho = m.obj_predict_head(vis, out_keys=["obj", "feat"])
+        d["head_feat"], d["head_obj"] = ho["feat"].numpy(), ho["obj"].numpy()
+        d["head_transform"] = m.obj_predict_head.transform(vis).numpy()
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **d)
+    print("blocks done")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    tiny = dict(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
+                max_position_embeddings=32, visual_feat_dim=32, num_clusters=50)
+    gen_blocks()
+    gen_tiny("tiny_222", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1234, B=3, L=8, grid=4)
+    gen_tiny("tiny_955", O.OracleConfig(l_layers=9, x_layers=5, r_layers=5, **tiny), seed=4321, B=2, L=8, grid=4,
+             store_grads=False)
+    gen_config1()

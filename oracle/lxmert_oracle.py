@@ -1,0 +1,401 @@
+"""CPU oracle for the X-LXMERT hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32 or fp64) restatement of the arithmetic the
+reference executes on the path named by BASELINE.json's north_star.  It is the
+checker for the HIP kernels; nothing in the product package (`xlxmert_amd/`)
+imports it.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
+`cpu_baseline` leg may import or execute it.
+
+Where the arithmetic lives.  The reference (`/root/reference/x-lxmert/src/lxrt/modeling.py`)
+imports its encoder from the un-vendored dependency `transformers`
+(pin: transformers==4.1.1, `/root/reference/requirements.txt:11`; the container
+has 5.15.0).  Citations below:
+  ref:<file>:<lines>  -> file under /root/reference/
+  HF:<lines>          -> transformers/models/lxmert/modeling_lxmert.py (5.15.0 as
+                         installed; the 4.1.1 math is identical on this path, see
+                         SURVEY.md section 8c)
+
+Parity pin.  The reference ships no tests or golden vectors ("parity unpinned" by
+the reference itself).  This restatement is pinned against outputs of the
+reference's own classes imported in the build container
+(`oracle/gen_golden.py` -> `tests/golden/*.npz`, checked by
+`tests/test_oracle_golden.py`).
+
+All functions take a flat state dict (`{name: tensor}` with the reference's key
+layout) and are differentiable through torch autograd, so
+the same restatement yields the gradient goldens.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class OracleConfig:
+    """Subset of LxmertConfig (HFcfg:72-101) that the path reads."""
+    vocab_size: int = 30522
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    l_layers: int = 9
+    x_layers: int = 5
+    r_layers: int = 5
+    visual_feat_dim: int = 2048
+    visual_pos_dim: int = 4
+    num_clusters: int = 10000
+    layer_norm_eps: float = 1e-12       # HF:188,273,335,460,464,580 (literal 1e-12)
+
+
+# --------------------------------------------------------------------------- inputs
+def box_position(grid_size: int = 8) -> np.ndarray:
+    """ref:x-lxmert/src/utils.py:75-85 -- (x0,y0,x1,y1) of each grid cell, row-major."""
+    n = grid_size * grid_size
+    boxes = np.zeros((n, 4), dtype=np.float32)
+    for i in range(grid_size):
+        for j in range(grid_size):
+            boxes[i * grid_size + j] = (j / grid_size, i / grid_size,
+                                        (j + 1) / grid_size, (i + 1) / grid_size)
+    return boxes
+
+
+def extended_mask(attention_mask: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """HF:758-766 -- [B,L] {0,1} -> additive [B,1,1,L]: (1-m)*finfo(dtype).min."""
+    m = attention_mask[:, None, None, :].to(dtype)
+    return (1.0 - m) * torch.finfo(dtype).min
+
+
+# --------------------------------------------------------------------------- blocks
+def _linear(sd, prefix, x):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def _layer_norm(sd, prefix, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def embeddings(sd, cfg, input_ids, token_type_ids, prefix="bert.embeddings"):
+    """HF:191-214 -- LN(word[ids] + pos[0..L-1] + type[tt]); dropout is identity (eval)."""
+    B, L = input_ids.shape
+    pos_ids = torch.arange(L, device=input_ids.device)[None, :].expand(B, L)
+    # all three tables are nn.Embedding(..., padding_idx=0) (HF:184-186): forward is a plain gather,
+    # but row 0 of each table receives NO gradient -- i.e. [PAD] word, position 0 ([CLS]) and
+    # token-type 0 (every token; ref lxmert_pretrain.py:200) are frozen rows.
+    e = (F.embedding(input_ids, sd[prefix + ".word_embeddings.weight"], padding_idx=0)
+         + F.embedding(pos_ids, sd[prefix + ".position_embeddings.weight"], padding_idx=0)
+         + F.embedding(token_type_ids, sd[prefix + ".token_type_embeddings.weight"], padding_idx=0))
+    return _layer_norm(sd, prefix + ".LayerNorm", e, cfg.layer_norm_eps)
+
+
+def attention(sd, cfg, prefix, hidden, context, mask_add=None):
+    """HF:238-266 -- multi-head softmax(QK^T/sqrt(dh) + mask) V, heads merged."""
+    H = cfg.num_attention_heads
+    dh = cfg.hidden_size // H
+    B, nq, _ = hidden.shape
+    nk = context.shape[1]
+    q = _linear(sd, prefix + ".query", hidden).view(B, nq, H, dh).transpose(1, 2)
+    k = _linear(sd, prefix + ".key", context).view(B, nk, H, dh).transpose(1, 2)
+    v = _linear(sd, prefix + ".value", context).view(B, nk, H, dh).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
+    if mask_add is not None:
+        s = s + mask_add
+    p = F.softmax(s, dim=-1)
+    o = torch.matmul(p, v)
+    return o.permute(0, 2, 1, 3).contiguous().view(B, nq, H * dh)
+
+
+def attention_output(sd, cfg, prefix, x, input_tensor):
+    """HF:276-280 -- LN(dense(x) + input)."""
+    return _layer_norm(sd, prefix + ".LayerNorm", _linear(sd, prefix + ".dense", x) + input_tensor,
+                       cfg.layer_norm_eps)
+
+
+def self_attention_layer(sd, cfg, prefix, x, mask_add):
+    """HF:304-316."""
+    return attention_output(sd, cfg, prefix + ".output",
+                            attention(sd, cfg, prefix + ".self", x, x, mask_add), x)
+
+
+def cross_attention_layer(sd, cfg, prefix, x, ctx, ctx_mask_add):
+    """HF:289-295."""
+    return attention_output(sd, cfg, prefix + ".output",
+                            attention(sd, cfg, prefix + ".att", x, ctx, ctx_mask_add), x)
+
+
+def intermediate(sd, cfg, prefix, x):
+    """HF:325-328 -- exact-erf GELU (ACT2FN['gelu'])."""
+    return F.gelu(_linear(sd, prefix + ".dense", x))
+
+
+def output(sd, cfg, prefix, h, input_tensor):
+    """HF:338-342."""
+    return _layer_norm(sd, prefix + ".LayerNorm", _linear(sd, prefix + ".dense", h) + input_tensor,
+                       cfg.layer_norm_eps)
+
+
+def lxmert_layer(sd, cfg, prefix, x, mask_add=None):
+    """HF:352-358 -- self-attention block then FFN block."""
+    a = self_attention_layer(sd, cfg, prefix + ".attention", x, mask_add)
+    return output(sd, cfg, prefix + ".output", intermediate(sd, cfg, prefix + ".intermediate", a), a)
+
+
+def x_layer(sd, cfg, prefix, lang, lang_mask_add, vis, vis_mask_add=None):
+    """HF:417-449 -- ONE shared `visual_attention` used in both directions, both reading
+    the pre-update inputs (HF:386-397); then per-stream self-attention and FFN."""
+    l1 = cross_attention_layer(sd, cfg, prefix + ".visual_attention", lang, vis, vis_mask_add)
+    v1 = cross_attention_layer(sd, cfg, prefix + ".visual_attention", vis, lang, lang_mask_add)
+    l2 = self_attention_layer(sd, cfg, prefix + ".lang_self_att", l1, lang_mask_add)
+    v2 = self_attention_layer(sd, cfg, prefix + ".visn_self_att", v1, vis_mask_add)
+    l3 = output(sd, cfg, prefix + ".lang_output", intermediate(sd, cfg, prefix + ".lang_inter", l2), l2)
+    v3 = output(sd, cfg, prefix + ".visn_output", intermediate(sd, cfg, prefix + ".visn_inter", v2), v2)
+    return l3, v3
+
+
+def visual_feature_encoder(sd, cfg, visual_feats, visual_pos, prefix="bert.encoder.visn_fc"):
+    """HF:468-476 -- (LN(Wf f + bf) + LN(Wp p + bp)) / 2."""
+    x = _layer_norm(sd, prefix + ".visn_layer_norm", _linear(sd, prefix + ".visn_fc", visual_feats),
+                    cfg.layer_norm_eps)
+    y = _layer_norm(sd, prefix + ".box_layer_norm", _linear(sd, prefix + ".box_fc", visual_pos),
+                    cfg.layer_norm_eps)
+    return (x + y) / 2
+
+
+def encoder(sd, cfg, lang, lang_mask_add, visual_feats, visual_pos, vis_mask_add=None,
+            prefix="bert.encoder", return_hidden=False):
+    """HF:498-557 -- visn_fc; l_layers x lang; r_layers x vis; x_layers x cross."""
+    vis = visual_feature_encoder(sd, cfg, visual_feats, visual_pos, prefix + ".visn_fc")
+    lang_h, vis_h = [], []
+    for i in range(cfg.l_layers):
+        lang = lxmert_layer(sd, cfg, f"{prefix}.layer.{i}", lang, lang_mask_add)
+        lang_h.append(lang)
+    for i in range(cfg.r_layers):
+        vis = lxmert_layer(sd, cfg, f"{prefix}.r_layers.{i}", vis, vis_mask_add)
+        vis_h.append(vis)
+    for i in range(cfg.x_layers):
+        lang, vis = x_layer(sd, cfg, f"{prefix}.x_layers.{i}", lang, lang_mask_add, vis, vis_mask_add)
+        lang_h.append(lang)
+        vis_h.append(vis)
+    if return_hidden:
+        return lang, vis, lang_h, vis_h
+    return lang, vis
+
+
+def pooler(sd, cfg, lang, prefix="bert.pooler"):
+    """HF:566-572 -- tanh(dense(lang[:,0]))."""
+    return torch.tanh(_linear(sd, prefix + ".dense", lang[:, 0]))
+
+
+def lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=None,
+                 token_type_ids=None, prefix="bert", return_hidden=False):
+    """HF:691-822 -- returns (language_output, vision_output, pooled_output).
+    `visual_attention_mask` is None in every reference caller
+    (ref:x-lxmert/src/pretrain/lxmert_pretrain.py:207)."""
+    dtype = sd[prefix + ".embeddings.word_embeddings.weight"].dtype
+    if attention_mask is None:
+        attention_mask = torch.ones_like(input_ids)
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(input_ids)
+    mask_add = extended_mask(attention_mask, dtype)
+    emb = embeddings(sd, cfg, input_ids, token_type_ids, prefix + ".embeddings")
+    out = encoder(sd, cfg, emb, mask_add, visual_feats.to(dtype), visual_pos.to(dtype), None,
+                  prefix + ".encoder", return_hidden)
+    lang, vis = out[0], out[1]
+    pooled = pooler(sd, cfg, lang, prefix + ".pooler")
+    if return_hidden:
+        return lang, vis, pooled, out[2], out[3]
+    return lang, vis, pooled
+
+
+# --------------------------------------------------------------------------- head + losses
+def head_transform(sd, cfg, x, prefix="obj_predict_head.transform"):
+    """HF:582-586 -- LN(gelu(dense(x)))."""
+    return _layer_norm(sd, prefix + ".LayerNorm", F.gelu(_linear(sd, prefix + ".dense", x)),
+                       cfg.layer_norm_eps)
+
+
+def visual_obj_head(sd, cfg, vis, prefix="obj_predict_head"):
+    """ref:x-lxmert/src/lxrt/modeling.py:38-53 (cluster mode) -- returns (feat, obj_logits).
+    out_cluster.weight is the frozen centroid matrix (tied, ref :150-151)."""
+    h = head_transform(sd, cfg, vis, prefix + ".transform")
+    feat = _linear(sd, prefix + ".linear_feat", h)
+    obj = F.linear(feat, sd[prefix + ".out_cluster.weight"], sd[prefix + ".out_cluster.bias"])
+    return feat, obj
+
+
+def codebook_features(sd, cluster_ids, vis_mask=None):
+    """ref:x-lxmert/src/lxrt/modeling.py:185-193 -- centroid lookup + [MASK]-feature substitution."""
+    feats = sd["vis_emb.weight"][cluster_ids]
+    if vis_mask is not None:
+        B, V = cluster_ids.shape
+        feats = torch.where(vis_mask.view(B, V, 1).bool(),
+                            sd["mask_feat"].view(1, 1, -1).to(feats.dtype), feats)
+    return feats
+
+
+def vis_mask_losses(cfg, feat, obj, obj_labels, feat_labels, vis_mask):
+    """ref:x-lxmert/src/lxrt/modeling.py:237-290 -- CE(mean over labels != -100) + masked
+    SmoothL1 feature regression."""
+    B, V, K = obj.shape
+    obj_loss = F.cross_entropy(obj.view(B * V, K), obj_labels.flatten())          # ignore_index=-100
+    fl = F.smooth_l1_loss(feat, feat_labels.view(B, V, -1), reduction="none").mean(dim=2)
+    fl = (fl * vis_mask).sum(dim=1)
+    n_mask = vis_mask.sum(dim=1).clamp(min=1)
+    feat_loss = (fl / n_mask).mean()
+    return obj_loss, feat_loss
+
+
+def xlxmert_vis_mask_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, vis_mask,
+                             obj_labels, feat_labels=None, token_type_ids=None, return_all=False):
+    """ref:x-lxmert/src/lxrt/modeling.py:154-308, task == 'vis_mask'.
+    `feat_labels` defaults to the un-masked centroid features (ref lxmert_pretrain.py:177-179)."""
+    feats = codebook_features(sd, cluster_ids, vis_mask)
+    lang, vis, pooled = lxmert_model(sd, cfg, input_ids, feats, visual_pos, attention_mask, token_type_ids)
+    feat, obj = visual_obj_head(sd, cfg, vis)
+    if feat_labels is None:
+        feat_labels = sd["vis_emb.weight"][cluster_ids]
+    obj_loss, feat_loss = vis_mask_losses(cfg, feat, obj, obj_labels, feat_labels, vis_mask)
+    out = {"obj_loss": obj_loss, "feat_loss": feat_loss, "vis_loss": obj_loss + feat_loss,
+           "total_loss": obj_loss + feat_loss}
+    if return_all:
+        out.update(lang=lang, vis=vis, pooled=pooled, feat=feat, obj=obj)
+    return out
+
+
+# --------------------------------------------------------------------------- step semantics
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ semantics (ref lxmert_pretrain.py:343-353):
+    total L2 norm; scale = max_norm/(norm+1e-6) clamped to <= 1."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return total, [g * coef for g in grads]
+
+
+def adamw_update(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.0,
+                 correct_bias=True):
+    """transformers==4.1.1 `optimization.AdamW.step` (the class no longer exists in 5.15.0;
+    SURVEY.md section 8a row A16).  eps is added to sqrt(v) BEFORE bias correction; decoupled
+    weight decay is applied AFTER the Adam update with the plain lr.  Returns (p, m, v)."""
+    m = m * beta1 + g * (1.0 - beta1)
+    v = v * beta2 + g * g * (1.0 - beta2)
+    denom = v.sqrt() + eps
+    step_size = lr
+    if correct_bias:
+        step_size = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    p = p - step_size * (m / denom)
+    if weight_decay > 0.0:
+        p = p - lr * weight_decay * p
+    return p, m, v
+
+
+def linear_schedule(step, warmup_steps, total_steps):
+    """transformers.get_linear_schedule_with_warmup lambda (ref lxmert_pretrain.py:138-139)."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))
+
+
+# --------------------------------------------------------------------------- deterministic weights
+def param_shapes(cfg: OracleConfig):
+    """State-dict layout on the path, in a fixed order."""
+    d, dff, F_, K = cfg.hidden_size, cfg.intermediate_size, cfg.visual_feat_dim, cfg.num_clusters
+    out = [("mask_feat", (F_,)), ("vis_emb.weight", (K, F_)),
+           ("bert.embeddings.word_embeddings.weight", (cfg.vocab_size, d)),
+           ("bert.embeddings.position_embeddings.weight", (cfg.max_position_embeddings, d)),
+           ("bert.embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, d)),
+           ("bert.embeddings.LayerNorm.weight", (d,)), ("bert.embeddings.LayerNorm.bias", (d,)),
+           ("bert.encoder.visn_fc.visn_fc.weight", (d, F_)), ("bert.encoder.visn_fc.visn_fc.bias", (d,)),
+           ("bert.encoder.visn_fc.visn_layer_norm.weight", (d,)), ("bert.encoder.visn_fc.visn_layer_norm.bias", (d,)),
+           ("bert.encoder.visn_fc.box_fc.weight", (d, cfg.visual_pos_dim)), ("bert.encoder.visn_fc.box_fc.bias", (d,)),
+           ("bert.encoder.visn_fc.box_layer_norm.weight", (d,)), ("bert.encoder.visn_fc.box_layer_norm.bias", (d,))]
+
+    def att(p, self_name):
+        r = []
+        for n in ("query", "key", "value"):
+            r += [(f"{p}.{self_name}.{n}.weight", (d, d)), (f"{p}.{self_name}.{n}.bias", (d,))]
+        r += [(f"{p}.output.dense.weight", (d, d)), (f"{p}.output.dense.bias", (d,)),
+              (f"{p}.output.LayerNorm.weight", (d,)), (f"{p}.output.LayerNorm.bias", (d,))]
+        return r
+
+    def ffn(pi, po):
+        return [(f"{pi}.dense.weight", (dff, d)), (f"{pi}.dense.bias", (dff,)),
+                (f"{po}.dense.weight", (d, dff)), (f"{po}.dense.bias", (d,)),
+                (f"{po}.LayerNorm.weight", (d,)), (f"{po}.LayerNorm.bias", (d,))]
+
+    for stack, n in (("layer", cfg.l_layers), ("r_layers", cfg.r_layers)):
+        for i in range(n):
+            p = f"bert.encoder.{stack}.{i}"
+            out += att(p + ".attention", "self") + ffn(p + ".intermediate", p + ".output")
+    for i in range(cfg.x_layers):
+        p = f"bert.encoder.x_layers.{i}"
+        out += att(p + ".visual_attention", "att") + att(p + ".lang_self_att", "self") + att(p + ".visn_self_att", "self")
+        out += ffn(p + ".lang_inter", p + ".lang_output") + ffn(p + ".visn_inter", p + ".visn_output")
+    out += [("bert.pooler.dense.weight", (d, d)), ("bert.pooler.dense.bias", (d,)),
+            ("obj_predict_head.transform.dense.weight", (d, d)), ("obj_predict_head.transform.dense.bias", (d,)),
+            ("obj_predict_head.transform.LayerNorm.weight", (d,)), ("obj_predict_head.transform.LayerNorm.bias", (d,)),
+            ("obj_predict_head.linear_feat.weight", (F_, d)), ("obj_predict_head.linear_feat.bias", (F_,)),
+            ("obj_predict_head.out_cluster.bias", (K,))]
+    return out
+
+
+def make_state_dict(cfg: OracleConfig, seed: int, perturb: bool = True, dtype=torch.float32):
+    """Deterministic weights from numpy's PCG64 stream (stable across numpy versions), so that
+    fixtures need to store only the seed.  `perturb=False` gives the reference init
+    (N(0,0.02) matrices, LN (1,0), zero biases, zero mask_feat); `perturb=True` also
+    randomises biases / LN affine / mask_feat so that every term is exercised.
+    Centroids = relu(N(0,1))."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, shape in param_shapes(cfg):
+        if name == "vis_emb.weight":
+            w = np.maximum(rng.standard_normal(shape, dtype=np.float32), 0.0)
+        elif name.endswith("LayerNorm.weight") or name.endswith("layer_norm.weight"):
+            w = np.ones(shape, np.float32)
+            if perturb:
+                w += 0.1 * rng.standard_normal(shape, dtype=np.float32)
+        elif len(shape) == 1:
+            w = np.zeros(shape, np.float32)
+            if perturb:
+                w += 0.05 * rng.standard_normal(shape, dtype=np.float32)
+        else:
+            w = 0.02 * rng.standard_normal(shape, dtype=np.float32)
+        sd[name] = torch.from_numpy(w).to(dtype)
+    sd["obj_predict_head.out_cluster.weight"] = sd["vis_emb.weight"]      # tied (ref modeling.py:150-151)
+    return sd
+
+
+def make_inputs(cfg: OracleConfig, seed: int, B: int, L: int = 20, grid: int = 8, ragged: bool = True,
+                mask_mode: str = "predict"):
+    """Synthetic batch with the reference's layout:
+    input_ids [B,L] int64 ([CLS]=101 first, [SEP]=102 last real, 0 = PAD), attention_mask = ids > 0,
+    cluster_ids [B,V] int64, vis_mask [B,V] bool (`predict`: n_masks ~ U{1..V} per example,
+    ref lxmert_data.py:414-419; `bernoulli`: p=0.15, ref :457-458), obj_labels = cluster_ids with
+    -100 where unmasked (ref lxmert_pretrain.py:163-166), visual_pos = box_position(grid)."""
+    rng = np.random.default_rng(seed)
+    V = grid * grid
+    lo = min(1000, cfg.vocab_size // 2)
+    ids = rng.integers(lo, cfg.vocab_size, size=(B, L), dtype=np.int64)
+    ids[:, 0] = min(101, cfg.vocab_size - 2)
+    for b in range(B):
+        n = int(rng.integers(min(6, L), L + 1)) if ragged else L
+        ids[b, n - 1] = min(102, cfg.vocab_size - 1)
+        ids[b, n:] = 0
+    cid = rng.integers(0, cfg.num_clusters, size=(B, V), dtype=np.int64)
+    vm = np.zeros((B, V), dtype=bool)
+    for b in range(B):
+        if mask_mode == "predict":
+            n = int(rng.integers(1, V + 1))
+            vm[b, rng.permutation(V)[:n]] = True
+        else:
+            vm[b] = rng.random(V) < 0.15
+    lab = cid.copy()
+    lab[~vm] = -100
+    pos = np.broadcast_to(box_position(grid)[None], (B, V, 4)).copy()
+    t = torch.from_numpy
+    return {"input_ids": t(ids), "attention_mask": t(ids > 0), "token_type_ids": torch.zeros(B, L, dtype=torch.long),
+            "cluster_ids": t(cid), "vis_mask": t(vm), "obj_labels": t(lab), "visual_pos": t(pos)}
