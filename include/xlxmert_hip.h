@@ -1,0 +1,168 @@
+/*
+ * xlxmert_hip.h -- C ABI of libxlxmert_hip.so: the MI355X (gfx950) kernels behind the
+ * X-LXMERT hot path (LxmertEncoder stack + masked-visual-token head, data-parallel training step).
+ *
+ * The reference has no FFI seam on this path: the seam is the Python nn.Module API
+ * (SURVEY.md section 8b).  Each entry point below replaces the aten op sequence the reference
+ * launches at the cited site ("HF:" = transformers/models/lxmert/modeling_lxmert.py, the
+ * un-vendored dependency where the arithmetic lives; "ref:" = /root/reference/...).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch types.  All pointers are DEVICE pointers to
+ *     caller-owned, 16-byte-aligned memory; the library never allocates tensor memory.
+ *   - every call is asynchronous on the caller-supplied hipStream_t (passed as void*).
+ *   - return 0 on success, negative XL_ERR_* otherwise; xl_last_error() gives the text.
+ *   - dtype: activation / compute-weight element type.  XL_F32 = exact-fp32 path (parity
+ *     config, fp32 FMA / fp32 accumulate); XL_BF16 = bf16 operands, fp32 accumulate on MFMA.
+ *     LayerNorm statistics, softmax, losses, gradients of parameters, optimizer state: always fp32.
+ *   - "ld*" are leading dimensions in ELEMENTS.
+ */
+#ifndef XLXMERT_HIP_H
+#define XLXMERT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XL_F32  0
+#define XL_BF16 1
+
+#define XL_OK             0
+#define XL_ERR_BAD_SHAPE -1
+#define XL_ERR_BAD_DTYPE -2
+#define XL_ERR_UNALIGNED -3
+#define XL_ERR_HIP       -4
+#define XL_ERR_BAD_ARG   -5
+
+/* GEMM epilogues */
+#define XL_EPI_NONE     0   /* C = acc (+bias)                                                      */
+#define XL_EPI_GELU     1   /* aux = acc+bias (pre-activation, saved); C = gelu_erf(aux)   HF:325-328 */
+#define XL_EPI_RESIDUAL 2   /* C = dropout(acc+bias) + residual                   HF:276-279, 338-341 */
+#define XL_EPI_DGELU    3   /* C = acc * gelu_erf'(aux)          (backward of XL_EPI_GELU)            */
+#define XL_EPI_TANH     4   /* C = tanh(acc+bias)                                        HF:566-572   */
+
+const char* xl_last_error(void);
+int  xl_version(void);
+/* 1: GEMM/SDPA transposed operands use ds_read_b64_tr_b16; 0: 16-bit LDS gathers (debug switch) */
+int  xl_set_lds_transpose_read(int enable);
+
+/* ---------------------------------------------------------------- dense contractions (nn.Linear)
+ * C[M,N] = alpha * sum_k A(m,k) * B(n,k)  [+ bias[n]]  -> epilogue
+ *   a_kmajor: 1 -> A stored [M][K] (lda >= K);  0 -> A stored [K][M] (lda >= M)
+ *   b_kmajor: 1 -> B stored [N][K] (ldb >= K);  0 -> B stored [K][N] (ldb >= N)
+ *   forward  y = x W^T + b         (HF:232-234,277,326,339,469; ref lxrt/modeling.py:42,47): a_kmajor=1,b_kmajor=1
+ *   backward dx = dy W                                                                      : a_kmajor=1,b_kmajor=0
+ *   backward dW = dy^T x  (fp32 out, accumulate!=0 adds into C; split-K uses fp32 atomics)  : a_kmajor=0,b_kmajor=0
+ *   in_dtype: element type of A,B,residual,aux.  out_dtype: element type of C (XL_F32 allowed with bf16 inputs).
+ *   bias: fp32 [N] or NULL.  residual/aux: [M,N] with ldr/ldx or NULL.
+ *   dropout (XL_EPI_RESIDUAL only): keep-prob (1-p_drop), mask = hash(seed, m*N+n); p_drop=0 disables.
+ */
+int xl_gemm(const void* A, const void* B, void* C, const float* bias,
+            const void* residual, void* aux,
+            int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldx,
+            int a_kmajor, int b_kmajor, int in_dtype, int out_dtype,
+            int epilogue, float alpha, int accumulate,
+            float p_drop, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm (eps inside sqrt, HF:188 et al.)
+ * y = (x-mean)*rstd*gamma+beta over the last dim N; saves mean,rstd (fp32 [M]).  */
+int xl_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                     float* mean, float* rstd, int M, int N, float eps, int dtype, void* stream);
+/* dx from dy; dgamma/dbeta (fp32 [N]) are ACCUMULATED (atomics).  If dbias_prev != NULL it also
+ * accumulates colsum(dx) (= bias gradient of the dense layer feeding this LayerNorm). */
+int xl_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                     const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev,
+                     int M, int N, int dtype, void* stream);
+
+/* visual feature encoder tail (HF:468-476): y = (LN_v(xv) + LN_b(pos W_b^T + b_b)) / 2
+ * xv = visn_fc output [M,N]; pos fp32 [M,P] (P<=8); box weights fp32 [N,P].
+ * saves mean/rstd of both LayerNorms and the box pre-LN row is recomputed in backward. */
+int xl_visn_ln_fwd(const void* xv, const float* pos, const float* wbox, const float* bbox,
+                   const float* gv, const float* bv, const float* gb, const float* bb,
+                   void* y, float* mean_v, float* rstd_v, float* mean_b, float* rstd_b,
+                   int M, int N, int P, float eps, int dtype, void* stream);
+int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, const float* wbox, const float* bbox,
+                   const float* gv, const float* gb,
+                   const float* mean_v, const float* rstd_v, const float* mean_b, const float* rstd_b,
+                   void* dxv, float* dgv, float* dbv, float* dgb, float* dbb,
+                   float* dwbox, float* dbbox, float* dbias_visn,
+                   int M, int N, int P, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- embeddings (HF:191-214)
+ * y[b,l] = LN(word[ids[b,l]] + pos[l] + type[tt[b,l]]); tables in `dtype`; saves pre-LN sum + stats. */
+int xl_embed_ln_fwd(const int64_t* ids, const int64_t* tt, const void* word, const void* pos,
+                    const void* type, const float* gamma, const float* beta,
+                    void* y, void* pre, float* mean, float* rstd,
+                    int B, int L, int N, float eps, int dtype, void* stream);
+/* scatter-add of d(pre) into the fp32 table gradients.  Row 0 of every table is frozen
+ * (nn.Embedding(padding_idx=0), HF:184-186). */
+int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t* tt,
+                 float* dword, float* dpos, float* dtype_tab, int B, int L, int N, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- codebook input (ref lxrt/modeling.py:185-193)
+ * feats[b,v,:] = vis_mask[b,v] ? mask_feat : centroids[cluster_ids[b,v]]   (centroids in `dtype`) */
+int xl_codebook_gather(const int64_t* cluster_ids, const uint8_t* vis_mask, const void* centroids,
+                       const float* mask_feat, void* feats, int M, int F, int dtype, void* stream);
+/* out[n] += sum over rows m with mask[m]!=0 of x[m,n]    (d mask_feat pre-image; also generic masked colsum) */
+int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, int dtype, void* stream);
+/* out[n] += sum_m x[m,n]   (bias gradients) */
+int xl_colsum(const void* x, float* out, int M, int N, int ldx, int dtype, void* stream);
+
+/* dx = dy * gelu_erf'(pre), n elements (head transform backward, HF:582-586) */
+int xl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- attention core (HF:247-263)
+ * per (b,h): O = softmax(Q K^T * scale, keys with key_mask==0 excluded) V ; nq,nk <= 64.
+ * q/k/v/o are [B, n, H*dh]-shaped views with row strides ldq/ldk/ldv/ldo (elements); head h
+ * occupies columns [h*dh, (h+1)*dh).  key_mask: uint8 [B,nk] or NULL.  lse: fp32 [B,H,nq]
+ * (log-sum-exp of the scaled scores) saved for backward.  Probability dropout (HF:258):
+ * p_drop with mask hash(seed, ((b*H+h)*nq+q)*nk+key). */
+int xl_sdpa_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
+                void* o, float* lse, int B, int H, int nq, int nk, int dh,
+                int ldq, int ldk, int ldv, int ldo, float scale,
+                float p_drop, uint64_t seed, int dtype, void* stream);
+int xl_sdpa_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
+                const void* dout, const float* lse,
+                void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
+                int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
+                float p_drop, uint64_t seed, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- head losses (ref lxrt/modeling.py:237-290)
+ * counts[0] = #labels != -100 ; nmask[b] = sum_v vis_mask[b,v]            (device-side, no host sync) */
+int xl_mask_counts(const int64_t* labels, const uint8_t* vis_mask, float* counts, float* nmask,
+                   int B, int V, void* stream);
+/* CrossEntropyLoss(ignore_index=-100, mean): logits fp32 [M,K] (ldl); loss_out[0] += sum_rows nll / count;
+ * dlogits (`dtype`, lddl) = (softmax - onehot) * grad_scale / count for valid rows, 0 otherwise.
+ * Also writes per-row lse / argmax (fp32 / int32, may be NULL) for the sampler. */
+int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const float* counts,
+                  void* dlogits, float* loss_out, float* row_lse, int32_t* row_argmax, float* row_maxprob,
+                  int M, int K, int ldl, int lddl, float grad_scale, int dtype, void* stream);
+/* masked SmoothL1 feature regression: target row = centroids[cluster_ids[m]] (never masked);
+ * loss_out[0] += mean_b( sum_v mask*mean_F sl1 / max(nmask_b,1) ); dpred written for every row. */
+int xl_featloss_fwd_bwd(const void* pred, const void* centroids, const int64_t* cluster_ids,
+                        const uint8_t* vis_mask, const float* nmask, void* dpred, float* loss_out,
+                        int B, int V, int F, float grad_scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- optimizer side (ref lxmert_pretrain.py:343-364)
+ * sumsq[0] += sum g^2 over n fp32 elements */
+int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream);
+/* transformers==4.1.1 AdamW on flat fp32 buffers with fused gradient clipping:
+ * clip = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) (max_norm<=0 disables), g' = g*clip*grad_scale;
+ * decay_flags: uint8 per 256-element chunk (1 = apply weight decay).  lr_and_steps (device, fp32[4]):
+ * {lr, bias_corr1 = 1-beta1^t, bias_corr2 = 1-beta2^t, unused}.  Writes the compute copy
+ * (`dtype`) of every updated parameter to p_compute (may be NULL). */
+int xl_adamw(float* p, const float* g, float* m, float* v, void* p_compute,
+             const uint8_t* decay_flags, const float* sumsq, const float* lr_and_steps,
+             int64_t n, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+             float grad_scale, int dtype, void* stream);
+/* dst (`dtype`) = src (fp32), n elements */
+int xl_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
+/* dst (fp32) = src (`dtype`) */
+int xl_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""TEST INFRASTRUCTURE: a host-memory stand-in for xlxmert_amd.ops.HipOps with the same method signatures,
+written with plain torch CPU math (the argument conventions of include/xlxmert_hip.h, nothing else).
+
+It exists so that the engine's kernel *sequencing* (forward chain, hand-derived backward chain, buffer/stride
+bookkeeping, gradient placement) can be checked against the oracle in the GPU-less build container.  It is never
+importable from the product package and is not a fallback: `xlxmert_amd` only ever constructs HipOps.
+"""
+import math
+
+import torch
+
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH = 0, 1, 2, 3, 4
+
+
+def v2(t, rows, cols, ld):
+    return torch.as_strided(t, (rows, cols), (ld, 1))
+
+
+def gelu_grad(x):
+    cdf = 0.5 * (1.0 + torch.erf(x * 0.7071067811865476))
+    pdf = 0.3989422804014327 * torch.exp(-0.5 * x * x)
+    return cdf + x * pdf
+
+
+class FakeOps:
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.calls = []
+
+    def set_lds_transpose_read(self, enable):
+        pass
+
+    def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
+             out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0):
+        self.calls.append(("gemm", M, N, K, a_kmajor, b_kmajor, epilogue))
+        assert p_drop == 0.0
+        a = (v2(A, M, K, lda) if a_kmajor else v2(A, K, M, lda).t()).float()
+        b = (v2(B, N, K, ldb) if b_kmajor else v2(B, K, N, ldb).t()).float()
+        acc = alpha * (a @ b.t())
+        if bias is not None:
+            acc = acc + torch.as_strided(bias, (N,), (1,)).float()[None, :]
+        if epilogue == EPI_GELU:
+            v2(aux, M, N, ldx).copy_(acc)
+            acc = torch.nn.functional.gelu(acc)
+        elif epilogue == EPI_RESIDUAL:
+            acc = acc + v2(residual, M, N, ldr).float()
+        elif epilogue == EPI_DGELU:
+            acc = acc * gelu_grad(v2(aux, M, N, ldx).float())
+        elif epilogue == EPI_TANH:
+            acc = torch.tanh(acc)
+        c = v2(C, M, N, ldc)
+        if out_f32:
+            assert C.dtype == torch.float32
+        if accumulate:
+            c.add_(acc)
+        else:
+            c.copy_(acc)
+
+    @staticmethod
+    def _ln(x, g, b, eps):
+        mean = x.mean(1, keepdim=True)
+        var = ((x - mean) ** 2).mean(1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        return (x - mean) * rstd * g + b, mean[:, 0], rstd[:, 0]
+
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, N, eps):
+        o, m, r = self._ln(v2(x, M, N, N).float(), gamma.float(), beta.float(), eps)
+        v2(y, M, N, N).copy_(o)
+        mean[:M].copy_(m)
+        rstd[:M].copy_(r)
+
+    @staticmethod
+    def _ln_bwd(dy, x, g, mean, rstd):
+        xh = (x - mean[:, None]) * rstd[:, None]
+        gd = dy * g
+        c1 = gd.mean(1, keepdim=True)
+        c2 = (gd * xh).mean(1, keepdim=True)
+        dx = rstd[:, None] * (gd - c1 - xh * c2)
+        return dx, (dy * xh).sum(0), dy.sum(0)
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N):
+        d, dg, db = self._ln_bwd(v2(dy, M, N, N).float(), v2(x, M, N, N).float(), gamma.float(), mean[:M], rstd[:M])
+        v2(dx, M, N, N).copy_(d)
+        dgamma.add_(dg)
+        dbeta.add_(db)
+        if dbias_prev is not None:
+            dbias_prev.add_(v2(dx, M, N, N).float().sum(0) if False else d.sum(0))
+
+    def visn_ln_fwd(self, xv, pos, wbox, bbox, gv, bv, gb, bb, y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps):
+        a, mv, rv = self._ln(v2(xv, M, N, N).float(), gv, bv, eps)
+        box = pos.view(M, P) @ wbox.view(N, P).t() + bbox
+        b, mb, rb = self._ln(box, gb, bb, eps)
+        v2(y, M, N, N).copy_((a + b) / 2)
+        mean_v.copy_(mv); rstd_v.copy_(rv); mean_b.copy_(mb); rstd_b.copy_(rb)
+
+    def visn_ln_bwd(self, dy, xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b, dxv, dgv, dbv, dgb, dbb,
+                    dwbox, dbbox, dbias_visn, M, N, P):
+        dh = v2(dy, M, N, N).float() * 0.5
+        d1, dg1, db1 = self._ln_bwd(dh, v2(xv, M, N, N).float(), gv, mean_v, rstd_v)
+        box = pos.view(M, P) @ wbox.view(N, P).t() + bbox
+        d2, dg2, db2 = self._ln_bwd(dh, box, gb, mean_b, rstd_b)
+        v2(dxv, M, N, N).copy_(d1)
+        dgv.add_(dg1); dbv.add_(db1); dgb.add_(dg2); dbb.add_(db2)
+        dwbox.add_(d2.t() @ pos.view(M, P))
+        dbbox.add_(d2.sum(0))
+        if dbias_visn is not None:
+            dbias_visn.add_(d1.sum(0))
+
+    def embed_ln_fwd(self, ids, tt, word, pos, type_, gamma, beta, y, pre, mean, rstd, B, L, N, eps):
+        M = B * L
+        p = (word[ids.view(-1)].float() + pos[torch.arange(L).repeat(B)].float() + type_[tt.view(-1)].float())
+        v2(pre, M, N, N).copy_(p)
+        o, m, r = self._ln(v2(pre, M, N, N).float(), gamma, beta, eps)
+        v2(y, M, N, N).copy_(o)
+        mean.copy_(m); rstd.copy_(r)
+
+    def embed_bwd(self, dpre, ids, tt, dword, dpos, dtype_tab, B, L, N):
+        M = B * L
+        d = v2(dpre, M, N, N).float()
+        idf, ttf = ids.view(-1), tt.view(-1)
+        lf = torch.arange(L).repeat(B)
+        dword.index_add_(0, idf[idf != 0], d[idf != 0])
+        dpos.index_add_(0, lf[lf != 0], d[lf != 0])
+        dtype_tab.index_add_(0, ttf[ttf != 0], d[ttf != 0])
+
+    def codebook_gather(self, cluster_ids, vis_mask, centroids, mask_feat, feats, M, F):
+        f = centroids[cluster_ids.view(-1)].float()
+        if vis_mask is not None:
+            f = torch.where(vis_mask.view(-1, 1) != 0, mask_feat.view(1, -1), f)
+        v2(feats, M, F, F).copy_(f)
+
+    def masked_colsum(self, x, mask, out, M, N, ldx):
+        xx = v2(x, M, N, ldx).float()
+        out[:N].add_((xx * (mask.view(-1, 1) != 0)).sum(0))
+
+    def colsum(self, x, out, M, N, ldx):
+        torch.as_strided(out, (N,), (1,)).add_(v2(x, M, N, ldx).float().sum(0))
+
+    def gelu_bwd(self, dy, pre, dx, n):
+        dx.view(-1)[:n].copy_(dy.reshape(-1)[:n].float() * gelu_grad(pre.reshape(-1)[:n].float()))
+
+    @staticmethod
+    def _heads(t, B, n, H, dh, ld):
+        return torch.as_strided(t, (B, H, n, dh), (n * ld, dh, ld, 1))
+
+    def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
+        assert p_drop == 0.0
+        Q, K_, V_ = (self._heads(t, B, n, H, dh, ld).float() for t, n, ld in ((q, nq, ldq), (k, nk, ldk), (v, nk, ldv)))
+        s = Q @ K_.transpose(-1, -2) * scale
+        if key_mask is not None:
+            s = s.masked_fill(key_mask.view(B, 1, 1, nk) == 0, float("-inf"))
+        lse.view(B, H, nq).copy_(torch.logsumexp(s, -1))
+        self._heads(o, B, nq, H, dh, ldo).copy_(torch.softmax(s, -1) @ V_)
+
+    def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
+                 lddv, scale, p_drop=0.0, seed=0):
+        Q, K_, V_, dO = (self._heads(t, B, n, H, dh, ld).float()
+                         for t, n, ld in ((q, nq, ldq), (k, nk, ldk), (v, nk, ldv), (dout, nq, ldo)))
+        s = Q @ K_.transpose(-1, -2) * scale
+        p = torch.exp(s - lse.view(B, H, nq, 1))
+        if key_mask is not None:
+            p = p.masked_fill(key_mask.view(B, 1, 1, nk) == 0, 0.0)
+        dp = dO @ V_.transpose(-1, -2)
+        delta = (p * dp).sum(-1, keepdim=True)
+        ds = p * (dp - delta) * scale
+        self._heads(dq, B, nq, H, dh, lddq).copy_(ds @ K_)
+        self._heads(dk, B, nk, H, dh, lddk).copy_(ds.transpose(-1, -2) @ Q)
+        self._heads(dv, B, nk, H, dh, lddv).copy_(p.transpose(-1, -2) @ dO)
+
+    def mask_counts(self, labels, vis_mask, counts, nmask, B, V):
+        counts[0] = (labels != -100).sum().float()
+        nmask.copy_((vis_mask.view(B, V) != 0).sum(1).float())
+
+    def ce_fwd_bwd(self, logits, labels, counts, dlogits, loss_out, row_lse, row_argmax, row_maxprob, M, K, ldl, lddl,
+                   grad_scale=1.0):
+        lg = v2(logits, M, K, ldl)
+        lse = torch.logsumexp(lg, 1)
+        if row_lse is not None:
+            row_lse.copy_(lse)
+        if row_argmax is not None:
+            row_argmax.copy_(lg.argmax(1).int())
+        if row_maxprob is not None:
+            row_maxprob.copy_(torch.exp(lg.max(1).values - lse))
+        if labels is None:
+            return
+        lab = labels.view(-1)
+        valid = lab != -100
+        cnt = counts[0].clamp(min=1)
+        safe = lab.clamp(min=0)
+        nll = (lse - lg.gather(1, safe[:, None])[:, 0]) * valid
+        if loss_out is not None:
+            loss_out[0] += nll.sum() / cnt
+        if dlogits is not None:
+            g = torch.softmax(lg, 1)
+            g[torch.arange(M), safe] -= 1.0
+            g = g * valid[:, None] * (grad_scale / cnt)
+            v2(dlogits, M, K, lddl).copy_(g)
+
+    def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F, grad_scale=1.0):
+        M = B * V
+        p = v2(pred, M, F, F).float()
+        t = centroids[cluster_ids.view(-1)].float()
+        d = p - t
+        sl1 = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5).mean(1)
+        w = (vis_mask.view(-1) != 0).float() / (nmask.clamp(min=1).repeat_interleave(V) * B)
+        if loss_out is not None:
+            loss_out[0] += (w * sl1).sum()
+        if dpred is not None:
+            v2(dpred, M, F, F).copy_(grad_scale * w[:, None] / F * d.clamp(-1, 1))
+
+    def sumsq(self, g, out, n):
+        out[0] += (g[:n].double() ** 2).sum().float()
+
+    def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
+              max_norm, grad_scale=1.0):
+        lr, bc1, bc2 = (float(x) for x in lr_and_steps[:3])
+        clip = grad_scale
+        if max_norm > 0 and sumsq is not None:
+            norm = math.sqrt(float(sumsq[0])) * grad_scale
+            clip *= min(1.0, max_norm / (norm + 1e-6))
+        gg = g[:n] * clip
+        m[:n].mul_(beta1).add_(gg, alpha=1 - beta1)
+        v[:n].mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        step = lr * math.sqrt(bc2) / bc1
+        p[:n].addcdiv_(m[:n], v[:n].sqrt() + eps, value=-step)
+        if weight_decay > 0 and decay_flags is not None:
+            dec = decay_flags.repeat_interleave(256)[:n] != 0
+            p[:n][dec] -= lr * weight_decay * p[:n][dec]
+        if p_compute is not None and p_compute.data_ptr() != p.data_ptr():
+            p_compute[:n].copy_(p[:n])
+
+    def cast_from_f32(self, src, dst, n):
+        if dst.data_ptr() != src.data_ptr():
+            dst.view(-1)[:n].copy_(src.view(-1)[:n])
+
+    def cast_to_f32(self, src, dst, n):
+        dst.view(-1)[:n].copy_(src.view(-1)[:n])

@@ -1,0 +1,73 @@
+"""ctypes binding of libxlxmert_hip.so.  Signatures are parsed from include/xlxmert_hip.h so that the
+Python side cannot drift from the C ABI.  There is NO fallback: if the library cannot be loaded the
+import of any compute path raises."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "xlxmert_hip.h")
+LIB_PATH = os.path.join(HERE, "libxlxmert_hip.so")
+
+_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(argtype, argname), ...])} for every `xl_*` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(xl_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                alist.append((mm.group(1).strip(), mm.group(2)))
+        protos[name] = ("char*" if "char" in ret else "int", alist)
+    return protos
+
+
+def _ctype(t):
+    if "*" in t:
+        return ctypes.c_void_p
+    t = t.replace("const", "").strip()
+    return _CTYPES[t]
+
+
+class XlError(RuntimeError):
+    pass
+
+
+class Lib:
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise XlError(f"{path} not found: build it first (python -m xlxmert_amd.build, or __graft_entry__.build()). "
+                          "There is no CPU / eager fallback for the X-LXMERT hot path.")
+        self._dll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(self._dll, name)        # raises AttributeError if the .so lacks a declared symbol
+            fn.argtypes = [_ctype(t) for t, _ in args]
+            fn.restype = ctypes.c_char_p if ret == "char*" else ctypes.c_int
+        self.path = path
+
+    def call(self, name, *args):
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            raise XlError(f"{name} failed ({rc}): {self._dll.xl_last_error().decode()}")
+
+    def raw(self, name):
+        return getattr(self._dll, name)
+
+
+_LIB = None
+
+
+def get_lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib()
+    return _LIB

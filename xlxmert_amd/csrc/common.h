@@ -1,0 +1,125 @@
+// Shared device/host helpers for libxlxmert_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/xlxmert_hip.h"
+
+namespace xl {
+
+typedef uint16_t bf16_t;          // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;    // MFMA A/B fragment (8 bf16)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ------------------------------------------------------------------ error plumbing
+void set_error(const char* fmt, ...);
+#define XL_CHECK_ARG(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            xl::set_error(__VA_ARGS__);          \
+            return (code);                       \
+        }                                        \
+    } while (0)
+#define XL_CHECK_LAUNCH()                                                          \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            xl::set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__,        \
+                          hipGetErrorString(e__));                                 \
+            return XL_ERR_HIP;                                                     \
+        }                                                                          \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------ bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even (NaN kept quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;                 // elements per 16-byte access
+    __device__ static float ld(const float* p) { return *p; }
+    __device__ static void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte vector load/store of VEC elements as fp32 registers
+__device__ __forceinline__ void ldvec(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void stvec(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void ldvec(const bf16_t* p, float (&v)[8]) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void stvec(bf16_t* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = pack2bf(v[0], v[1]); t.y = pack2bf(v[2], v[3]);
+    t.z = pack2bf(v[4], v[5]); t.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+
+// ------------------------------------------------------------------ wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------ math
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ------------------------------------------------------------------ counter-based dropout
+// keep-mask for element `idx` under (seed): two rounds of a 64->32 bit mixer (splitmix64 finaliser).
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 16);
+}
+// returns 1/(1-p) if kept, 0 if dropped
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
+    const uint32_t r = hash_u32(seed, idx);
+    const uint32_t thr = (uint32_t)(p_drop * 4294967296.0f);
+    return r >= thr ? inv_keep : 0.0f;
+}
+
+extern int g_use_tr_read;   // set by xl_set_lds_transpose_read
+
+}  // namespace xl

@@ -1,0 +1,142 @@
+// Optimizer-side kernels (HBM-bound streams over the flat parameter buffers) and library plumbing.
+//   grad-norm (ref lxmert_pretrain.py:343-353), transformers==4.1.1 AdamW (ref :110-141), dtype casts.
+#include <stdarg.h>
+#include "common.h"
+
+namespace xl {
+
+static thread_local char g_err[512] = "";
+int g_use_tr_read = 1;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* out, int64_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// one thread = 4 consecutive parameters (n is padded to a multiple of 256 by the caller's layout)
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, T* __restrict__ pc, const uint8_t* __restrict__ decay,
+                                                    const float* __restrict__ sumsq, const float* __restrict__ lrs, int64_t n4,
+                                                    float beta1, float beta2, float eps, float wd, float max_norm, float gscale) {
+    const float lr = lrs[0], bc1 = lrs[1], bc2 = lrs[2];
+    float clip = gscale;
+    if (max_norm > 0.f && sumsq != nullptr) {
+        const float norm = sqrtf(sumsq[0]) * gscale;
+        clip *= fminf(1.0f, max_norm / (norm + 1e-6f));
+    }
+    const float step = lr * sqrtf(bc2) / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        const bool dec = wd > 0.f && decay != nullptr && decay[i >> 6] != 0;       // 256-element chunks
+        float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+        float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = ga[j] * clip;
+            ma[j] = ma[j] * beta1 + gg * (1.0f - beta1);
+            va[j] = va[j] * beta2 + gg * gg * (1.0f - beta2);
+            pa[j] -= step * (ma[j] / (sqrtf(va[j]) + eps));
+            if (dec) pa[j] -= lr * wd * pa[j];
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+        if (pc != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Elem<T>::st(pc + i * 4 + j, pa[j]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) Elem<T>::st(dst + i, src[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = Elem<T>::ld(src + i);
+}
+
+static inline int stream_grid(int64_t work_items) {
+    int64_t b = (work_items + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace xl
+
+using namespace xl;
+
+extern "C" const char* xl_last_error(void) { return g_err; }
+extern "C" int xl_version(void) { return 1; }
+extern "C" int xl_set_lds_transpose_read(int enable) { g_use_tr_read = enable ? 1 : 0; return XL_OK; }
+
+extern "C" int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream) {
+    XL_CHECK_ARG(g && sumsq && n > 0 && aligned16(g), XL_ERR_BAD_ARG, "xl_sumsq: bad args");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, g, sumsq, n);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_adamw(float* p, const float* g, float* m, float* v, void* p_compute,
+                        const uint8_t* decay_flags, const float* sumsq, const float* lr_and_steps,
+                        int64_t n, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                        float grad_scale, int dtype, void* stream) {
+    XL_CHECK_ARG(p && g && m && v && lr_and_steps, XL_ERR_BAD_ARG, "xl_adamw: null pointer");
+    XL_CHECK_ARG(n > 0 && n % 256 == 0, XL_ERR_BAD_SHAPE, "xl_adamw: n=%lld must be a positive multiple of 256", (long long)n);
+    XL_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), XL_ERR_UNALIGNED, "xl_adamw: unaligned buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n4 = n >> 2;
+    if (dtype == XL_BF16)
+        hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_compute,
+                           decay_flags, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
+    else if (dtype == XL_F32)
+        hipLaunchKernelGGL((adamw_kernel<float>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (float*)p_compute,
+                           decay_flags, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
+    else { set_error("xl_adamw: bad dtype %d", dtype); return XL_ERR_BAD_DTYPE; }
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+    XL_CHECK_ARG(src && dst && n > 0, XL_ERR_BAD_ARG, "xl_cast_from_f32: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XL_BF16) hipLaunchKernelGGL((cast_from_f32_kernel<bf16_t>), dim3(stream_grid(n)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    else if (dtype == XL_F32) hipLaunchKernelGGL((cast_from_f32_kernel<float>), dim3(stream_grid(n)), dim3(256), 0, st, src, (float*)dst, n);
+    else { set_error("xl_cast_from_f32: bad dtype %d", dtype); return XL_ERR_BAD_DTYPE; }
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream) {
+    XL_CHECK_ARG(src && dst && n > 0, XL_ERR_BAD_ARG, "xl_cast_to_f32: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XL_BF16) hipLaunchKernelGGL((cast_to_f32_kernel<bf16_t>), dim3(stream_grid(n)), dim3(256), 0, st, (const bf16_t*)src, dst, n);
+    else if (dtype == XL_F32) hipLaunchKernelGGL((cast_to_f32_kernel<float>), dim3(stream_grid(n)), dim3(256), 0, st, (const float*)src, dst, n);
+    else { set_error("xl_cast_to_f32: bad dtype %d", dtype); return XL_ERR_BAD_DTYPE; }
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}

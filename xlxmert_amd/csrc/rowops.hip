@@ -1,0 +1,716 @@
+// HBM-bound row kernels of the X-LXMERT path: LayerNorm fwd/bwd, visual-feature-encoder tail,
+// embeddings, codebook gather, column sums, cross-entropy / SmoothL1 heads.
+// All are "one wave (64 lanes) per row, 16-byte accesses per lane" kernels; statistics in fp32.
+#include "common.h"
+
+namespace xl {
+
+constexpr int WPB = 4;   // waves (rows) per 256-thread block
+
+template <typename T, int NIT>
+__device__ __forceinline__ void load_row(const T* row, int N, int lane, float (&v)[NIT][Elem<T>::VEC]) {
+    constexpr int VEC = Elem<T>::VEC;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N) ldvec(row + col, v[it]);
+        else
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[it][i] = 0.f;
+    }
+}
+
+template <int NIT, int VEC>
+__device__ __forceinline__ void row_stats(const float (&v)[NIT][VEC], int N, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s += v[it][i];
+    mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { const float d = v[it][i] - mean; q += d * d; }
+    }
+    const float var = wave_sum(q) / (float)N;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+// ------------------------------------------------------------------ LayerNorm forward
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     int M, int N, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[NIT][VEC];
+    load_row<T, NIT>(x + (size_t)row * N, N, lane, v);
+    float mean, rstd;
+    row_stats<NIT, VEC>(v, N, lane, eps, mean, rstd);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N) {
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o[i] = (v[it][i] - mean) * rstd * gamma[col + i] + beta[col + i];
+            stvec(y + (size_t)row * N + col, o);
+        }
+    }
+}
+
+// per-lane column partials -> block reduce over the 4 waves -> atomics
+template <int NIT, int VEC>
+__device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out, int N, float* red /*[WPB][64*VEC]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) red[(wave * 64 + lane) * VEC + i] = acc[it][i];
+        __syncthreads();
+        if (wave == 0) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WPB; ++w) s += red[(w * 64 + lane) * VEC + i];
+                    atomicAdd(out + col + i, s);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, T* __restrict__ dx,
+                                                     float* dgamma, float* dbeta, float* dbias_prev, int M, int N) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[WPB * 64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ag[NIT][VEC] = {}, ab[NIT][VEC] = {}, ax[NIT][VEC] = {};
+    float g[NIT][VEC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[it][i] = (col < N) ? gamma[col + i] : 0.f;
+    }
+    for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
+        float xv[NIT][VEC], dv[NIT][VEC];
+        load_row<T, NIT>(x + (size_t)row * N, N, lane, xv);
+        load_row<T, NIT>(dy + (size_t)row * N, N, lane, dv);
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float xh = (xv[it][i] - mean) * rstd;
+                    const float gd = g[it][i] * dv[it][i];
+                    xv[it][i] = xh;
+                    s1 += gd; s2 += gd * xh;
+                    ag[it][i] += dv[it][i] * xh;
+                    ab[it][i] += dv[it][i];
+                }
+        }
+        const float c1 = wave_sum(s1) / (float)N, c2 = wave_sum(s2) / (float)N;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N) {
+                float o[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    o[i] = rstd * (g[it][i] * dv[it][i] - c1 - xv[it][i] * c2);
+                    ax[it][i] += o[i];
+                }
+                stvec(dx + (size_t)row * N + col, o);
+            }
+        }
+    }
+    flush_colsums<NIT, VEC>(ag, dgamma, N, red);
+    flush_colsums<NIT, VEC>(ab, dbeta, N, red);
+    if (dbias_prev != nullptr) flush_colsums<NIT, VEC>(ax, dbias_prev, N, red);
+}
+
+// ------------------------------------------------------------------ visual feature encoder tail (HF:468-476)
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void visn_ln_fwd_kernel(const T* __restrict__ xv, const float* __restrict__ pos,
+                                                          const float* __restrict__ wbox, const float* __restrict__ bbox,
+                                                          const float* __restrict__ gv, const float* __restrict__ bv,
+                                                          const float* __restrict__ gb, const float* __restrict__ bb,
+                                                          T* __restrict__ y, float* mean_v, float* rstd_v,
+                                                          float* mean_b, float* rstd_b, int M, int N, int P, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[NIT][VEC], bx[NIT][VEC];
+    load_row<T, NIT>(xv + (size_t)row * N, N, lane, v);
+    float pr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pr[q] = q < P ? pos[(size_t)row * P + q] : 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float s = 0.f;
+            if (col < N) {
+                s = bbox[col + i];
+                for (int q = 0; q < P; ++q) s = fmaf(pr[q], wbox[(size_t)(col + i) * P + q], s);
+            }
+            bx[it][i] = s;
+        }
+    }
+    float mv, rv, mb, rb;
+    row_stats<NIT, VEC>(v, N, lane, eps, mv, rv);
+    row_stats<NIT, VEC>(bx, N, lane, eps, mb, rb);
+    if (lane == 0) { mean_v[row] = mv; rstd_v[row] = rv; mean_b[row] = mb; rstd_b[row] = rb; }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N) {
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float a = (v[it][i] - mv) * rv * gv[col + i] + bv[col + i];
+                const float b = (bx[it][i] - mb) * rb * gb[col + i] + bb[col + i];
+                o[i] = (a + b) / 2;
+            }
+            stvec(y + (size_t)row * N + col, o);
+        }
+    }
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void visn_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xv,
+                                                          const float* __restrict__ pos, const float* __restrict__ wbox,
+                                                          const float* __restrict__ bbox, const float* __restrict__ gv,
+                                                          const float* __restrict__ gb, const float* __restrict__ mean_v,
+                                                          const float* __restrict__ rstd_v, const float* __restrict__ mean_b,
+                                                          const float* __restrict__ rstd_b, T* __restrict__ dxv,
+                                                          float* dgv, float* dbv, float* dgb, float* dbb, float* dwbox,
+                                                          float* dbbox, float* dbias_visn, int M, int N, int P) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[WPB * 64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float agv[NIT][VEC] = {}, abv[NIT][VEC] = {}, agb[NIT][VEC] = {}, abx[NIT][VEC] = {}, axv[NIT][VEC] = {};
+    float aw[NIT][VEC][4] = {};          // d(box_fc.weight) partials for pos dims 0..3 (P<=4 stays in registers)
+    for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
+        float v[NIT][VEC], d[NIT][VEC], bx[NIT][VEC];
+        load_row<T, NIT>(xv + (size_t)row * N, N, lane, v);
+        load_row<T, NIT>(dy + (size_t)row * N, N, lane, d);
+        float pr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pr[q] = q < P ? pos[(size_t)row * P + q] : 0.f;
+        const float mv = mean_v[row], rv = rstd_v[row], mb = mean_b[row], rb = rstd_b[row];
+        float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if (col < N) {
+                    float s = bbox[col + i];
+                    for (int q = 0; q < P; ++q) s = fmaf(pr[q], wbox[(size_t)(col + i) * P + q], s);
+                    const float dh = d[it][i] * 0.5f;            // d(LN out) of either branch
+                    const float xh = (v[it][i] - mv) * rv, bh = (s - mb) * rb;
+                    v[it][i] = xh; bx[it][i] = bh; d[it][i] = dh;
+                    const float g1 = gv[col + i] * dh, g2 = gb[col + i] * dh;
+                    s1 += g1; s2 += g1 * xh; t1 += g2; t2 += g2 * bh;
+                    agv[it][i] += dh * xh; abv[it][i] += dh; agb[it][i] += dh * bh;
+                } else { v[it][i] = 0.f; bx[it][i] = 0.f; d[it][i] = 0.f; }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)N, c2 = wave_sum(s2) / (float)N;
+        const float e1 = wave_sum(t1) / (float)N, e2 = wave_sum(t2) / (float)N;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N) {
+                float o[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    o[i] = rv * (gv[col + i] * d[it][i] - c1 - v[it][i] * c2);
+                    axv[it][i] += o[i];
+                    const float dbx = rb * (gb[col + i] * d[it][i] - e1 - bx[it][i] * e2);   // d(box pre-LN)
+                    abx[it][i] += dbx;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) aw[it][i][q] += dbx * pr[q];
+                    for (int q = 4; q < P; ++q) atomicAdd(dwbox + (size_t)(col + i) * P + q, dbx * pr[q]);
+                }
+                stvec(dxv + (size_t)row * N + col, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < P) atomicAdd(dwbox + (size_t)(col + i) * P + q, aw[it][i][q]);
+    }
+    flush_colsums<NIT, VEC>(agv, dgv, N, red);
+    flush_colsums<NIT, VEC>(abv, dbv, N, red);
+    flush_colsums<NIT, VEC>(agb, dgb, N, red);
+    flush_colsums<NIT, VEC>(abv, dbb, N, red);      // d(beta_box) = sum dh (same as d(beta_v))
+    flush_colsums<NIT, VEC>(abx, dbbox, N, red);
+    if (dbias_visn != nullptr) flush_colsums<NIT, VEC>(axv, dbias_visn, N, red);
+}
+
+// ------------------------------------------------------------------ embeddings
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tt,
+                                                           const T* __restrict__ word, const T* __restrict__ pos,
+                                                           const T* __restrict__ type, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y,
+                                                           T* __restrict__ pre, float* mean_o, float* rstd_o,
+                                                           int M, int L, int N, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t id = ids[row], ty = tt ? tt[row] : 0;
+    const int l = row % L;
+    float v[NIT][VEC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N) {
+            float a[VEC], b[VEC], c[VEC];
+            ldvec(word + (size_t)id * N + col, a);
+            ldvec(pos + (size_t)l * N + col, b);
+            ldvec(type + (size_t)ty * N + col, c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[it][i] = a[i] + b[i] + c[i];
+            stvec(pre + (size_t)row * N + col, v[it]);
+            // LayerNorm sees what was stored (bf16 mode: the rounded sum), so backward is consistent
+            ldvec(pre + (size_t)row * N + col, v[it]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[it][i] = 0.f;
+        }
+    }
+    float mean, rstd;
+    row_stats<NIT, VEC>(v, N, lane, eps, mean, rstd);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N) {
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o[i] = (v[it][i] - mean) * rstd * gamma[col + i] + beta[col + i];
+            stvec(y + (size_t)row * N + col, o);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ ids,
+                                                        const int64_t* __restrict__ tt, float* dword, float* dpos,
+                                                        float* dtype_tab, int M, int L, int N) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t id = ids[row], ty = tt ? tt[row] : 0;
+    const int l = row % L;
+    for (int col = lane * VEC; col < N; col += 64 * VEC) {
+        float d[VEC];
+        ldvec(dpre + (size_t)row * N + col, d);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            if (id != 0) atomicAdd(dword + (size_t)id * N + col + i, d[i]);     // padding_idx=0 rows are frozen
+            if (l != 0) atomicAdd(dpos + (size_t)l * N + col + i, d[i]);
+            if (ty != 0) atomicAdd(dtype_tab + (size_t)ty * N + col + i, d[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ codebook gather + [MASK] substitution
+template <typename T>
+__global__ __launch_bounds__(256) void codebook_gather_kernel(const int64_t* __restrict__ cid, const uint8_t* __restrict__ mask,
+                                                              const T* __restrict__ cent, const float* __restrict__ mask_feat,
+                                                              T* __restrict__ feats, int M, int F) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bool masked = mask != nullptr && mask[row] != 0;
+    const T* src = cent + (size_t)cid[row] * F;
+    for (int col = lane * VEC; col < F; col += 64 * VEC) {
+        float v[VEC];
+        if (masked) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = mask_feat[col + i];
+        } else ldvec(src + col, v);
+        stvec(feats + (size_t)row * F + col, v);
+    }
+}
+
+// out[n] += sum_{m (masked)} x[m,n]; grid (col blocks, row chunks)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                     float* out, int M, int N, int ldx, int rows_per_block) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[WPB * 64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * VEC;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc[1][VEC] = {};
+    if (col < N)
+        for (int row = r0 + wave; row < r1; row += WPB) {
+            if (mask != nullptr && mask[row] == 0) continue;
+            float v[VEC];
+            ldvec(x + (size_t)row * ldx + col, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[0][i] += v[i];
+        }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[(wave * 64 + lane) * VEC + i] = acc[0][i];
+    __syncthreads();
+    if (wave == 0 && col < N)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) s += red[(w * 64 + lane) * VEC + i];
+            atomicAdd(out + col + i, s);
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ dx, int64_t nvec) {
+    constexpr int VEC = Elem<T>::VEC;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float a[VEC], b[VEC], o[VEC];
+        ldvec(dy + i * VEC, a);
+        ldvec(pre + i * VEC, b);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = a[j] * gelu_erf_grad(b[j]);
+        stvec(dx + i * VEC, o);
+    }
+}
+
+// ------------------------------------------------------------------ head losses
+__global__ __launch_bounds__(256) void mask_counts_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ vis_mask,
+                                                          float* counts, float* nmask, int B, int V) {
+    __shared__ float red[4];
+    float c = 0.f;
+    for (int i = threadIdx.x; i < B * V; i += 256) c += labels[i] != -100 ? 1.f : 0.f;
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[0] = red[0] + red[1] + red[2] + red[3];
+    for (int b = threadIdx.x >> 6; b < B; b += 4) {
+        float s = 0.f;
+        for (int v = threadIdx.x & 63; v < V; v += 64) s += vis_mask[b * V + v] ? 1.f : 0.f;
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) nmask[b] = s;
+    }
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// one 256-thread block per row of fp32 logits
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 const float* __restrict__ counts, T* __restrict__ dlogits,
+                                                 float* loss_out, float* row_lse, int32_t* row_argmax, float* row_maxprob,
+                                                 int M, int K, int ldl, int lddl, float grad_scale) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int row = blockIdx.x;
+    const int64_t lab = labels ? labels[row] : -100;
+    const bool valid = lab >= 0 && lab < K;
+    const bool want_aux = row_lse != nullptr || row_argmax != nullptr || row_maxprob != nullptr;
+    const float* lr = logits + (size_t)row * ldl;
+    if (!valid && !want_aux) {
+        if (dlogits) for (int k = threadIdx.x; k < K; k += 256) Elem<T>::st(dlogits + (size_t)row * lddl + k, 0.f);
+        return;
+    }
+    float mx = -INFINITY; int am = 0;
+    for (int k = threadIdx.x; k < K; k += 256) { const float v = lr[k]; if (v > mx) { mx = v; am = k; } }
+    const float bm = block_max(mx, red);
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) s += __expf(lr[k] - bm);
+    const float tot = block_sum(s, red);
+    const float lse = bm + logf(tot);
+    if (want_aux) {
+        // argmax: smallest index among the maxima (torch.max semantics)
+        int cand = (mx == bm) ? am : 0x7fffffff;
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cand;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (row_argmax) row_argmax[row] = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            if (row_lse) row_lse[row] = lse;
+            if (row_maxprob) row_maxprob[row] = 1.0f / tot;      // exp(max - lse)
+        }
+    }
+    if (valid) {
+        const float inv_count = 1.0f / fmaxf(counts[0], 1.0f);
+        if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, (lse - lr[lab]) * inv_count);
+        if (dlogits) {
+            const float sc = grad_scale * inv_count;
+            for (int k = threadIdx.x; k < K; k += 256) {
+                float g = __expf(lr[k] - lse);
+                if (k == (int)lab) g -= 1.0f;
+                Elem<T>::st(dlogits + (size_t)row * lddl + k, g * sc);
+            }
+        }
+    } else if (dlogits) {
+        for (int k = threadIdx.x; k < K; k += 256) Elem<T>::st(dlogits + (size_t)row * lddl + k, 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pred, const T* __restrict__ cent,
+                                                       const int64_t* __restrict__ cid, const uint8_t* __restrict__ mask,
+                                                       const float* __restrict__ nmask, T* __restrict__ dpred,
+                                                       float* loss_out, int B, int V, int F, float grad_scale) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= B * V) return;
+    const int b = row / V;
+    const float w = mask[row] ? 1.0f / (fmaxf(nmask[b], 1.0f) * (float)B) : 0.f;
+    const T* tgt = cent + (size_t)cid[row] * F;
+    float s = 0.f;
+    for (int col = lane * VEC; col < F; col += 64 * VEC) {
+        float p[VEC], t[VEC], g[VEC];
+        ldvec(pred + (size_t)row * F + col, p);
+        ldvec(tgt + col, t);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float d = p[i] - t[i], ad = fabsf(d);
+            s += ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+            g[i] = grad_scale * w / (float)F * fminf(fmaxf(d, -1.0f), 1.0f);
+        }
+        if (dpred) stvec(dpred + (size_t)row * F + col, g);
+    }
+    s = wave_sum(s);
+    if (lane == 0 && w != 0.f && loss_out) atomicAdd(loss_out, w * s / (float)F);
+}
+
+}  // namespace xl
+
+using namespace xl;
+
+#define DISPATCH_T(dtype, ...)                                                      \
+    {                                                                               \
+        if ((dtype) == XL_F32) { typedef float T; __VA_ARGS__ }                     \
+        else if ((dtype) == XL_BF16) { typedef bf16_t T; __VA_ARGS__ }              \
+        else { xl::set_error("bad dtype %d", (int)(dtype)); return XL_ERR_BAD_DTYPE; } \
+    }
+
+// NIT = ceil(N / (64*VEC)) rounded to {1,2,4,8}
+#define DISPATCH_NIT(T, N, ...)                                                     \
+    {                                                                               \
+        const int per__ = 64 * Elem<T>::VEC;                                        \
+        const int nit__ = ((N) + per__ - 1) / per__;                                \
+        if (nit__ <= 1) { constexpr int NIT = 1; __VA_ARGS__ }                      \
+        else if (nit__ <= 2) { constexpr int NIT = 2; __VA_ARGS__ }                 \
+        else if (nit__ <= 4) { constexpr int NIT = 4; __VA_ARGS__ }                 \
+        else if (nit__ <= 8) { constexpr int NIT = 8; __VA_ARGS__ }                 \
+        else { xl::set_error("row length %d too large", (int)(N)); return XL_ERR_BAD_SHAPE; } \
+    }
+
+static inline int vec_of(int dtype) { return dtype == XL_F32 ? 4 : 8; }
+#define CHECK_ROW(N, dtype) XL_CHECK_ARG((N) > 0 && (N) % vec_of(dtype) == 0, XL_ERR_BAD_SHAPE, \
+                                         "%s: row length %d must be a multiple of %d", __func__, (int)(N), vec_of(dtype))
+
+extern "C" int xl_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                                float* mean, float* rstd, int M, int N, float eps, int dtype, void* stream) {
+    CHECK_ROW(N, dtype);
+    XL_CHECK_ARG(M > 0 && x && y && gamma && beta && mean && rstd, XL_ERR_BAD_ARG, "xl_layernorm_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+        hipLaunchKernelGGL((ln_fwd_kernel<T, NIT>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                           (const T*)x, gamma, beta, (T*)y, mean, rstd, M, N, eps);));
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev,
+                                int M, int N, int dtype, void* stream) {
+    CHECK_ROW(N, dtype);
+    XL_CHECK_ARG(M > 0 && dy && x && gamma && mean && rstd && dx && dgamma && dbeta, XL_ERR_BAD_ARG, "xl_layernorm_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = min((M + WPB - 1) / WPB, 1024);
+    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+        hipLaunchKernelGGL((ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
+                           (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N);));
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_visn_ln_fwd(const void* xv, const float* pos, const float* wbox, const float* bbox,
+                              const float* gv, const float* bv, const float* gb, const float* bb,
+                              void* y, float* mean_v, float* rstd_v, float* mean_b, float* rstd_b,
+                              int M, int N, int P, float eps, int dtype, void* stream) {
+    CHECK_ROW(N, dtype);
+    XL_CHECK_ARG(P >= 1 && P <= 8, XL_ERR_BAD_SHAPE, "xl_visn_ln_fwd: pos dim %d not in 1..8", P);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+        hipLaunchKernelGGL((visn_ln_fwd_kernel<T, NIT>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                           (const T*)xv, pos, wbox, bbox, gv, bv, gb, bb, (T*)y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps);));
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, const float* wbox, const float* bbox,
+                              const float* gv, const float* gb,
+                              const float* mean_v, const float* rstd_v, const float* mean_b, const float* rstd_b,
+                              void* dxv, float* dgv, float* dbv, float* dgb, float* dbb,
+                              float* dwbox, float* dbbox, float* dbias_visn,
+                              int M, int N, int P, int dtype, void* stream) {
+    CHECK_ROW(N, dtype);
+    XL_CHECK_ARG(P >= 1 && P <= 8, XL_ERR_BAD_SHAPE, "xl_visn_ln_bwd: pos dim %d not in 1..8", P);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = min((M + WPB - 1) / WPB, 256);
+    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+        hipLaunchKernelGGL((visn_ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
+                           (const T*)dy, (const T*)xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b,
+                           (T*)dxv, dgv, dbv, dgb, dbb, dwbox, dbbox, dbias_visn, M, N, P);));
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_embed_ln_fwd(const int64_t* ids, const int64_t* tt, const void* word, const void* pos,
+                               const void* type, const float* gamma, const float* beta,
+                               void* y, void* pre, float* mean, float* rstd,
+                               int B, int L, int N, float eps, int dtype, void* stream) {
+    CHECK_ROW(N, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = B * L;
+    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+        hipLaunchKernelGGL((embed_ln_fwd_kernel<T, NIT>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                           ids, tt, (const T*)word, (const T*)pos, (const T*)type, gamma, beta, (T*)y, (T*)pre,
+                           mean, rstd, M, L, N, eps);));
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t* tt,
+                            float* dword, float* dpos, float* dtype_tab, int B, int L, int N, int dtype, void* stream) {
+    CHECK_ROW(N, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = B * L;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                           (const T*)dpre, ids, tt, dword, dpos, dtype_tab, M, L, N););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_codebook_gather(const int64_t* cluster_ids, const uint8_t* vis_mask, const void* centroids,
+                                  const float* mask_feat, void* feats, int M, int F, int dtype, void* stream) {
+    CHECK_ROW(F, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((codebook_gather_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                           cluster_ids, vis_mask, (const T*)centroids, mask_feat, (T*)feats, M, F););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+static int colsum_impl(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, int dtype, void* stream) {
+    XL_CHECK_ARG(N % vec_of(dtype) == 0 && ldx % vec_of(dtype) == 0, XL_ERR_BAD_SHAPE,
+                 "xl_colsum: N=%d / ldx=%d must be multiples of %d", N, ldx, vec_of(dtype));
+    hipStream_t st = (hipStream_t)stream;
+    const int per = 64 * vec_of(dtype);
+    const int rows_per_block = 128;
+    dim3 grid((N + per - 1) / per, (M + rows_per_block - 1) / rows_per_block);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, mask, out, M, N, ldx, rows_per_block););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+extern "C" int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, int dtype, void* stream) {
+    return colsum_impl(x, mask, out, M, N, ldx, dtype, stream);
+}
+extern "C" int xl_colsum(const void* x, float* out, int M, int N, int ldx, int dtype, void* stream) {
+    return colsum_impl(x, nullptr, out, M, N, ldx, dtype, stream);
+}
+
+extern "C" int xl_mask_counts(const int64_t* labels, const uint8_t* vis_mask, float* counts, float* nmask,
+                              int B, int V, void* stream) {
+    hipLaunchKernelGGL(mask_counts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, labels, vis_mask, counts, nmask, B, V);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const float* counts,
+                             void* dlogits, float* loss_out, float* row_lse, int32_t* row_argmax, float* row_maxprob,
+                             int M, int K, int ldl, int lddl, float grad_scale, int dtype, void* stream) {
+    XL_CHECK_ARG(M > 0 && K > 0 && ldl >= K && logits, XL_ERR_BAD_SHAPE, "xl_ce_fwd_bwd: bad shape");
+    if (labels) XL_CHECK_ARG(counts != nullptr, XL_ERR_BAD_ARG, "xl_ce_fwd_bwd: counts missing");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((ce_kernel<T>), dim3(M), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+                           row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_featloss_fwd_bwd(const void* pred, const void* centroids, const int64_t* cluster_ids,
+                                   const uint8_t* vis_mask, const float* nmask, void* dpred, float* loss_out,
+                                   int B, int V, int F, float grad_scale, int dtype, void* stream) {
+    CHECK_ROW(F, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = B * V;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((featloss_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                           (const T*)pred, (const T*)centroids, cluster_ids, vis_mask, nmask, (T*)dpred, loss_out, B, V, F, grad_scale););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream) {
+    XL_CHECK_ARG(dy && pre && dx && n > 0 && n % vec_of(dtype) == 0, XL_ERR_BAD_SHAPE, "xl_gelu_bwd: n=%lld must be a multiple of %d",
+                 (long long)n, vec_of(dtype));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nvec = n / vec_of(dtype);
+    int64_t grid = (nvec + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3((int)grid), dim3(256), 0, st, (const T*)dy, (const T*)pre, (T*)dx, nvec););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}

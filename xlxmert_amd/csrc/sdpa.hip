@@ -1,0 +1,597 @@
+// Attention core of LxmertAttention (HF:247-263) for the four (nq,nk) shapes of the path
+// ({20,64} x {20,64}): one wavefront per (batch, head) problem, everything on chip.
+//
+//   sdpa_*_generic<T>   exact-fp32 arithmetic (XL_F32 parity path; also any dh <= 64), one lane per query row.
+//   sdpa_*_mfma         bf16 operands on v_mfma_f32_32x32x16_bf16.  The scores are computed TRANSPOSED
+//                       (S^T = K Q^T) so that a lane owns one query column: softmax needs a single
+//                       lane^32 exchange, and the probabilities are already laid out as the B operand of
+//                       O^T = V^T P^T (no cross-lane movement).  Q/K/dO fragments with the contraction
+//                       along dh are read straight from global memory (16 B per lane); operands that are
+//                       contracted along the sequence (V^T, K^T, Q^T, dO^T) are staged once in LDS and
+//                       gathered (ds_read_b64_tr_b16 or 16-bit reads).  The k-slot <-> index mapping of the
+//                       MFMA is applied identically to both operands.
+#include "common.h"
+
+namespace xl {
+
+constexpr int MAXN = 64;   // nq, nk <= 64 (8x8 grid, <=20 text tokens)
+
+// ================================================================== generic (fp32 math)
+template <typename T>
+__global__ __launch_bounds__(64) void sdpa_fwd_generic(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                       const uint8_t* __restrict__ key_mask, T* __restrict__ o,
+                                                       float* __restrict__ lse, int H, int nq, int nk, int dh,
+                                                       int ldq, int ldk, int ldv, int ldo, float scale,
+                                                       float p_drop, float inv_keep, uint64_t seed) {
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int qi = threadIdx.x;
+    if (qi >= nq) return;
+    const T* qr = q + (size_t)(b * nq + qi) * ldq + h * dh;
+    float qv[MAXN], s[MAXN], acc[MAXN];
+    for (int d = 0; d < dh; ++d) { qv[d] = Elem<T>::ld(qr + d); acc[d] = 0.f; }
+    float mx = -INFINITY;
+    for (int j = 0; j < nk; ++j) {
+        const T* kr = k + (size_t)(b * nk + j) * ldk + h * dh;
+        float d0 = 0.f;
+        for (int d = 0; d < dh; ++d) d0 = fmaf(qv[d], Elem<T>::ld(kr + d), d0);
+        d0 *= scale;
+        if (key_mask && !key_mask[b * nk + j]) d0 = -INFINITY;
+        s[j] = d0;
+        mx = fmaxf(mx, d0);
+    }
+    if (mx == -INFINITY) mx = 0.f;
+    float sum = 0.f;
+    for (int j = 0; j < nk; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < nk; ++j) {
+        float p = s[j] * inv;
+        if (p_drop > 0.f) p *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + j, p_drop, inv_keep);
+        const T* vr = v + (size_t)(b * nk + j) * ldv + h * dh;
+        for (int d = 0; d < dh; ++d) acc[d] = fmaf(p, Elem<T>::ld(vr + d), acc[d]);
+    }
+    T* orow = o + (size_t)(b * nq + qi) * ldo + h * dh;
+    for (int d = 0; d < dh; ++d) Elem<T>::st(orow + d, acc[d]);
+    lse[(size_t)bh * nq + qi] = mx + logf(sum);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                       const uint8_t* __restrict__ key_mask, const T* __restrict__ dout,
+                                                       const float* __restrict__ lse, T* __restrict__ dq, T* __restrict__ dk,
+                                                       T* __restrict__ dv, int H, int nq, int nk, int dh,
+                                                       int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                                                       float scale, float p_drop, float inv_keep, uint64_t seed) {
+    __shared__ float sdk[MAXN * MAXN];
+    __shared__ float sdv[MAXN * MAXN];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int qi = threadIdx.x;
+    for (int i = threadIdx.x; i < nk * dh; i += 64) { sdk[i] = 0.f; sdv[i] = 0.f; }
+    __syncthreads();
+    if (qi < nq) {
+        const T* qr = q + (size_t)(b * nq + qi) * ldq + h * dh;
+        const T* dor = dout + (size_t)(b * nq + qi) * ldo + h * dh;
+        float qv[MAXN], dov[MAXN], dqv[MAXN], p[MAXN], dp[MAXN];
+        for (int d = 0; d < dh; ++d) { qv[d] = Elem<T>::ld(qr + d); dov[d] = Elem<T>::ld(dor + d); dqv[d] = 0.f; }
+        const float l = lse[(size_t)bh * nq + qi];
+        float delta = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            const T* kr = k + (size_t)(b * nk + j) * ldk + h * dh;
+            const T* vr = v + (size_t)(b * nk + j) * ldv + h * dh;
+            float s0 = 0.f, g = 0.f;
+            for (int d = 0; d < dh; ++d) { s0 = fmaf(qv[d], Elem<T>::ld(kr + d), s0); g = fmaf(dov[d], Elem<T>::ld(vr + d), g); }
+            float pj = expf(s0 * scale - l);
+            if (key_mask && !key_mask[b * nk + j]) pj = 0.f;
+            float msk = 1.f;
+            if (p_drop > 0.f) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + j, p_drop, inv_keep);
+            p[j] = pj;
+            dp[j] = g * msk;                 // d(p) through the dropout mask
+            delta += pj * dp[j];
+            const float pt = pj * msk;       // dropped probability used in O = P~ V
+            for (int d = 0; d < dh; ++d) atomicAdd(&sdv[j * dh + d], pt * dov[d]);
+        }
+        for (int j = 0; j < nk; ++j) {
+            const float ds = p[j] * (dp[j] - delta) * scale;
+            const T* kr = k + (size_t)(b * nk + j) * ldk + h * dh;
+            for (int d = 0; d < dh; ++d) {
+                dqv[d] = fmaf(ds, Elem<T>::ld(kr + d), dqv[d]);
+                atomicAdd(&sdk[j * dh + d], ds * qv[d]);
+            }
+        }
+        T* dqr = dq + (size_t)(b * nq + qi) * lddq + h * dh;
+        for (int d = 0; d < dh; ++d) Elem<T>::st(dqr + d, dqv[d]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk * dh; i += 64) {
+        const int j = i / dh, d = i % dh;
+        Elem<T>::st(dk + (size_t)(b * nk + j) * lddk + h * dh + d, sdk[i]);
+        Elem<T>::st(dv + (size_t)(b * nk + j) * lddv + h * dh + d, sdv[i]);
+    }
+}
+
+// ================================================================== bf16 MFMA kernels
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4bf16s_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 v8bf16s_t;
+
+__device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf16s_t, a), __builtin_bit_cast(v8bf16s_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t zero16() {
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+// accumulator row of register r for lane-half hi:  (r&3) + 8*(r>>2) + 4*hi
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// fragment with the contraction along dh, straight from global: row `row` (zero if >= nrows), 8 elems at col
+__device__ __forceinline__ bf16x8_t gfrag(const bf16_t* __restrict__ base, int ld, int row, int nrows, int col) {
+    bf16x8_t f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < nrows) f = *reinterpret_cast<const bf16x8_t*>(base + (size_t)row * ld + col);
+    return f;
+}
+
+template <int DH> struct Tile {
+    static constexpr int DHP = DH < 32 ? 32 : DH;       // padded so that every MFMA row d<32 exists (zeros)
+    static constexpr int PITCH = DHP * 2 + 16;          // bytes per sequence row
+    static constexpr int BYTES = MAXN * PITCH;
+};
+
+// stage rows [0,64) x [0,DH) of a [n, ld] matrix (head slice at column c0) into an LDS tile; rows >= n and
+// columns >= DH are zero.
+template <int DH>
+__device__ __forceinline__ void stage_tile(uint8_t* tile, const bf16_t* __restrict__ base, int ld, int n, int c0, int lane) {
+    constexpr int CH = Tile<DH>::DHP / 8;               // 16-byte chunks per row
+    for (int idx = lane; idx < MAXN * CH; idx += 64) {
+        const int row = idx / CH, c = idx % CH;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < n && c * 8 < DH) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c0 + c * 8);
+        *reinterpret_cast<uint4*>(tile + row * Tile<DH>::PITCH + c * 16) = v;
+    }
+}
+
+// A operand "X^T": MFMA row = feature d0+(lane&31); k-slots j=0..7 <-> sequence index
+//   seq = sbase + 8*(j>>2) + 4*(lane>>5) + (j&3)           (the order in which a lane's accumulator rows come)
+template <int DH, bool TR>
+__device__ __forceinline__ bf16x8_t tfrag(const uint8_t* tile, int d0, int sbase, int lane) {
+    constexpr int PITCH = Tile<DH>::PITCH;
+    const int hi = lane >> 5;
+    if (TR) {
+        const int t = lane & 15;
+        const int dcol = d0 + ((lane >> 4) & 1) * 16 + (t & 3) * 4;
+        const int s0 = sbase + 4 * hi + (t >> 2);
+        auto p0 = (__attribute__((address_space(3))) v4bf16s_t*)(tile + s0 * PITCH + dcol * 2);
+        auto p1 = (__attribute__((address_space(3))) v4bf16s_t*)(tile + (s0 + 8) * PITCH + dcol * 2);
+        bf16x4_t lo = __builtin_bit_cast(bf16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p0));
+        bf16x4_t hi4 = __builtin_bit_cast(bf16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p1));
+        return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+        const int d = d0 + (lane & 31);
+        bf16x8_t f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = sbase + 8 * (j >> 2) + 4 * hi + (j & 3);
+            f[j] = *reinterpret_cast<const short*>(tile + s * PITCH + d * 2);
+        }
+        return f;
+    }
+}
+
+// registers 8u..8u+7 of an accumulator -> bf16 B operand (k-slots in the same order as tfrag's)
+__device__ __forceinline__ bf16x8_t acc_to_frag(const f32x16_t& a, int u) {
+    bf16x8_t f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (short)f2bf(a[8 * u + j]);
+    return f;
+}
+
+// store an "X^T" accumulator pair as rows of X: lane owns sequence row (l&31), 4 consecutive features per register quad
+template <int DH>
+__device__ __forceinline__ void store_rows(const f32x16_t& a, bf16_t* __restrict__ base, int ld, int row, int nrows, int c0,
+                                           int d0, int lane, float mul) {
+    if (row >= nrows) return;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d = d0 + 8 * g + 4 * hi;
+        if (d < DH) {
+            uint2 w;
+            w.x = pack2bf(a[4 * g] * mul, a[4 * g + 1] * mul);
+            w.y = pack2bf(a[4 * g + 2] * mul, a[4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(base + (size_t)row * ld + c0 + d) = w;
+        }
+    }
+}
+
+template <int DH, int NQF, int NKF, bool TR>
+__global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                    const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
+                                                    bf16_t* __restrict__ o, float* __restrict__ lse, int H, int nq, int nk,
+                                                    int ldq, int ldk, int ldv, int ldo, float scale,
+                                                    float p_drop, float inv_keep, uint64_t seed) {
+    __shared__ __attribute__((aligned(16))) uint8_t vt[Tile<DH>::BYTES];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+    const bf16_t* qb = q + (size_t)b * nq * ldq;
+    const bf16_t* kb = k + (size_t)b * nk * ldk;
+    const bf16_t* vb = v + (size_t)b * nk * ldv;
+    stage_tile<DH>(vt, vb, ldv, nk, h * DH, lane);
+
+    // S^T[key][q]
+    f32x16_t st[NKF][NQF];
+#pragma unroll
+    for (int i = 0; i < NKF; ++i)
+#pragma unroll
+        for (int j = 0; j < NQF; ++j) st[i][j] = zero16();
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        bf16x8_t fk[NKF], fq[NQF];
+#pragma unroll
+        for (int i = 0; i < NKF; ++i) fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, h * DH + s * 16 + hi * 8);
+#pragma unroll
+        for (int j = 0; j < NQF; ++j) fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, h * DH + s * 16 + hi * 8);
+#pragma unroll
+        for (int i = 0; i < NKF; ++i)
+#pragma unroll
+            for (int j = 0; j < NQF; ++j) st[i][j] = mfma32(fk[i], fq[j], st[i][j]);
+    }
+    // key validity of this lane's accumulator rows
+    uint32_t kval = 0;
+#pragma unroll
+    for (int i = 0; i < NKF; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = i * 32 + acc_row(r, hi);
+            bool ok = key < nk;
+            if (ok && key_mask) ok = key_mask[b * nk + key] != 0;
+            kval |= (ok ? 1u : 0u) << (i * 16 + r);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NQF; ++j) {
+        const int qi = j * 32 + l31;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NKF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sv = ((kval >> (i * 16 + r)) & 1u) ? st[i][j][r] * scale : -INFINITY;
+                st[i][j][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NKF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = __expf(st[i][j][r] - mx); st[i][j][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (hi == 0 && qi < nq) lse[(size_t)bh * nq + qi] = mx + __logf(sum);
+#pragma unroll
+        for (int i = 0; i < NKF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = st[i][j][r] * inv;
+                if (p_drop > 0.f)
+                    pv *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
+                st[i][j][r] = pv;
+            }
+    }
+    // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+    constexpr int ND = (DH + 31) / 32;
+#pragma unroll
+    for (int id = 0; id < ND; ++id) {
+        f32x16_t oa[NQF];
+#pragma unroll
+        for (int j = 0; j < NQF; ++j) oa[j] = zero16();
+#pragma unroll
+        for (int i = 0; i < NKF; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8_t fv = tfrag<DH, TR>(vt, id * 32, i * 32 + u * 16, lane);
+#pragma unroll
+                for (int j = 0; j < NQF; ++j) oa[j] = mfma32(fv, acc_to_frag(st[i][j], u), oa[j]);
+            }
+#pragma unroll
+        for (int j = 0; j < NQF; ++j)
+            store_rows<DH>(oa[j], o + (size_t)b * nq * ldo, ldo, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
+    }
+}
+
+template <int DH, int NQF, int NKF, bool TR>
+__global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                    const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
+                                                    const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                    bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+                                                    int H, int nq, int nk, int ldq, int ldk, int ldv, int ldo,
+                                                    int lddq, int lddk, int lddv, float scale,
+                                                    float p_drop, float inv_keep, uint64_t seed) {
+    __shared__ __attribute__((aligned(16))) uint8_t tk[Tile<DH>::BYTES];     // K   [key][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tq[Tile<DH>::BYTES];     // Q   [q][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tdo[Tile<DH>::BYTES];    // dO  [q][d]
+    __shared__ float s_delta[MAXN];
+    __shared__ float s_lse[MAXN];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+    const bf16_t* qb = q + (size_t)b * nq * ldq;
+    const bf16_t* kb = k + (size_t)b * nk * ldk;
+    const bf16_t* vb = v + (size_t)b * nk * ldv;
+    const bf16_t* dob = dout + (size_t)b * nq * ldo;
+    stage_tile<DH>(tk, kb, ldk, nk, h * DH, lane);
+    stage_tile<DH>(tq, qb, ldq, nq, h * DH, lane);
+    stage_tile<DH>(tdo, dob, ldo, nq, h * DH, lane);
+    s_lse[lane] = lane < nq ? lse[(size_t)bh * nq + lane] : 0.f;
+    constexpr int ND = (DH + 31) / 32;
+
+    // ---------------- phase 1: lane owns a query column.  dQ and delta.
+    {
+        f32x16_t st[NKF][NQF], dpt[NKF][NQF];
+#pragma unroll
+        for (int i = 0; i < NKF; ++i)
+#pragma unroll
+            for (int j = 0; j < NQF; ++j) { st[i][j] = zero16(); dpt[i][j] = zero16(); }
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) {
+            const int col = h * DH + s * 16 + hi * 8;
+            bf16x8_t fk[NKF], fv[NKF], fq[NQF], fdo[NQF];
+#pragma unroll
+            for (int i = 0; i < NKF; ++i) { fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, col); fv[i] = gfrag(vb, ldv, i * 32 + l31, nk, col); }
+#pragma unroll
+            for (int j = 0; j < NQF; ++j) { fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, col); fdo[j] = gfrag(dob, ldo, j * 32 + l31, nq, col); }
+#pragma unroll
+            for (int i = 0; i < NKF; ++i)
+#pragma unroll
+                for (int j = 0; j < NQF; ++j) { st[i][j] = mfma32(fk[i], fq[j], st[i][j]); dpt[i][j] = mfma32(fv[i], fdo[j], dpt[i][j]); }
+        }
+        uint32_t kval = 0;
+#pragma unroll
+        for (int i = 0; i < NKF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = i * 32 + acc_row(r, hi);
+                bool ok = key < nk;
+                if (ok && key_mask) ok = key_mask[b * nk + key] != 0;
+                kval |= (ok ? 1u : 0u) << (i * 16 + r);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NQF; ++j) {
+            const int qi = j * 32 + l31;
+            const float l = s_lse[qi];
+            float delta = 0.f;
+#pragma unroll
+            for (int i = 0; i < NKF; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pv = ((kval >> (i * 16 + r)) & 1u) ? __expf(st[i][j][r] * scale - l) : 0.f;
+                    float dp = dpt[i][j][r];
+                    if (p_drop > 0.f)
+                        dp *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
+                    st[i][j][r] = pv;
+                    dpt[i][j][r] = dp;
+                    delta += pv * dp;
+                }
+            delta += __shfl_xor(delta, 32, 64);
+            if (hi == 0) s_delta[qi] = delta;
+#pragma unroll
+            for (int i = 0; i < NKF; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[i][j][r] = st[i][j][r] * (dpt[i][j][r] - delta) * scale;   // dS^T
+        }
+        // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int id = 0; id < ND; ++id) {
+            f32x16_t qa[NQF];
+#pragma unroll
+            for (int j = 0; j < NQF; ++j) qa[j] = zero16();
+#pragma unroll
+            for (int i = 0; i < NKF; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8_t fkt = tfrag<DH, TR>(tk, id * 32, i * 32 + u * 16, lane);
+#pragma unroll
+                    for (int j = 0; j < NQF; ++j) qa[j] = mfma32(fkt, acc_to_frag(st[i][j], u), qa[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < NQF; ++j)
+                store_rows<DH>(qa[j], dq + (size_t)b * nq * lddq, lddq, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
+        }
+    }
+    __syncthreads();
+    // ---------------- phase 2: lane owns a key column.  dV and dK.
+    {
+        f32x16_t s2[NQF][NKF], dp2[NQF][NKF];
+#pragma unroll
+        for (int j = 0; j < NQF; ++j)
+#pragma unroll
+            for (int i = 0; i < NKF; ++i) { s2[j][i] = zero16(); dp2[j][i] = zero16(); }
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) {
+            const int col = h * DH + s * 16 + hi * 8;
+            bf16x8_t fk[NKF], fv[NKF], fq[NQF], fdo[NQF];
+#pragma unroll
+            for (int i = 0; i < NKF; ++i) { fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, col); fv[i] = gfrag(vb, ldv, i * 32 + l31, nk, col); }
+#pragma unroll
+            for (int j = 0; j < NQF; ++j) { fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, col); fdo[j] = gfrag(dob, ldo, j * 32 + l31, nq, col); }
+#pragma unroll
+            for (int j = 0; j < NQF; ++j)
+#pragma unroll
+                for (int i = 0; i < NKF; ++i) { s2[j][i] = mfma32(fq[j], fk[i], s2[j][i]); dp2[j][i] = mfma32(fdo[j], fv[i], dp2[j][i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < NKF; ++i) {
+            const int key = i * 32 + l31;
+            bool kok = key < nk;
+            if (kok && key_mask) kok = key_mask[b * nk + key] != 0;
+#pragma unroll
+            for (int j = 0; j < NQF; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = j * 32 + acc_row(r, hi);
+                    float pv = (kok && qi < nq) ? __expf(s2[j][i][r] * scale - s_lse[qi]) : 0.f;
+                    float msk = 1.f;
+                    if (p_drop > 0.f) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
+                    const float dp = dp2[j][i][r] * msk;
+                    dp2[j][i][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
+                    s2[j][i][r] = pv * msk;                              // P~[q][key]
+                }
+        }
+        // dV^T[d][key] = sum_q dO^T[d][q] P~[q][key] ;  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int id = 0; id < ND; ++id) {
+            f32x16_t va[NKF], ka[NKF];
+#pragma unroll
+            for (int i = 0; i < NKF; ++i) { va[i] = zero16(); ka[i] = zero16(); }
+#pragma unroll
+            for (int j = 0; j < NQF; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8_t fdot = tfrag<DH, TR>(tdo, id * 32, j * 32 + u * 16, lane);
+                    const bf16x8_t fqt = tfrag<DH, TR>(tq, id * 32, j * 32 + u * 16, lane);
+#pragma unroll
+                    for (int i = 0; i < NKF; ++i) {
+                        va[i] = mfma32(fdot, acc_to_frag(s2[j][i], u), va[i]);
+                        ka[i] = mfma32(fqt, acc_to_frag(dp2[j][i], u), ka[i]);
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < NKF; ++i) {
+                store_rows<DH>(va[i], dv + (size_t)b * nk * lddv, lddv, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
+                store_rows<DH>(ka[i], dk + (size_t)b * nk * lddk, lddk, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
+            }
+        }
+    }
+}
+
+struct SdpaArgs {
+    const void *q, *k, *v; const uint8_t* key_mask; const void* dout; void* o; float* lse;
+    void *dq, *dk, *dv;
+    int B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float scale, p_drop, inv_keep; uint64_t seed;
+};
+
+template <int DH, int NQF, int NKF>
+static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
+    dim3 grid(a.B * a.H), block(64);
+    if (g_use_tr_read)
+        hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, true>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
+                           (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo,
+                           a.scale, a.p_drop, a.inv_keep, a.seed);
+    else
+        hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, false>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
+                           (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo,
+                           a.scale, a.p_drop, a.inv_keep, a.seed);
+}
+template <int DH, int NQF, int NKF>
+static void launch_bwd(const SdpaArgs& a, hipStream_t st) {
+    dim3 grid(a.B * a.H), block(64);
+    if (g_use_tr_read)
+        hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, true>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
+                           (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq, (bf16_t*)a.dk,
+                           (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv, a.scale,
+                           a.p_drop, a.inv_keep, a.seed);
+    else
+        hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, false>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
+                           (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq, (bf16_t*)a.dk,
+                           (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv, a.scale,
+                           a.p_drop, a.inv_keep, a.seed);
+}
+
+template <bool FWD, int DH>
+static void dispatch_frags(const SdpaArgs& a, hipStream_t st) {
+    const int nqf = (a.nq + 31) / 32, nkf = (a.nk + 31) / 32;
+#define XL_CASE(QF, KF)                                                       \
+    if (nqf == QF && nkf == KF) {                                             \
+        if (FWD) launch_fwd<DH, QF, KF>(a, st); else launch_bwd<DH, QF, KF>(a, st); \
+        return;                                                               \
+    }
+    XL_CASE(1, 1) XL_CASE(1, 2) XL_CASE(2, 1) XL_CASE(2, 2)
+#undef XL_CASE
+}
+
+static bool mfma_eligible(const SdpaArgs& a, bool bwd) {
+    if (!(a.dh == 16 || a.dh == 32 || a.dh == 64)) return false;
+    if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 8) return false;
+    if (!aligned16(a.q) || !aligned16(a.k) || !aligned16(a.v)) return false;
+    if (bwd) {
+        if (a.lddq % 4 || a.lddk % 4 || a.lddv % 4) return false;
+        if (!aligned16(a.dout) || !aligned16(a.dq) || !aligned16(a.dk) || !aligned16(a.dv)) return false;
+    } else if (a.ldo % 4 || !aligned16(a.o)) return false;
+    return true;
+}
+
+static int check_common(const SdpaArgs& a, int dtype, const char* fn) {
+    XL_CHECK_ARG(dtype == XL_F32 || dtype == XL_BF16, XL_ERR_BAD_DTYPE, "%s: bad dtype %d", fn, dtype);
+    XL_CHECK_ARG(a.B > 0 && a.H > 0 && a.nq > 0 && a.nk > 0 && a.nq <= MAXN && a.nk <= MAXN, XL_ERR_BAD_SHAPE,
+                 "%s: need 1 <= nq,nk <= %d (got %d,%d)", fn, MAXN, a.nq, a.nk);
+    XL_CHECK_ARG(a.dh > 0 && a.dh <= MAXN, XL_ERR_BAD_SHAPE, "%s: head size %d not in 1..%d", fn, a.dh, MAXN);
+    XL_CHECK_ARG(a.p_drop >= 0.f && a.p_drop < 1.f, XL_ERR_BAD_ARG, "%s: p_drop %f", fn, a.p_drop);
+    return XL_OK;
+}
+
+}  // namespace xl
+
+using namespace xl;
+
+extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
+                           void* o, float* lse, int B, int H, int nq, int nk, int dh,
+                           int ldq, int ldk, int ldv, int ldo, float scale,
+                           float p_drop, uint64_t seed, int dtype, void* stream) {
+    SdpaArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.o = o; a.lse = lse;
+    a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.dh = dh; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale = scale; a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+    int rc = check_common(a, dtype, "xl_sdpa_fwd");
+    if (rc) return rc;
+    XL_CHECK_ARG(q && k && v && o && lse, XL_ERR_BAD_ARG, "xl_sdpa_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XL_BF16 && mfma_eligible(a, false)) {
+        if (dh == 64) dispatch_frags<true, 64>(a, st);
+        else if (dh == 32) dispatch_frags<true, 32>(a, st);
+        else dispatch_frags<true, 16>(a, st);
+    } else if (dtype == XL_BF16) {
+        hipLaunchKernelGGL((sdpa_fwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, key_mask, (bf16_t*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
+                           a.inv_keep, seed);
+    } else {
+        hipLaunchKernelGGL((sdpa_fwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
+                           (const float*)v, key_mask, (float*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
+                           a.inv_keep, seed);
+    }
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
+                           const void* dout, const float* lse,
+                           void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
+                           int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
+                           float p_drop, uint64_t seed, int dtype, void* stream) {
+    SdpaArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.dout = dout; a.lse = const_cast<float*>(lse);
+    a.dq = dq; a.dk = dk; a.dv = dv;
+    a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.dh = dh; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.scale = scale; a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+    int rc = check_common(a, dtype, "xl_sdpa_bwd");
+    if (rc) return rc;
+    XL_CHECK_ARG(q && k && v && dout && lse && dq && dk && dv, XL_ERR_BAD_ARG, "xl_sdpa_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XL_BF16 && mfma_eligible(a, true)) {
+        if (dh == 64) dispatch_frags<false, 64>(a, st);
+        else if (dh == 32) dispatch_frags<false, 32>(a, st);
+        else dispatch_frags<false, 16>(a, st);
+    } else if (dtype == XL_BF16) {
+        hipLaunchKernelGGL((sdpa_bwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, key_mask, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, H, nq,
+                           nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed);
+    } else {
+        hipLaunchKernelGGL((sdpa_bwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
+                           (const float*)v, key_mask, (const float*)dout, lse, (float*)dq, (float*)dk, (float*)dv, H, nq, nk,
+                           dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed);
+    }
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}

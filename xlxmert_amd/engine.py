@@ -1,0 +1,533 @@
+"""Forward / backward program of the X-LXMERT hot path over the HIP kernels.
+
+The engine owns a static activation plan for one (B, L, V) batch geometry and runs the encoder
+(HF:498-557), the model shell (HF:691-822), the codebook head (ref lxrt/modeling.py:38-53) and the
+masked-visual-token losses (ref :237-290) as explicit kernel sequences -- forward and hand-derived backward --
+through an `ops` object (xlxmert_amd.ops.HipOps).  No autograd graph, no per-op allocation.
+
+Layout decisions (MI355X-first):
+  * language rows (B*L) and visual rows (B*V) of the cross-modality layers live in ONE [B*L + B*V, d] buffer:
+    the bidirectional cross-attention uses one set of weights for both directions (HF:386-397), so its QKV
+    projection, output projection and LayerNorm run as single contractions over all rows, and the weight
+    gradient is one contraction instead of two accumulated ones.
+  * query/key/value weights are adjacent in the flat parameter buffer -> one [3d, d] operand.
+  * the language side of the last cross layer is skipped when only the visual output is consumed
+    (vis_mask task) -- its parameters sit outside the optimizer range.
+"""
+import math
+
+import torch
+
+from .ops import EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_TANH
+
+
+class _Att:
+    """LxmertAttention + LxmertAttentionOutput parameters (fused q/k/v views)."""
+
+    def __init__(self, eng, prefix, self_name):
+        st = eng.store
+        qkv_w = [f"{prefix}.{self_name}.{n}.weight" for n in ("query", "key", "value")]
+        qkv_b = [f"{prefix}.{self_name}.{n}.bias" for n in ("query", "key", "value")]
+        self.wqkv, self.gwqkv = st.fused(qkv_w, st.compute), st.fused(qkv_w, st.grad)
+        self.bqkv, self.gbqkv = st.fused(qkv_b, st.master), st.fused(qkv_b, st.grad)
+        o = f"{prefix}.output"
+        self.wo, self.gwo = st.cview(o + ".dense.weight"), st.gview(o + ".dense.weight")
+        self.bo, self.gbo = st.view(o + ".dense.bias"), st.gview(o + ".dense.bias")
+        self.g, self.gg = st.view(o + ".LayerNorm.weight"), st.gview(o + ".LayerNorm.weight")
+        self.b, self.gb = st.view(o + ".LayerNorm.bias"), st.gview(o + ".LayerNorm.bias")
+
+
+class SelfAttBlock:
+    """LxmertSelfAttentionLayer (HF:304-316): y = LN(dense(attn(x,x,mask)) + x)."""
+
+    def __init__(self, eng, prefix, n_tok, masked, tag):
+        self.e, self.n, self.masked, self.tag = eng, n_tok, masked, tag
+        self.p = _Att(eng, prefix, "self")
+        self.M = eng.B * n_tok
+        d = eng.d
+        self.qkv = eng.act(self.M, 3 * d)
+        self.ctx = eng.act(self.M, d)
+        self.z = eng.act(self.M, d)
+        self.lse = eng.f32(eng.B * eng.H * n_tok)
+        self.mean, self.rstd = eng.f32(self.M), eng.f32(self.M)
+        self.site = eng.new_site(2)
+
+    def fwd(self, x, y):
+        e, p, d, M = self.e, self.p, self.e.d, self.M
+        ops = e.ops
+        ops.gemm(x, p.wqkv, self.qkv, p.bqkv, None, None, M, 3 * d, d, d, d, 3 * d)
+        km = e.kmask if self.masked else None
+        ops.sdpa_fwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, self.ctx, self.lse, e.B, e.H, self.n, self.n,
+                     e.dh, 3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
+        ops.gemm(self.ctx, p.wo, self.z, p.bo, x, None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
+                 p_drop=e.p_hid, seed=e.seed(self.site + 1))
+        ops.layernorm_fwd(self.z, p.g, p.b, y, self.mean, self.rstd, M, d, e.eps)
+        self.x = x
+
+    def bwd(self, dy, dx):
+        e, p, d, M = self.e, self.p, self.e.d, self.M
+        ops = e.ops
+        dz = e.tmp("dz", M, d)
+        ops.layernorm_bwd(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo if e.p_hid == 0 else None, M, d)
+        dzm = e.drop_bwd(dz, "dzm", M, d, self.site + 1, p.gbo)
+        ops.gemm(dzm, self.ctx, p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        dctx = e.tmp("dctx", M, d)
+        ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        dqkv = e.tmp("dqkv", M, 3 * d)
+        km = e.kmask if self.masked else None
+        ops.sdpa_bwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
+                     dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
+                     e.scale, e.p_attn, e.seed(self.site))
+        ops.colsum(dqkv, p.gbqkv, M, 3 * d, 3 * d)
+        ops.gemm(dqkv, self.x, p.gwqkv, None, None, None, 3 * d, d, M, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+                 epilogue=EPI_RESIDUAL)
+
+
+class FFNBlock:
+    """LxmertIntermediate + LxmertOutput (HF:325-342): y = LN(W2 gelu(W1 x + b1) + b2 + x)."""
+
+    def __init__(self, eng, p_inter, p_out, M, tag):
+        self.e, self.M, self.tag = eng, M, tag
+        st = eng.store
+        self.w1, self.gw1 = st.cview(p_inter + ".dense.weight"), st.gview(p_inter + ".dense.weight")
+        self.b1, self.gb1 = st.view(p_inter + ".dense.bias"), st.gview(p_inter + ".dense.bias")
+        self.w2, self.gw2 = st.cview(p_out + ".dense.weight"), st.gview(p_out + ".dense.weight")
+        self.b2, self.gb2 = st.view(p_out + ".dense.bias"), st.gview(p_out + ".dense.bias")
+        self.g, self.gg = st.view(p_out + ".LayerNorm.weight"), st.gview(p_out + ".LayerNorm.weight")
+        self.b, self.gb = st.view(p_out + ".LayerNorm.bias"), st.gview(p_out + ".LayerNorm.bias")
+        d, dff = eng.d, eng.dff
+        self.pre = eng.act(M, dff)
+        self.h = eng.act(M, dff)
+        self.z = eng.act(M, d)
+        self.mean, self.rstd = eng.f32(M), eng.f32(M)
+        self.site = eng.new_site(1)
+
+    def fwd(self, x, y):
+        e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
+        ops = e.ops
+        ops.gemm(x, self.w1, self.h, self.b1, None, self.pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU)
+        ops.gemm(self.h, self.w2, self.z, self.b2, x, None, M, d, dff, dff, dff, d, ldr=d, epilogue=EPI_RESIDUAL,
+                 p_drop=e.p_hid, seed=e.seed(self.site))
+        ops.layernorm_fwd(self.z, self.g, self.b, y, self.mean, self.rstd, M, d, e.eps)
+        self.x = x
+
+    def bwd(self, dy, dx):
+        e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
+        ops = e.ops
+        dz = e.tmp("dz", M, d)
+        ops.layernorm_bwd(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb,
+                          self.gb2 if e.p_hid == 0 else None, M, d)
+        dzm = e.drop_bwd(dz, "dzm", M, d, self.site, self.gb2)
+        ops.gemm(dzm, self.h, self.gw2, None, None, None, d, dff, M, d, dff, dff, a_kmajor=0, b_kmajor=0, out_f32=True)
+        dpre = e.tmp("dpre", M, dff)
+        ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
+                 epilogue=EPI_DGELU)
+        ops.colsum(dpre, self.gb1, M, dff, dff)
+        ops.gemm(dpre, self.x, self.gw1, None, None, None, dff, d, M, dff, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+                 epilogue=EPI_RESIDUAL)
+
+
+class CrossAttBlock:
+    """LxmertXLayer.cross_att (HF:377-398): ONE LxmertCrossAttentionLayer applied in both directions on the
+    pre-update inputs.  Rows = [language (B*L) ; visual (B*V)]."""
+
+    def __init__(self, eng, prefix, need_lang, tag):
+        self.e, self.need_lang, self.tag = eng, need_lang, tag
+        self.p = _Att(eng, prefix, "att")
+        d = eng.d
+        self.qkv = eng.act(eng.MX, 3 * d)
+        self.ctx = eng.act(eng.MX, d)
+        self.z = eng.act(eng.MX, d)
+        self.lse_l = eng.f32(eng.B * eng.H * eng.L)
+        self.lse_v = eng.f32(eng.B * eng.H * eng.V)
+        self.mean, self.rstd = eng.f32(eng.MX), eng.f32(eng.MX)
+        self.site = eng.new_site(3)
+
+    def fwd(self, X, Y):
+        e, p, d = self.e, self.p, self.e.d
+        ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
+        qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
+        if self.need_lang:
+            ops.gemm(X, p.wqkv, self.qkv, p.bqkv, None, None, MX, 3 * d, d, d, d, 3 * d)
+            # language queries over visual keys/values (no mask: visual_attention_mask is None in every caller)
+            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
+                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
+        else:
+            ops.gemm(X[ML:], p.wqkv, qkv_v, p.bqkv, None, None, MV, d, d, d, d, 3 * d)                    # Q of visual rows
+            ops.gemm(X[:ML], p.wqkv[d:], qkv_l[:, d:], p.bqkv[d:], None, None, ML, 2 * d, d, d, d, 3 * d)  # K,V of language rows
+        # visual queries over language keys/values, padded language keys excluded
+        ops.sdpa_fwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], e.kmask, self.ctx[ML:], self.lse_v, e.B, e.H, e.V, e.L, e.dh,
+                     3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site + 1))
+        r0, M = (0, MX) if self.need_lang else (ML, MV)
+        ops.gemm(self.ctx[r0:], p.wo, self.z[r0:], p.bo, X[r0:], None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
+                 p_drop=e.p_hid, seed=e.seed(self.site + 2))
+        ops.layernorm_fwd(self.z[r0:], p.g, p.b, Y[r0:], self.mean[r0:], self.rstd[r0:], M, d, e.eps)
+        self.X = X
+
+    def bwd(self, dY, dX):
+        e, p, d = self.e, self.p, self.e.d
+        ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
+        r0, M = (0, MX) if self.need_lang else (ML, MV)
+        dz_full = e.tmp("dz", MX, d)
+        dz = dz_full[r0:]
+        ops.layernorm_bwd(dY[r0:], self.z[r0:], p.g, self.mean[r0:], self.rstd[r0:], dz, p.gg, p.gb,
+                          p.gbo if e.p_hid == 0 else None, M, d)
+        dzm = e.drop_bwd(dz, "dzm", M, d, self.site + 2, p.gbo)
+        ops.gemm(dzm, self.ctx[r0:], p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        dctx_full = e.tmp("dctx", MX, d)
+        dctx = dctx_full[r0:]
+        ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        dqkv = e.tmp("dqkv", MX, 3 * d)
+        dqkv_l, dqkv_v = dqkv[:ML], dqkv[ML:]
+        qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
+        ops.sdpa_bwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], e.kmask, dctx_full[ML:], self.lse_v, dqkv_v, dqkv_l[:, d:],
+                     dqkv_l[:, 2 * d:], e.B, e.H, e.V, e.L, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
+                     e.p_attn, e.seed(self.site + 1))
+        X = self.X
+        if self.need_lang:
+            ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, dctx_full[:ML], self.lse_l, dqkv_l, dqkv_v[:, d:],
+                         dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
+                         e.p_attn, e.seed(self.site))
+            ops.colsum(dqkv, p.gbqkv, MX, 3 * d, 3 * d)
+            ops.gemm(dqkv, X, p.gwqkv, None, None, None, 3 * d, d, MX, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+            ops.gemm(dqkv, p.wqkv, dX, None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+                     epilogue=EPI_RESIDUAL)
+        else:
+            ops.colsum(dqkv_v, p.gbqkv, MV, d, 3 * d)
+            ops.colsum(dqkv_l[:, d:], p.gbqkv[d:], ML, 2 * d, 3 * d)
+            ops.gemm(dqkv_v, X[ML:], p.gwqkv, None, None, None, d, d, MV, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+            ops.gemm(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], None, None, None, 2 * d, d, ML, 3 * d, d, d, a_kmajor=0,
+                     b_kmajor=0, out_f32=True)
+            ops.gemm(dqkv_v, p.wqkv, dX[ML:], None, dz, None, MV, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+                     epilogue=EPI_RESIDUAL)
+            ops.gemm(dqkv_l[:, d:], p.wqkv[d:], dX[:ML], None, None, None, ML, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
+
+
+class Engine:
+    """Static-shape forward/backward program.  `need_lang`: whether lang/pooled outputs of the last cross layer are
+    consumed (False for the masked-visual-token step)."""
+
+    def __init__(self, cfg, store, ops, B, L, V, need_lang=False, train_dropout=False):
+        assert cfg.l_layers >= 1 and cfg.r_layers >= 1 and cfg.x_layers >= 1
+        assert L <= 64 and V <= 64, "attention kernels hold a whole (batch, head) problem on chip: n <= 64"
+        self.cfg, self.store, self.ops = cfg, store, ops
+        self.dev, self.cdtype = store.device, store.compute_dtype
+        self.B, self.L, self.V = B, L, V
+        self.d, self.dff, self.F, self.K = cfg.hidden_size, cfg.intermediate_size, cfg.visual_feat_dim, cfg.num_clusters
+        self.H, self.dh = cfg.num_attention_heads, cfg.head_dim
+        self.P = cfg.visual_pos_dim
+        self.ML, self.MV = B * L, B * V
+        self.MX = self.ML + self.MV
+        self.scale = 1.0 / math.sqrt(self.dh)
+        self.eps = cfg.layer_norm_eps
+        self.need_lang = need_lang
+        self.p_hid = cfg.hidden_dropout_prob if train_dropout else 0.0
+        self.p_attn = cfg.attention_probs_dropout_prob if train_dropout else 0.0
+        self._n_sites = 0
+        self._seed = 0
+        self._tmp = {}
+        self.act_bytes = 0
+        st, d = store, self.d
+        # ---- blocks
+        e_ = "bert.encoder"
+        self.lang_layers = [(SelfAttBlock(self, f"{e_}.layer.{i}.attention", L, True, f"l{i}"),
+                             FFNBlock(self, f"{e_}.layer.{i}.intermediate", f"{e_}.layer.{i}.output", self.ML, f"l{i}"))
+                            for i in range(cfg.l_layers)]
+        self.vis_layers = [(SelfAttBlock(self, f"{e_}.r_layers.{i}.attention", V, False, f"r{i}"),
+                            FFNBlock(self, f"{e_}.r_layers.{i}.intermediate", f"{e_}.r_layers.{i}.output", self.MV, f"r{i}"))
+                           for i in range(cfg.r_layers)]
+        self.x_layers = []
+        for i in range(cfg.x_layers):
+            p = f"{e_}.x_layers.{i}"
+            lang_on = need_lang or i < cfg.x_layers - 1
+            blk = {"cross": CrossAttBlock(self, p + ".visual_attention", lang_on, f"x{i}"), "lang_on": lang_on,
+                   "sa_v": SelfAttBlock(self, p + ".visn_self_att", V, False, f"x{i}v"),
+                   "ffn_v": FFNBlock(self, p + ".visn_inter", p + ".visn_output", self.MV, f"x{i}v")}
+            if lang_on:
+                blk["sa_l"] = SelfAttBlock(self, p + ".lang_self_att", L, True, f"x{i}l")
+                blk["ffn_l"] = FFNBlock(self, p + ".lang_inter", p + ".lang_output", self.ML, f"x{i}l")
+            self.x_layers.append(blk)
+        # ---- activations of the chain
+        self.emb_y, self.emb_pre = self.act(self.ML, d), self.act(self.ML, d)
+        self.emb_mean, self.emb_rstd = self.f32(self.ML), self.f32(self.ML)
+        self.feats = self.act(self.MV, self.F)
+        self.xv = self.act(self.MV, d)
+        self.vis0 = self.act(self.MV, d)
+        self.vn_stats = [self.f32(self.MV) for _ in range(4)]
+        self.lang_mid = [self.act(self.ML, d) for _ in range(cfg.l_layers)]          # attention-block outputs
+        self.lang_out = [self.act(self.ML, d) for _ in range(cfg.l_layers - 1)]
+        self.vis_mid = [self.act(self.MV, d) for _ in range(cfg.r_layers)]
+        self.vis_out = [self.act(self.MV, d) for _ in range(cfg.r_layers - 1)]
+        self.X = [self.act(self.MX, d) for _ in range(cfg.x_layers + 1)]             # [lang ; vis] per cross layer
+        self.XY = [self.act(self.MX, d) for _ in range(cfg.x_layers)]                # cross-attention outputs
+        self.XS = [self.act(self.MX, d) for _ in range(cfg.x_layers)]                # self-attention outputs
+        self.pooled = self.act(B, d)
+        self.kmask = torch.ones(B, L, dtype=torch.uint8, device=self.dev)
+        self.pos = torch.zeros(self.MV, self.P, dtype=torch.float32, device=self.dev)
+        self.ids = torch.zeros(B, L, dtype=torch.int64, device=self.dev)
+        self.tt = torch.zeros(B, L, dtype=torch.int64, device=self.dev)
+        self.cid = torch.zeros(B, V, dtype=torch.int64, device=self.dev)
+        self.vmask = torch.zeros(B, V, dtype=torch.uint8, device=self.dev)
+        self.labels = torch.full((B, V), -100, dtype=torch.int64, device=self.dev)
+        # ---- head (ref lxrt/modeling.py:38-53) + losses
+        h = "obj_predict_head"
+        self.hd = {k: (st.cview(n) if c else st.view(n), st.gview(n)) for k, n, c in (
+            ("wt", h + ".transform.dense.weight", True), ("bt", h + ".transform.dense.bias", False),
+            ("gt", h + ".transform.LayerNorm.weight", False), ("bbt", h + ".transform.LayerNorm.bias", False),
+            ("wf", h + ".linear_feat.weight", True), ("bf", h + ".linear_feat.bias", False),
+            ("bc", h + ".out_cluster.bias", False))}
+        self.Kp = (self.K + 7) // 8 * 8
+        self.t_pre, self.t_h, self.t_y = self.act(self.MV, d), self.act(self.MV, d), self.act(self.MV, d)
+        self.t_mean, self.t_rstd = self.f32(self.MV), self.f32(self.MV)
+        self.feat = self.act(self.MV, self.F)
+        self.logits = torch.zeros(self.MV, self.K, dtype=torch.float32, device=self.dev)
+        self.dlogits = self.act(self.MV, self.Kp)
+        self.dfeat = self.act(self.MV, self.F)
+        self.counts, self.nmask = self.f32(4), self.f32(B)
+        self.losses = self.f32(4)             # [obj_loss, feat_loss, -, -]
+        self.row_lse, self.row_maxprob = self.f32(self.MV), self.f32(self.MV)
+        self.row_argmax = torch.zeros(self.MV, dtype=torch.int32, device=self.dev)
+        self.mf_tmp = self.f32(d)
+        self.mf_tmp_c = self.act(1, d)
+        # ---- activation-gradient ping-pong
+        self.GA, self.GB = self.act(self.MX, d), self.act(self.MX, d)
+
+    # ------------------------------------------------------------ memory helpers
+    def act(self, *shape):
+        t = torch.zeros(*shape, dtype=self.cdtype, device=self.dev)
+        self.act_bytes += t.numel() * t.element_size()
+        return t
+
+    def f32(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    def tmp(self, name, M, N):
+        """backward scratch, shared by all blocks (sized for the largest user)."""
+        key = (name, N)
+        if key not in self._tmp:
+            self._tmp[key] = torch.zeros(self.MX, N, dtype=self.cdtype, device=self.dev)
+        return self._tmp[key][:M]
+
+    def new_site(self, n):
+        s = self._n_sites
+        self._n_sites += n
+        return s
+
+    def seed(self, site):
+        return (self._seed * 1000003 + site * 7919 + 12345) & 0x7FFFFFFFFFFFFFFF
+
+    def set_step_seed(self, seed):
+        self._seed = int(seed)
+
+    def drop_bwd(self, dz, name, M, N, site, gbias):
+        """gradient through a hidden dropout site: with p == 0 it is the identity (bias gradient was fused in LN bwd)."""
+        if self.p_hid == 0:
+            return dz
+        raise NotImplementedError("hidden dropout backward: enable once xl_dropout lands")
+
+    def sync_compute_weights(self):
+        """refresh the compute-dtype copy of the master parameters (after load_state_dict / init)."""
+        st = self.store
+        if st.compute_dtype != torch.float32:
+            self.ops.cast_from_f32(st.master, st.compute, st.n_total)
+
+    # ------------------------------------------------------------ inputs
+    def set_inputs(self, input_ids, attention_mask=None, token_type_ids=None, visual_pos=None, cluster_ids=None,
+                   vis_mask=None, obj_labels=None, visual_feats=None):
+        B, L, V = self.B, self.L, self.V
+        assert tuple(input_ids.shape) == (B, L), (input_ids.shape, (B, L))
+        self.ids.copy_(input_ids, non_blocking=True)
+        if attention_mask is None:
+            self.kmask.fill_(1)
+        else:
+            self.kmask.copy_(attention_mask.reshape(B, L) != 0, non_blocking=True)
+        if token_type_ids is None:
+            self.tt.zero_()
+        else:
+            self.tt.copy_(token_type_ids, non_blocking=True)
+        self.pos.copy_(visual_pos.reshape(self.MV, self.P), non_blocking=True)
+        self.use_codebook = cluster_ids is not None
+        if cluster_ids is not None:
+            self.cid.copy_(cluster_ids, non_blocking=True)
+            self.has_vmask = vis_mask is not None
+            if vis_mask is not None:
+                self.vmask.copy_(vis_mask.reshape(B, V) != 0, non_blocking=True)
+        else:
+            self.feats.copy_(visual_feats.reshape(self.MV, self.F), non_blocking=True)
+        if obj_labels is not None:
+            self.labels.copy_(obj_labels, non_blocking=True)
+
+    # ------------------------------------------------------------ forward
+    def encoder_forward(self, want_pooled=True):
+        cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
+        ML, MV = self.ML, self.MV
+        e = "bert.embeddings"
+        ops.embed_ln_fwd(self.ids, self.tt, st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
+                         st.cview(e + ".token_type_embeddings.weight"), st.view(e + ".LayerNorm.weight"),
+                         st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
+                         self.B, self.L, d, self.eps)
+        if self.use_codebook:
+            ops.codebook_gather(self.cid, self.vmask if self.has_vmask else None, st.centroids_c, st.view("mask_feat"),
+                                self.feats, MV, self.F)
+        v = "bert.encoder.visn_fc"
+        ops.gemm(self.feats, st.cview(v + ".visn_fc.weight"), self.xv, st.view(v + ".visn_fc.bias"), None, None,
+                 MV, d, self.F, self.F, self.F, d)
+        ops.visn_ln_fwd(self.xv, self.pos, st.view(v + ".box_fc.weight"), st.view(v + ".box_fc.bias"),
+                        st.view(v + ".visn_layer_norm.weight"), st.view(v + ".visn_layer_norm.bias"),
+                        st.view(v + ".box_layer_norm.weight"), st.view(v + ".box_layer_norm.bias"),
+                        self.vis0, *self.vn_stats, MV, d, self.P, self.eps)
+        X0 = self.X[0]
+        x = self.emb_y
+        for i, (sa, ffn) in enumerate(self.lang_layers):
+            sa.fwd(x, self.lang_mid[i])
+            y = X0[:ML] if i == cfg.l_layers - 1 else self.lang_out[i]
+            ffn.fwd(self.lang_mid[i], y)
+            x = y
+        x = self.vis0
+        for i, (sa, ffn) in enumerate(self.vis_layers):
+            sa.fwd(x, self.vis_mid[i])
+            y = X0[ML:] if i == cfg.r_layers - 1 else self.vis_out[i]
+            ffn.fwd(self.vis_mid[i], y)
+            x = y
+        for i, blk in enumerate(self.x_layers):
+            Xi, Y, S, Xo = self.X[i], self.XY[i], self.XS[i], self.X[i + 1]
+            blk["cross"].fwd(Xi, Y)
+            blk["sa_v"].fwd(Y[ML:], S[ML:])
+            blk["ffn_v"].fwd(S[ML:], Xo[ML:])
+            if blk["lang_on"]:
+                blk["sa_l"].fwd(Y[:ML], S[:ML])
+                blk["ffn_l"].fwd(S[:ML], Xo[:ML])
+        Xl = self.X[-1]
+        self.lang_final, self.vis_final = Xl[:ML], Xl[ML:]
+        if want_pooled and self.need_lang:
+            # LxmertPooler (HF:566-572): tanh(dense(lang[:, 0]))
+            ops.gemm(self.lang_final, st.cview("bert.pooler.dense.weight"), self.pooled, st.view("bert.pooler.dense.bias"),
+                     None, None, self.B, d, d, self.L * d, d, d, epilogue=EPI_TANH)
+        return self.lang_final, self.vis_final, self.pooled
+
+    def head_forward(self, want_logits=True):
+        """LxmertVisualObjHead.forward (ref lxrt/modeling.py:38-53): returns (feat, logits)."""
+        ops, d, MV, F, K = self.ops, self.d, self.MV, self.F, self.K
+        hd = self.hd
+        ops.gemm(self.vis_final, hd["wt"][0], self.t_h, hd["bt"][0], None, self.t_pre, MV, d, d, d, d, d, ldx=d, epilogue=EPI_GELU)
+        ops.layernorm_fwd(self.t_h, hd["gt"][0], hd["bbt"][0], self.t_y, self.t_mean, self.t_rstd, MV, d, self.eps)
+        ops.gemm(self.t_y, hd["wf"][0], self.feat, hd["bf"][0], None, None, MV, F, d, d, d, F)
+        if want_logits:
+            ops.gemm(self.feat, self.store.centroids_c, self.logits, hd["bc"][0], None, None, MV, K, F, F, F, K, out_f32=True)
+        return self.feat, self.logits
+
+    def losses_forward_backward(self, want_grad=True, feat_loss=True):
+        """ref lxrt/modeling.py:237-290.  Leaves d(logits) / d(feat) for head_backward; returns the loss buffer
+        [obj_loss, feat_loss] (device, fp32)."""
+        ops, MV, F, K = self.ops, self.MV, self.F, self.K
+        self.losses.zero_()
+        ops.mask_counts(self.labels, self.vmask, self.counts, self.nmask, self.B, self.V)
+        ops.ce_fwd_bwd(self.logits, self.labels, self.counts, self.dlogits if want_grad else None, self.losses[0:],
+                       None, None, None, MV, K, K, self.Kp, 1.0)
+        self.with_feat_loss = feat_loss
+        if feat_loss:
+            ops.featloss_fwd_bwd(self.feat, self.store.centroids_c, self.cid, self.vmask, self.nmask,
+                                 self.dfeat if want_grad else None, self.losses[1:], self.B, self.V, F, 1.0)
+        return self.losses
+
+    def predict_codes(self):
+        """head -> softmax -> max over the codebook (ref tasks/imggen_model.py:229-235): (max prob, argmax) per row."""
+        self.ops.ce_fwd_bwd(self.logits, None, None, None, None, self.row_lse, self.row_argmax, self.row_maxprob,
+                            self.MV, self.K, self.K, self.Kp, 1.0)
+        return self.row_maxprob, self.row_argmax
+
+    # ------------------------------------------------------------ backward
+    def zero_accumulated_grads(self):
+        st = self.store
+        st.grad[st.n_mat:st.n_used].zero_()
+
+    def head_backward(self, d_vis):
+        """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis."""
+        ops, d, MV, F, K = self.ops, self.d, self.MV, self.F, self.K
+        hd = self.hd
+        ops.colsum(self.dlogits, hd["bc"][1], MV, self.Kp, self.Kp)      # pad columns are zero; the bias unit is padded
+        dfeat = self.tmp("dfeat", MV, F)
+        if self.with_feat_loss:
+            ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, self.dfeat, None, MV, F, K, self.Kp, F, F, ldr=F,
+                     a_kmajor=1, b_kmajor=0, epilogue=EPI_RESIDUAL)
+        else:
+            ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, None, None, MV, F, K, self.Kp, F, F, a_kmajor=1, b_kmajor=0)
+        ops.colsum(dfeat, hd["bf"][1], MV, F, F)
+        ops.gemm(dfeat, self.t_y, hd["wf"][1], None, None, None, F, d, MV, F, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        dty = self.tmp("dz", MV, d)
+        ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, MV, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
+        dth = self.tmp("dctx", MV, d)
+        ops.layernorm_bwd(dty, self.t_h, hd["gt"][0], self.t_mean, self.t_rstd, dth, hd["gt"][1], hd["bbt"][1], None, MV, d)
+        dtp = self.tmp("dzm", MV, d)
+        ops.gelu_bwd(dth, self.t_pre, dtp, MV * d)
+        ops.colsum(dtp, hd["bt"][1], MV, d, d)
+        ops.gemm(dtp, self.vis_final, hd["wt"][1], None, None, None, d, d, MV, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        ops.gemm(dtp, hd["wt"][0], d_vis, None, None, None, MV, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+
+    def encoder_backward(self, have_lang_grad=False):
+        """d(outputs) are expected in GA ([lang ; vis] rows; the language rows are ignored unless have_lang_grad)."""
+        cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
+        ML, MV = self.ML, self.MV
+        GA, GB = self.GA, self.GB
+        for i in reversed(range(cfg.x_layers)):
+            blk = self.x_layers[i]
+            lang_on = blk["lang_on"] and (have_lang_grad or i < cfg.x_layers - 1)
+            blk["ffn_v"].bwd(GA[ML:], GB[ML:])
+            blk["sa_v"].bwd(GB[ML:], GA[ML:])
+            if blk["lang_on"]:
+                if not lang_on:
+                    raise RuntimeError("engine built with need_lang=True needs d(language_output)")
+                blk["ffn_l"].bwd(GA[:ML], GB[:ML])
+                blk["sa_l"].bwd(GB[:ML], GA[:ML])
+            blk["cross"].bwd(GA, GB)
+            GA, GB = GB, GA
+        # relational (visual) stack
+        for i in reversed(range(cfg.r_layers)):
+            sa, ffn = self.vis_layers[i]
+            ffn.bwd(GA[ML:], GB[ML:])
+            sa.bwd(GB[ML:], GA[ML:])
+        # language stack
+        for i in reversed(range(cfg.l_layers)):
+            sa, ffn = self.lang_layers[i]
+            ffn.bwd(GA[:ML], GB[:ML])
+            sa.bwd(GB[:ML], GA[:ML])
+        # visual feature encoder (HF:468-476) + codebook input
+        v = "bert.encoder.visn_fc"
+        dxv = self.tmp("dctx", MV, d)
+        ops.visn_ln_bwd(GA[ML:], self.xv, self.pos, st.view(v + ".box_fc.weight"), st.view(v + ".box_fc.bias"),
+                        st.view(v + ".visn_layer_norm.weight"), st.view(v + ".box_layer_norm.weight"), *self.vn_stats,
+                        dxv, st.gview(v + ".visn_layer_norm.weight"), st.gview(v + ".visn_layer_norm.bias"),
+                        st.gview(v + ".box_layer_norm.weight"), st.gview(v + ".box_layer_norm.bias"),
+                        st.gview(v + ".box_fc.weight"), st.gview(v + ".box_fc.bias"), st.gview(v + ".visn_fc.bias"),
+                        MV, d, self.P)
+        ops.gemm(dxv, self.feats, st.gview(v + ".visn_fc.weight"), None, None, None, d, self.F, MV, d, self.F, self.F,
+                 a_kmajor=0, b_kmajor=0, out_f32=True)
+        if self.use_codebook and self.has_vmask:
+            # d(mask_feat) = (sum over masked rows of d(xv)) W_visn   (ref lxrt/modeling.py:190-193: mask_feat is a Parameter)
+            self.mf_tmp.zero_()
+            ops.masked_colsum(dxv, self.vmask, self.mf_tmp, MV, d, d)
+            ops.cast_from_f32(self.mf_tmp, self.mf_tmp_c, d)
+            ops.gemm(self.mf_tmp_c, st.cview(v + ".visn_fc.weight"), st.gview("mask_feat"), None, None, None, 1, self.F, d,
+                     d, self.F, self.F, a_kmajor=1, b_kmajor=0, out_f32=True, accumulate=1)
+        # embeddings (HF:191-214)
+        e = "bert.embeddings"
+        dpre = self.tmp("dz", ML, d)
+        ops.layernorm_bwd(GA[:ML], self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
+                          st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d)
+        ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
+                      st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
+                      self.B, self.L, d)
+
+    # ------------------------------------------------------------ whole vis_mask step (forward + backward)
+    def vis_mask_forward_backward(self, feat_loss=True):
+        """XLxmertForPretraining.forward(task='vis_mask') + loss.backward() (ref lxrt/modeling.py:154-308,
+        lxmert_pretrain.py:338).  Gradients land in store.grad; returns the device loss buffer."""
+        self.encoder_forward(want_pooled=False)
+        self.head_forward()
+        self.zero_accumulated_grads()
+        losses = self.losses_forward_backward(True, feat_loss)
+        self.head_backward(self.GA[self.ML:])
+        self.encoder_backward(False)
+        return losses

@@ -1,0 +1,145 @@
+"""Tensor-level wrappers over the C ABI (include/xlxmert_hip.h).
+
+`HipOps` hands raw device pointers of torch tensors to libxlxmert_hip.so on torch's current HIP stream.
+torch is only the allocator / stream provider here.  Every method mirrors one `xl_*` entry point
+(same argument meaning); tensors may be views -- the pointer passed is `tensor.data_ptr()`.
+There is no CPU or eager fallback: a CPU tensor or a missing library raises.
+"""
+import torch
+
+from ._lib import XlError, get_lib
+
+XL_F32, XL_BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH = 0, 1, 2, 3, 4
+
+TORCH_DTYPE = {XL_F32: torch.float32, XL_BF16: torch.bfloat16}
+
+
+def xl_dtype(torch_dtype):
+    if torch_dtype == torch.float32:
+        return XL_F32
+    if torch_dtype == torch.bfloat16:
+        return XL_BF16
+    raise XlError(f"unsupported dtype {torch_dtype}: the HIP path computes in float32 or bfloat16")
+
+
+class HipOps:
+    """One instance per compute dtype."""
+
+    def __init__(self, dtype):
+        self.lib = get_lib()
+        self.dtype = dtype
+        self.dt = xl_dtype(dtype)
+
+    # -- plumbing
+    @staticmethod
+    def _p(t):
+        if t is None:
+            return None
+        if not t.is_cuda:
+            raise XlError("HipOps got a CPU tensor: the X-LXMERT hot path has no CPU fallback")
+        return t.data_ptr()
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def set_lds_transpose_read(self, enable):
+        self.lib.call("xl_set_lds_transpose_read", int(enable))
+
+    # -- dense contractions
+    def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
+             out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0):
+        self.lib.call("xl_gemm", self._p(A), self._p(B), self._p(C), self._p(bias), self._p(residual), self._p(aux),
+                      M, N, K, lda, ldb, ldc, ldr, ldx, int(a_kmajor), int(b_kmajor), self.dt,
+                      XL_F32 if out_f32 else self.dt, epilogue, float(alpha), int(accumulate), float(p_drop),
+                      int(seed), self._stream())
+
+    # -- LayerNorm family
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, N, eps):
+        self.lib.call("xl_layernorm_fwd", self._p(x), self._p(gamma), self._p(beta), self._p(y), self._p(mean),
+                      self._p(rstd), M, N, float(eps), self.dt, self._stream())
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N):
+        self.lib.call("xl_layernorm_bwd", self._p(dy), self._p(x), self._p(gamma), self._p(mean), self._p(rstd),
+                      self._p(dx), self._p(dgamma), self._p(dbeta), self._p(dbias_prev), M, N, self.dt, self._stream())
+
+    def visn_ln_fwd(self, xv, pos, wbox, bbox, gv, bv, gb, bb, y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps):
+        self.lib.call("xl_visn_ln_fwd", self._p(xv), self._p(pos), self._p(wbox), self._p(bbox), self._p(gv),
+                      self._p(bv), self._p(gb), self._p(bb), self._p(y), self._p(mean_v), self._p(rstd_v),
+                      self._p(mean_b), self._p(rstd_b), M, N, P, float(eps), self.dt, self._stream())
+
+    def visn_ln_bwd(self, dy, xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b, dxv, dgv, dbv, dgb, dbb,
+                    dwbox, dbbox, dbias_visn, M, N, P):
+        self.lib.call("xl_visn_ln_bwd", self._p(dy), self._p(xv), self._p(pos), self._p(wbox), self._p(bbox),
+                      self._p(gv), self._p(gb), self._p(mean_v), self._p(rstd_v), self._p(mean_b), self._p(rstd_b),
+                      self._p(dxv), self._p(dgv), self._p(dbv), self._p(dgb), self._p(dbb), self._p(dwbox),
+                      self._p(dbbox), self._p(dbias_visn), M, N, P, self.dt, self._stream())
+
+    # -- embeddings / codebook
+    def embed_ln_fwd(self, ids, tt, word, pos, type_, gamma, beta, y, pre, mean, rstd, B, L, N, eps):
+        self.lib.call("xl_embed_ln_fwd", self._p(ids), self._p(tt), self._p(word), self._p(pos), self._p(type_),
+                      self._p(gamma), self._p(beta), self._p(y), self._p(pre), self._p(mean), self._p(rstd), B, L, N,
+                      float(eps), self.dt, self._stream())
+
+    def embed_bwd(self, dpre, ids, tt, dword, dpos, dtype_tab, B, L, N):
+        self.lib.call("xl_embed_bwd", self._p(dpre), self._p(ids), self._p(tt), self._p(dword), self._p(dpos),
+                      self._p(dtype_tab), B, L, N, self.dt, self._stream())
+
+    def codebook_gather(self, cluster_ids, vis_mask, centroids, mask_feat, feats, M, F):
+        self.lib.call("xl_codebook_gather", self._p(cluster_ids), self._p(vis_mask), self._p(centroids),
+                      self._p(mask_feat), self._p(feats), M, F, self.dt, self._stream())
+
+    def masked_colsum(self, x, mask, out, M, N, ldx):
+        self.lib.call("xl_masked_colsum", self._p(x), self._p(mask), self._p(out), M, N, ldx, self.dt, self._stream())
+
+    def colsum(self, x, out, M, N, ldx):
+        self.lib.call("xl_colsum", self._p(x), self._p(out), M, N, ldx, self.dt, self._stream())
+
+    def gelu_bwd(self, dy, pre, dx, n):
+        self.lib.call("xl_gelu_bwd", self._p(dy), self._p(pre), self._p(dx), n, self.dt, self._stream())
+
+    # -- attention core
+    def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
+        self.lib.call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),
+                      B, H, nq, nk, dh, ldq, ldk, ldv, ldo, float(scale), float(p_drop), int(seed), self.dt,
+                      self._stream())
+
+    def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
+                 lddv, scale, p_drop=0.0, seed=0):
+        self.lib.call("xl_sdpa_bwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(dout),
+                      self._p(lse), self._p(dq), self._p(dk), self._p(dv), B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq,
+                      lddk, lddv, float(scale), float(p_drop), int(seed), self.dt, self._stream())
+
+    # -- head losses
+    def mask_counts(self, labels, vis_mask, counts, nmask, B, V):
+        self.lib.call("xl_mask_counts", self._p(labels), self._p(vis_mask), self._p(counts), self._p(nmask), B, V,
+                      self._stream())
+
+    def ce_fwd_bwd(self, logits, labels, counts, dlogits, loss_out, row_lse, row_argmax, row_maxprob, M, K, ldl, lddl,
+                   grad_scale=1.0):
+        self.lib.call("xl_ce_fwd_bwd", self._p(logits), self._p(labels), self._p(counts), self._p(dlogits),
+                      self._p(loss_out), self._p(row_lse), self._p(row_argmax), self._p(row_maxprob), M, K, ldl, lddl,
+                      float(grad_scale), self.dt, self._stream())
+
+    def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F,
+                         grad_scale=1.0):
+        self.lib.call("xl_featloss_fwd_bwd", self._p(pred), self._p(centroids), self._p(cluster_ids),
+                      self._p(vis_mask), self._p(nmask), self._p(dpred), self._p(loss_out), B, V, F, float(grad_scale),
+                      self.dt, self._stream())
+
+    # -- optimizer side
+    def sumsq(self, g, out, n):
+        self.lib.call("xl_sumsq", self._p(g), self._p(out), n, self._stream())
+
+    def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
+              max_norm, grad_scale=1.0):
+        self.lib.call("xl_adamw", self._p(p), self._p(g), self._p(m), self._p(v), self._p(p_compute),
+                      self._p(decay_flags), self._p(sumsq), self._p(lr_and_steps), n, float(beta1), float(beta2),
+                      float(eps), float(weight_decay), float(max_norm), float(grad_scale), self.dt, self._stream())
+
+    def cast_from_f32(self, src, dst, n):
+        self.lib.call("xl_cast_from_f32", self._p(src), self._p(dst), n, self.dt, self._stream())
+
+    def cast_to_f32(self, src, dst, n):
+        self.lib.call("xl_cast_to_f32", self._p(src), self._p(dst), n, self.dt, self._stream())

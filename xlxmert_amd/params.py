@@ -1,0 +1,216 @@
+"""Flat parameter storage for the X-LXMERT hot path.
+
+All trainable tensors of the path live in ONE fp32 master buffer (plus same-shaped gradient, Adam m/v
+buffers and a compute-dtype copy), laid out so that
+  * query/key/value weights (and biases) of an attention block are adjacent -> one fused [3d, d] operand;
+  * parameters whose gradient is written exactly once per step by a weight-gradient contraction ("mat")
+    come first, parameters whose gradient is accumulated by atomics ("vec": biases, LayerNorm affine,
+    embedding tables, box_fc, mask_feat) follow, so that only that tail is zeroed per step;
+  * parameters that get no gradient on a masked-visual-token step (pooler and the language side of the last
+    cross layer -- SURVEY.md section 0.6 V3) sit behind `n_used`: the optimizer and the gradient exchange
+    run over [0, n_used) only (the reference's AdamW skips tensors whose .grad is None).
+State-dict names are the reference's; every named tensor is a view into the flat buffer.
+"""
+from dataclasses import dataclass, field
+
+import torch
+
+CHUNK = 256          # allocation granule (elements); AdamW weight-decay flags are per chunk
+
+
+@dataclass
+class Member:
+    name: str
+    shape: tuple
+    offset: int = 0          # element offset in the flat buffer
+
+
+@dataclass
+class Unit:
+    members: list
+    region: str              # "mat" | "vec"
+    used: bool = True
+    offset: int = 0
+    numel: int = 0
+    padded: int = 0
+    decay: bool = False
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _decays(name):
+    """ref lxmert_pretrain.py:125-135: no_decay = ["bias", "LayerNorm.weight"] (substring match)."""
+    return not ("bias" in name or "LayerNorm.weight" in name)
+
+
+def build_units(cfg, task="vis_mask"):
+    d, dff, F, P = cfg.hidden_size, cfg.intermediate_size, cfg.visual_feat_dim, cfg.visual_pos_dim
+    units = []
+
+    def U(region, used, *members):
+        units.append(Unit([Member(n, tuple(s)) for n, s in members], region, used))
+
+    def att(p, self_name, used=True):
+        U("mat", used, *[(f"{p}.{self_name}.{n}.weight", (d, d)) for n in ("query", "key", "value")])
+        U("vec", used, *[(f"{p}.{self_name}.{n}.bias", (d,)) for n in ("query", "key", "value")])
+        U("mat", used, (f"{p}.output.dense.weight", (d, d)))
+        U("vec", used, (f"{p}.output.dense.bias", (d,)))
+        U("vec", used, (f"{p}.output.LayerNorm.weight", (d,)))
+        U("vec", used, (f"{p}.output.LayerNorm.bias", (d,)))
+
+    def ffn(pi, po, used=True):
+        U("mat", used, (f"{pi}.dense.weight", (dff, d)))
+        U("vec", used, (f"{pi}.dense.bias", (dff,)))
+        U("mat", used, (f"{po}.dense.weight", (d, dff)))
+        U("vec", used, (f"{po}.dense.bias", (d,)))
+        U("vec", used, (f"{po}.LayerNorm.weight", (d,)))
+        U("vec", used, (f"{po}.LayerNorm.bias", (d,)))
+
+    U("vec", True, ("mask_feat", (F,)))
+    e = "bert.embeddings"
+    U("vec", True, (f"{e}.word_embeddings.weight", (cfg.vocab_size, d)))
+    U("vec", True, (f"{e}.position_embeddings.weight", (cfg.max_position_embeddings, d)))
+    U("vec", True, (f"{e}.token_type_embeddings.weight", (cfg.type_vocab_size, d)))
+    U("vec", True, (f"{e}.LayerNorm.weight", (d,)))
+    U("vec", True, (f"{e}.LayerNorm.bias", (d,)))
+    v = "bert.encoder.visn_fc"
+    U("mat", True, (f"{v}.visn_fc.weight", (d, F)))
+    U("vec", True, (f"{v}.visn_fc.bias", (d,)))
+    U("vec", True, (f"{v}.visn_layer_norm.weight", (d,)))
+    U("vec", True, (f"{v}.visn_layer_norm.bias", (d,)))
+    U("vec", True, (f"{v}.box_fc.weight", (d, P)))
+    U("vec", True, (f"{v}.box_fc.bias", (d,)))
+    U("vec", True, (f"{v}.box_layer_norm.weight", (d,)))
+    U("vec", True, (f"{v}.box_layer_norm.bias", (d,)))
+    for stack, n in (("layer", cfg.l_layers), ("r_layers", cfg.r_layers)):
+        for i in range(n):
+            p = f"bert.encoder.{stack}.{i}"
+            att(p + ".attention", "self")
+            ffn(p + ".intermediate", p + ".output")
+    for i in range(cfg.x_layers):
+        p = f"bert.encoder.x_layers.{i}"
+        # vis_mask never reads the language output of the LAST cross layer
+        lang_used = not (task == "vis_mask" and i == cfg.x_layers - 1)
+        att(p + ".visual_attention", "att")
+        att(p + ".lang_self_att", "self", lang_used)
+        att(p + ".visn_self_att", "self")
+        ffn(p + ".lang_inter", p + ".lang_output", lang_used)
+        ffn(p + ".visn_inter", p + ".visn_output")
+    pooled_used = task != "vis_mask"
+    U("mat", pooled_used, ("bert.pooler.dense.weight", (d, d)))
+    U("vec", pooled_used, ("bert.pooler.dense.bias", (d,)))
+    h = "obj_predict_head"
+    U("mat", True, (f"{h}.transform.dense.weight", (d, d)))
+    U("vec", True, (f"{h}.transform.dense.bias", (d,)))
+    U("vec", True, (f"{h}.transform.LayerNorm.weight", (d,)))
+    U("vec", True, (f"{h}.transform.LayerNorm.bias", (d,)))
+    U("mat", True, (f"{h}.linear_feat.weight", (F, d)))
+    U("vec", True, (f"{h}.linear_feat.bias", (F,)))
+    U("vec", True, (f"{h}.out_cluster.bias", (cfg.num_clusters,)))
+    return units
+
+
+class ParamStore:
+    """Flat fp32 master parameters + gradients + Adam state + compute-dtype copy, on one device."""
+
+    def __init__(self, cfg, device, compute_dtype=torch.bfloat16, task="vis_mask"):
+        self.cfg, self.device, self.compute_dtype, self.task = cfg, torch.device(device), compute_dtype, task
+        units = build_units(cfg, task)
+        order = ([u for u in units if u.used and u.region == "mat"] + [u for u in units if u.used and u.region == "vec"]
+                 + [u for u in units if not u.used])
+        off = 0
+        self.index = {}
+        for u in order:
+            u.offset = off
+            rel = 0
+            for m in u.members:
+                m.offset = off + rel
+                rel += _numel(m.shape)
+                self.index[m.name] = m
+            u.numel = rel
+            u.padded = (rel + CHUNK - 1) // CHUNK * CHUNK
+            u.decay = _decays(u.members[0].name)
+            off += u.padded
+        self.units = order
+        self.n_total = off
+        self.n_mat = sum(u.padded for u in order if u.used and u.region == "mat")
+        self.n_used = sum(u.padded for u in order if u.used)
+        dev = self.device
+        self.master = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.compute = (self.master if compute_dtype == torch.float32
+                        else torch.zeros(self.n_total, dtype=compute_dtype, device=dev))
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        flags = torch.zeros(self.n_total // CHUNK, dtype=torch.uint8)
+        for u in order:
+            if u.decay:
+                flags[u.offset // CHUNK:(u.offset + u.padded) // CHUNK] = 1
+        self.decay_flags = flags.to(dev)
+        # frozen centroid codebook (vis_emb.weight == obj_predict_head.out_cluster.weight, ref modeling.py:140-151)
+        self.centroids = None          # fp32 [K, F]
+        self.centroids_c = None        # compute dtype
+
+    # ---- views
+    def view(self, name, buf=None):
+        m = self.index[name]
+        buf = self.master if buf is None else buf
+        return buf[m.offset:m.offset + _numel(m.shape)].view(m.shape)
+
+    def cview(self, name):
+        return self.view(name, self.compute)
+
+    def gview(self, name):
+        return self.view(name, self.grad)
+
+    def fused(self, names, buf):
+        """[sum(rows), cols] view over adjacent members (query/key/value)."""
+        ms = [self.index[n] for n in names]
+        for a, b in zip(ms[:-1], ms[1:]):
+            assert b.offset == a.offset + _numel(a.shape), "members are not adjacent"
+        n = sum(_numel(m.shape) for m in ms)
+        flat = buf[ms[0].offset:ms[0].offset + n]
+        return flat.view(-1, ms[0].shape[1]) if len(ms[0].shape) == 2 else flat
+
+    def names(self):
+        return list(self.index.keys())
+
+    def set_centroids(self, centroids):
+        c = torch.as_tensor(centroids, dtype=torch.float32).to(self.device).contiguous()
+        assert c.shape == (self.cfg.num_clusters, self.cfg.visual_feat_dim), c.shape
+        self.centroids = c
+        self.centroids_c = c if self.compute_dtype == torch.float32 else c.to(self.compute_dtype)
+
+    def ensure_adam_state(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros(self.n_used, dtype=torch.float32, device=self.device)
+            self.exp_avg_sq = torch.zeros(self.n_used, dtype=torch.float32, device=self.device)
+
+    def load_named(self, sd, strict=False):
+        """Copy tensors of a reference-layout state dict into the master buffer (keys not on the path are ignored)."""
+        missing = []
+        with torch.no_grad():
+            for name in self.index:
+                if name in sd:
+                    self.view(name).copy_(torch.as_tensor(sd[name]).to(self.device, torch.float32))
+                else:
+                    missing.append(name)
+            for k in ("vis_emb.weight", "obj_predict_head.out_cluster.weight"):
+                if k in sd:
+                    self.set_centroids(sd[k])
+                    break
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:8]}...")
+        return missing
+
+    def named_state(self):
+        out = {n: self.view(n) for n in self.index}
+        if self.centroids is not None:
+            out["vis_emb.weight"] = self.centroids
+            out["obj_predict_head.out_cluster.weight"] = self.centroids
+        return out
