@@ -1,0 +1,180 @@
+"""Headline benchmark: masked-visual-token pretraining step throughput (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward + backward + gradient all-reduce (N>1) + clip + AdamW of the full X-LXMERT encoder
+(9 language / 5 visual / 5 cross layers, d=768) with the 10k-codebook head, per-GPU batch 256 of
+(20 text tokens x 64 visual tokens), bf16 operands / fp32 accumulate, synthetic inputs resident in HBM.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+GFLOP_PER_EXAMPLE = 50.782      # necessary fwd+bwd, SURVEY.md section 8d / Appendix D (contract figure)
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (measured 2495)
+
+
+def cpu_baseline(cfg, bs, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores: fwd + bwd + clip + AdamW."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lxmert_oracle as O
+    from xlxmert_amd.trainer import synthetic_batch
+    keys = ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size", "max_position_embeddings",
+            "type_vocab_size", "l_layers", "x_layers", "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")
+    oc = O.OracleConfig(**{k: getattr(cfg, k) for k in keys})
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = O.make_state_dict(oc, 9595, perturb=False)
+    leaf = {k: v.clone().requires_grad_(v.is_floating_point() and k != "vis_emb.weight") for k, v in sd.items()}
+    leaf["obj_predict_head.out_cluster.weight"] = leaf["vis_emb.weight"]
+    params = [v for k, v in leaf.items() if v.requires_grad and k != "obj_predict_head.out_cluster.weight"]
+    m = [torch.zeros_like(p) for p in params]
+    v2 = [torch.zeros_like(p) for p in params]
+    batch = synthetic_batch(cfg, bs, 20, 8, seed=9595)
+
+    def one(t):
+        for p in params:
+            p.grad = None
+        out = O.xlxmert_vis_mask_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                         batch["cluster_ids"], batch["vis_mask"], batch["obj_labels"])
+        out["total_loss"].backward()
+        live = [i for i, p in enumerate(params) if p.grad is not None]
+        _, clipped = O.clip_grad_norm([params[i].grad for i in live], 1.0)
+        with torch.no_grad():
+            for i, g in zip(live, clipped):
+                p, m[i], v2[i] = O.adamw_update(params[i].data, g, m[i], v2[i], t, 1e-4)
+                params[i].data.copy_(p)
+
+    one(1)                      # warm-up
+    times = []
+    t0 = time.time()
+    while len(times) < 5 and (time.time() - t0 < budget_s or not times):
+        s = time.time()
+        one(len(times) + 2)
+        times.append(time.time() - s)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(bs / med, 3), "unit": "examples/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full steps (fwd+bwd+clip+AdamW, fp32 torch-CPU oracle) at bs={bs}, median {med:.2f} s/step"}
+
+
+class GemmTimer:
+    """Wraps HipOps.gemm with HIP events on the launch stream (torch's current stream) for ONE instrumented step."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.rec = ops, ops.gemm, []
+
+    def __enter__(self):
+        def timed(A, B, C, bias, residual, aux, M, N, K, *a, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.orig(A, B, C, bias, residual, aux, M, N, K, *a, **kw)
+            e.record()
+            self.rec.append((s, e, 2.0 * M * N * K))
+        self.ops.gemm = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm = self.orig
+        torch.cuda.synchronize()
+        self.total_ms = sum(s.elapsed_time(e) for s, e, _ in self.rec)
+        self.flops = sum(f for _, _, f in self.rec)
+        self.launches = len(self.rec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (reference --batchSize, param.py:70)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig()
+    B = args.batch
+    tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595,
+                      total_steps=max(1000, args.steps + args.warmup))
+    g = torch.Generator().manual_seed(9595)
+    tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
+    batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=9595 + 17 * rank + i).items()}
+               for i in range(4)]                       # per-rank disjoint synthetic minibatches, resident in HBM
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tr.step(batches[i % 4])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = tr.step(batches[i % 4])
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    loss_val = losses[0].item()
+
+    with GemmTimer(tr.ops) as gt:                         # one extra, instrumented step (not in the timed region)
+        tr.step(batches[0])
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        gemm_tflops = gt.flops / (gt.total_ms * 1e-3) / 1e12
+        out = {
+            "metric": "pretrain examples/sec (20 text tok x 64 vis tok, bs=256)", "value": round(value, 1),
+            "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]+[2]: full X-LXMERT encoder 9L/5R/5X d=768 + obj_predict_head over 10k codebook, "
+                                   "masked-visual-token step fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world,
+                       "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}", "dropout": "off (eval-parity mode)",
+                       "loss": round(loss_val, 4)},
+            "step_mfma_frac": round(value / world * GFLOP_PER_EXAMPLE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_mfma_kernel (all dense contractions of one step)",
+                         "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": gt.launches, "avg_launch_us": round(gt.total_ms * 1e3 / gt.launches, 2),
+                         "gemm_ms_per_step": round(gt.total_ms, 3),
+                         "algorithmic_gflop_per_step": round(gt.flops / 1e9, 1),
+                         "contract_gflop_per_step": round(GFLOP_PER_EXAMPLE * B, 1)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: the library builds for gfx950, loads, and exports every symbol that
+include/xlxmert_hip.h declares; the product refuses to run without a GPU (no CPU fallback)."""
+import os
+
+import pytest
+import torch
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from xlxmert_amd.build import build_library
+    from xlxmert_amd._lib import Lib, parse_header
+    lib = Lib(build_library())
+    protos = parse_header()
+    assert len(protos) >= 20
+    for name in protos:
+        assert hasattr(lib._dll, name), name
+    assert lib.raw("xl_version")() == 1
+    must = {"xl_gemm", "xl_layernorm_fwd", "xl_layernorm_bwd", "xl_sdpa_fwd", "xl_sdpa_bwd", "xl_embed_ln_fwd",
+            "xl_codebook_gather", "xl_ce_fwd_bwd", "xl_featloss_fwd_bwd", "xl_adamw", "xl_sumsq", "xl_last_error"}
+    assert must <= set(protos)
+
+
+def test_argument_validation_without_gpu():
+    """bad arguments are rejected on the host before any launch (error text via xl_last_error)."""
+    from xlxmert_amd._lib import XlError, get_lib
+    lib = get_lib()
+    with pytest.raises(XlError, match="bad shape"):
+        lib.call("xl_gemm", None, None, None, None, None, None, 0, 4, 4, 4, 4, 4, 0, 0, 1, 1, 1, 1, 0, 1.0, 0, 0.0, 0, None)
+    with pytest.raises(XlError, match="nq,nk"):
+        lib.call("xl_sdpa_fwd", 16, 16, 16, None, 16, 16, 1, 1, 65, 8, 64, 64, 64, 64, 64, 1.0, 0.0, 0, 1, None)
+
+
+def test_no_cpu_fallback():
+    from xlxmert_amd._lib import XlError
+    from xlxmert_amd.ops import HipOps
+    ops = HipOps(torch.float32)
+    x = torch.zeros(4, 8)
+    with pytest.raises(XlError, match="CPU tensor"):
+        ops.colsum(x, torch.zeros(8), 4, 8, 8)
+
+
+def test_product_package_does_not_import_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xlxmert_amd")
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            src = open(os.path.join(root, fn)).read()
+            for line in src.splitlines():
+                ls = line.strip()
+                if ls.startswith("import ") or ls.startswith("from "):
+                    assert "oracle" not in ls and "fake_ops" not in ls and "transformers" not in ls, (fn, ls)

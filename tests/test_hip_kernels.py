@@ -1,0 +1,337 @@
+"""GPU parity tests: every C-ABI entry point of libxlxmert_hip.so (called through xlxmert_amd.ops.HipOps on a real
+MI355X) against the same operation restated in plain torch on the host (tests/fake_ops.FakeOps), on identical
+seeded inputs.  fp32 path: tight tolerance (it is the config-1 "logits within 1e-3" path).  bf16 path: outputs are
+bf16-rounded, tolerance relative to the output scale."""
+import math
+
+import pytest
+import torch
+
+from fake_ops import FakeOps
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def hip(dtype):
+    from xlxmert_amd.ops import HipOps
+    return HipOps(dtype)
+
+
+def run_both(dtype, name, args, kwargs=None):
+    """args: list of tensors / scalars / None.  Returns (cpu_args, gpu_args_on_cpu) after running the op on both."""
+    kwargs = kwargs or {}
+    cpu = [a.clone() if torch.is_tensor(a) else a for a in args]
+    gpu = [a.cuda() if torch.is_tensor(a) else a for a in args]
+    getattr(FakeOps(dtype), name)(*cpu, **kwargs)
+    getattr(hip(dtype), name)(*gpu, **kwargs)
+    torch.cuda.synchronize()
+    return cpu, [a.cpu() if torch.is_tensor(a) else a for a in gpu]
+
+
+def close(a, b, dtype, what="", scale=None, f32_tol=2e-5, bf16_tol=1.2e-2):
+    a, b = a.double(), b.double()
+    s = max(b.abs().max().item(), 1e-6) if scale is None else scale
+    err = (a - b).abs().max().item() / s
+    tol = f32_tol if dtype == torch.float32 else bf16_tol
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol:.1e} (scale {s:.3e})"
+    assert torch.isfinite(a).all(), f"{what}: non-finite output"
+
+
+def rnd(g, *shape, dtype=torch.float32, s=1.0):
+    return (torch.randn(*shape, generator=g) * s).to(dtype)
+
+
+# ---------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 192), (200, 72, 136), (40, 2304, 64), (1, 32, 64), (130, 56, 1000),
+               (768, 768, 2560)]
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_layouts(M, N, K, layout, dtype, tr):
+    if dtype == torch.float32 and tr == 0:
+        pytest.skip("transpose-read switch only affects the bf16 MFMA kernel")
+    ak, bk = layout
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ak * 2 + bk)
+    lda = (K if ak else M) + 8
+    ldb = (K if bk else N) + 16
+    A = rnd(g, (M if ak else K), lda, dtype=dtype)
+    B = rnd(g, (N if bk else K), ldb, dtype=dtype)
+    C = torch.zeros(M, N + 8, dtype=dtype)
+    bias = rnd(g, N)
+    ops = hip(dtype)
+    ops.set_lds_transpose_read(tr)
+    try:
+        cpu, gpu = run_both(dtype, "gemm", [A, B, C, bias, None, None, M, N, K, lda, ldb, N + 8],
+                            dict(a_kmajor=ak, b_kmajor=bk))
+    finally:
+        ops.set_lds_transpose_read(1)
+    close(gpu[2], cpu[2], dtype, f"gemm {M}x{N}x{K} ak={ak} bk={bk} tr={tr}", scale=math.sqrt(K))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("epi", [1, 2, 3, 4])
+def test_gemm_epilogues(epi, dtype):
+    g = torch.Generator().manual_seed(epi)
+    M, N, K = 192, 136, 96
+    A, B = rnd(g, M, K, dtype=dtype, s=0.3), rnd(g, N, K, dtype=dtype, s=0.3)
+    C = torch.zeros(M, N, dtype=dtype)
+    bias = rnd(g, N)
+    res = rnd(g, M, N, dtype=dtype)
+    aux = rnd(g, M, N, dtype=dtype)
+    cpu, gpu = run_both(dtype, "gemm", [A, B, C, bias, res, aux, M, N, K, K, K, N], dict(ldr=N, ldx=N, epilogue=epi))
+    close(gpu[2], cpu[2], dtype, f"epilogue {epi} C")
+    if epi == 1:
+        close(gpu[5], cpu[5], dtype, "epilogue GELU aux (pre-activation)")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_weight_gradient_splitk_and_accumulate(dtype):
+    """dW = dY^T X with fp32 output: deep contraction (split-K + atomics) and accumulate!=0."""
+    g = torch.Generator().manual_seed(5)
+    rows, n_out, k_in = 4096, 256, 192
+    dY, X = rnd(g, rows, n_out, dtype=dtype, s=0.1), rnd(g, rows, k_in, dtype=dtype)
+    C = torch.full((n_out, k_in), 3.0)
+    cpu, gpu = run_both(dtype, "gemm", [dY, X, C, None, None, None, n_out, k_in, rows, n_out, k_in, k_in],
+                        dict(a_kmajor=0, b_kmajor=0, out_f32=True))
+    close(gpu[2], cpu[2], dtype, "dW overwrite", f32_tol=1e-4, bf16_tol=2e-3)
+    cpu, gpu = run_both(dtype, "gemm", [dY, X, C, None, None, None, n_out, k_in, rows, n_out, k_in, k_in],
+                        dict(a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1))
+    close(gpu[2], cpu[2], dtype, "dW accumulate", f32_tol=1e-4, bf16_tol=2e-3)
+
+
+def test_gemm_in_place_residual_bf16():
+    """C aliases the residual (cross-attention context gradient accumulates into the other stream's buffer)."""
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 256, 128, 128
+    A, B = rnd(g, M, K, dtype=torch.bfloat16), rnd(g, N, K, dtype=torch.bfloat16)
+    C0 = rnd(g, M, N, dtype=torch.bfloat16)
+    ref = C0.clone()
+    FakeOps(torch.bfloat16).gemm(A, B, ref, None, ref, None, M, N, K, K, K, N, ldr=N, epilogue=2)
+    Cg = C0.cuda()
+    hip(torch.bfloat16).gemm(A.cuda(), B.cuda(), Cg, None, Cg, None, M, N, K, K, K, N, ldr=N, epilogue=2)
+    close(Cg.cpu(), ref, torch.bfloat16, "in-place residual")
+
+
+# ---------------------------------------------------------------- LayerNorm family
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N", [(37, 768), (5, 64), (130, 1536), (64, 128)])
+def test_layernorm_fwd_bwd(M, N, dtype):
+    g = torch.Generator().manual_seed(M + N)
+    x = rnd(g, M, N, dtype=dtype) * 2 + 0.5
+    gamma, beta = rnd(g, N) * 0.2 + 1, rnd(g, N) * 0.1
+    y = torch.zeros(M, N, dtype=dtype)
+    mean, rstd = torch.zeros(M), torch.zeros(M)
+    cpu, gpu = run_both(dtype, "layernorm_fwd", [x, gamma, beta, y, mean, rstd, M, N, 1e-12])
+    close(gpu[3], cpu[3], dtype, "ln y")
+    close(gpu[4], cpu[4], torch.float32, "ln mean", f32_tol=1e-5)
+    close(gpu[5], cpu[5], torch.float32, "ln rstd", f32_tol=1e-5)
+    dy = rnd(g, M, N, dtype=dtype)
+    dx = torch.zeros(M, N, dtype=dtype)
+    dg, db, dbp = torch.ones(N), torch.ones(N), torch.ones(N)
+    cpu, gpu = run_both(dtype, "layernorm_bwd", [dy, x, gamma, cpu[4], cpu[5], dx, dg, db, dbp, M, N])
+    close(gpu[5], cpu[5], dtype, "ln dx")
+    for i, nm in ((6, "dgamma"), (7, "dbeta"), (8, "dbias_prev")):
+        close(gpu[i], cpu[i], torch.float32, "ln " + nm, f32_tol=2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_visn_ln_fwd_bwd(dtype):
+    g = torch.Generator().manual_seed(3)
+    M, N, P = 130, 768, 4
+    xv = rnd(g, M, N, dtype=dtype)
+    pos = torch.rand(M, P, generator=g)
+    wbox, bbox = rnd(g, N, P) * 0.5, rnd(g, N) * 0.1
+    gv, bv, gb, bb = rnd(g, N) * 0.1 + 1, rnd(g, N) * 0.1, rnd(g, N) * 0.1 + 1, rnd(g, N) * 0.1
+    y = torch.zeros(M, N, dtype=dtype)
+    st = [torch.zeros(M) for _ in range(4)]
+    cpu, gpu = run_both(dtype, "visn_ln_fwd", [xv, pos, wbox, bbox, gv, bv, gb, bb, y, *st, M, N, P, 1e-12])
+    close(gpu[8], cpu[8], dtype, "visn y")
+    for i in range(9, 13):
+        close(gpu[i], cpu[i], torch.float32, f"visn stat {i}", f32_tol=1e-4)
+    dy = rnd(g, M, N, dtype=dtype)
+    outs = [torch.zeros(M, N, dtype=dtype)] + [torch.zeros(N) for _ in range(4)] + [torch.zeros(N, P), torch.zeros(N),
+                                                                                    torch.zeros(N)]
+    cpu2, gpu2 = run_both(dtype, "visn_ln_bwd", [dy, xv, pos, wbox, bbox, gv, gb, *cpu[9:13], *outs, M, N, P])
+    close(gpu2[11], cpu2[11], dtype, "visn dxv")
+    for i in range(12, 19):
+        close(gpu2[i], cpu2[i], torch.float32, f"visn grad {i}", f32_tol=1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_embeddings_fwd_bwd(dtype):
+    g = torch.Generator().manual_seed(11)
+    B, L, N, vocab = 5, 20, 768, 300
+    ids = torch.randint(0, vocab, (B, L), generator=g)
+    ids[:, 0] = 101
+    ids[2, 7:] = 0
+    tt = torch.zeros(B, L, dtype=torch.long)
+    tt[1, 3:] = 1
+    word, pos, typ = rnd(g, vocab, N, dtype=dtype), rnd(g, 32, N, dtype=dtype), rnd(g, 2, N, dtype=dtype)
+    gamma, beta = rnd(g, N) * 0.1 + 1, rnd(g, N) * 0.1
+    y, pre = torch.zeros(B * L, N, dtype=dtype), torch.zeros(B * L, N, dtype=dtype)
+    mean, rstd = torch.zeros(B * L), torch.zeros(B * L)
+    cpu, gpu = run_both(dtype, "embed_ln_fwd", [ids, tt, word, pos, typ, gamma, beta, y, pre, mean, rstd, B, L, N, 1e-12])
+    close(gpu[8], cpu[8], dtype, "embed pre")
+    close(gpu[7], cpu[7], dtype, "embed y")
+    dpre = rnd(g, B * L, N, dtype=dtype)
+    dw, dp, dt_ = torch.zeros(vocab, N), torch.zeros(32, N), torch.zeros(2, N)
+    cpu, gpu = run_both(dtype, "embed_bwd", [dpre, ids, tt, dw, dp, dt_, B, L, N])
+    for i, nm in ((3, "dword"), (4, "dpos"), (5, "dtype")):
+        close(gpu[i], cpu[i], torch.float32, "embed " + nm, f32_tol=1e-5)
+    assert gpu[3][0].abs().max() == 0 and gpu[4][0].abs().max() == 0 and gpu[5][0].abs().max() == 0   # padding_idx rows
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_codebook_colsums_gelu(dtype):
+    g = torch.Generator().manual_seed(13)
+    M, F, K = 130, 2048, 50
+    cid = torch.randint(0, K, (M,), generator=g)
+    vm = (torch.rand(M, generator=g) < 0.4).to(torch.uint8)
+    cent = rnd(g, K, F, dtype=dtype).relu()
+    mf = rnd(g, F)
+    feats = torch.zeros(M, F, dtype=dtype)
+    cpu, gpu = run_both(dtype, "codebook_gather", [cid, vm, cent, mf, feats, M, F])
+    close(gpu[4], cpu[4], dtype, "codebook gather", f32_tol=0, bf16_tol=4e-3)
+    x = rnd(g, 300, 776, dtype=dtype)
+    out = torch.ones(768)
+    cpu, gpu = run_both(dtype, "colsum", [x, out, 300, 768, 776])
+    close(gpu[1], cpu[1], torch.float32, "colsum", f32_tol=1e-5)
+    m2 = (torch.rand(300, generator=g) < 0.5).to(torch.uint8)
+    cpu, gpu = run_both(dtype, "masked_colsum", [x, m2, out, 300, 768, 776])
+    close(gpu[2], cpu[2], torch.float32, "masked colsum", f32_tol=1e-5)
+    dy, pre, dx = rnd(g, 64, 768, dtype=dtype), rnd(g, 64, 768, dtype=dtype) * 2, torch.zeros(64, 768, dtype=dtype)
+    cpu, gpu = run_both(dtype, "gelu_bwd", [dy, pre, dx, 64 * 768])
+    close(gpu[2], cpu[2], dtype, "gelu bwd")
+
+
+# ---------------------------------------------------------------- attention core
+SDPA_CASES = [(20, 20, 64, True), (64, 64, 64, False), (20, 64, 64, False), (64, 20, 64, True), (8, 16, 16, False),
+              (16, 8, 16, True), (33, 31, 32, True), (7, 64, 64, False)]
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nq,nk,dh,masked", SDPA_CASES)
+def test_sdpa_fwd_bwd(nq, nk, dh, masked, dtype, tr):
+    if dtype == torch.float32 and tr == 0:
+        pytest.skip("transpose-read switch only affects the bf16 MFMA kernel")
+    g = torch.Generator().manual_seed(nq * 64 + nk + dh)
+    B, H = 3, 4
+    d = H * dh
+    ld = 3 * d
+    qkv_q = rnd(g, B * nq, ld, dtype=dtype)          # q read from columns [0,d) of a fused buffer
+    qkv_k = rnd(g, B * nk, ld, dtype=dtype)
+    km = None
+    if masked:
+        km = torch.ones(B, nk, dtype=torch.uint8)
+        km[1, nk // 2:] = 0
+        km[2, 1:] = 0
+    o = torch.zeros(B * nq, d, dtype=dtype)
+    lse = torch.zeros(B * H * nq)
+    scale = 1.0 / math.sqrt(dh)
+    ops = hip(dtype)
+    ops.set_lds_transpose_read(tr)
+    try:
+        # k at columns [d,2d), v at [2d,3d) of the key-side buffer: pass offset views
+        fo, go = FakeOps(dtype), ops
+        cq, ck = qkv_q.clone(), qkv_k.clone()
+        co, cl = o.clone(), lse.clone()
+        fo.sdpa_fwd(cq, ck[:, d:], ck[:, 2 * d:], km, co, cl, B, H, nq, nk, dh, ld, ld, ld, d, scale)
+        gq, gk, go_, gl = qkv_q.cuda(), qkv_k.cuda(), o.cuda(), lse.cuda()
+        gkm = km.cuda() if km is not None else None
+        go.sdpa_fwd(gq, gk[:, d:], gk[:, 2 * d:], gkm, go_, gl, B, H, nq, nk, dh, ld, ld, ld, d, scale)
+        torch.cuda.synchronize()
+        close(go_.cpu(), co, dtype, f"sdpa o {nq}x{nk} dh{dh}")
+        close(gl.cpu(), cl, torch.float32, "sdpa lse", f32_tol=1e-5 if dtype == torch.float32 else 2e-2)
+        dout = rnd(g, B * nq, d, dtype=dtype)
+        cdq, cdk = torch.zeros(B * nq, ld, dtype=dtype), torch.zeros(B * nk, ld, dtype=dtype)
+        gdq, gdk = cdq.cuda(), cdk.cuda()
+        fo.sdpa_bwd(cq, ck[:, d:], ck[:, 2 * d:], km, dout, cl, cdq, cdk[:, d:], cdk[:, 2 * d:], B, H, nq, nk, dh,
+                    ld, ld, ld, d, ld, ld, ld, scale)
+        go.sdpa_bwd(gq, gk[:, d:], gk[:, 2 * d:], gkm, dout.cuda(), cl.cuda(), gdq, gdk[:, d:], gdk[:, 2 * d:], B, H,
+                    nq, nk, dh, ld, ld, ld, d, ld, ld, ld, scale)
+        torch.cuda.synchronize()
+        close(gdq.cpu()[:, :d], cdq[:, :d], dtype, "sdpa dq", bf16_tol=2.5e-2)
+        close(gdk.cpu()[:, d:2 * d], cdk[:, d:2 * d], dtype, "sdpa dk", bf16_tol=2.5e-2)
+        close(gdk.cpu()[:, 2 * d:], cdk[:, 2 * d:], dtype, "sdpa dv", bf16_tol=2.5e-2)
+        assert gdq.cpu()[:, d:].abs().max() == 0 and gdk.cpu()[:, :d].abs().max() == 0     # untouched columns
+    finally:
+        ops.set_lds_transpose_read(1)
+
+
+# ---------------------------------------------------------------- head losses
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("K", [10000, 50])
+def test_ce_and_featloss(K, dtype):
+    g = torch.Generator().manual_seed(K)
+    B, V, F = 4, 16, 64
+    M = B * V
+    Kp = (K + 7) // 8 * 8
+    logits = rnd(g, M, K) * 8
+    vm = (torch.rand(B, V, generator=g) < 0.5)
+    vm[3] = False                                   # an example without masked tokens (n_mask clamp)
+    cid = torch.randint(0, K, (B, V), generator=g)
+    labels = torch.where(vm, cid, torch.full_like(cid, -100))
+    vmu = vm.to(torch.uint8)
+    counts, nmask = torch.zeros(4), torch.zeros(B)
+    cpu, gpu = run_both(dtype, "mask_counts", [labels, vmu, counts, nmask, B, V])
+    assert torch.equal(gpu[2], cpu[2]) and torch.equal(gpu[3], cpu[3])
+    dl = torch.zeros(M, Kp, dtype=dtype)
+    loss = torch.zeros(2)
+    lse, am, mp = torch.zeros(M), torch.zeros(M, dtype=torch.int32), torch.zeros(M)
+    cpu2, gpu2 = run_both(dtype, "ce_fwd_bwd", [logits, labels, cpu[2], dl, loss, lse, am, mp, M, K, K, Kp])
+    close(gpu2[4], cpu2[4], torch.float32, "ce loss", f32_tol=1e-5)
+    close(gpu2[3], cpu2[3], dtype, "ce dlogits", scale=1.0 / max(cpu[2][0].item(), 1), bf16_tol=1e-2, f32_tol=1e-4)
+    close(gpu2[5], cpu2[5], torch.float32, "row lse", f32_tol=1e-5)
+    assert torch.equal(gpu2[6], cpu2[6])
+    close(gpu2[7], cpu2[7], torch.float32, "row maxprob", f32_tol=1e-4)
+    cent = rnd(g, K, F, dtype=dtype).relu()
+    pred = rnd(g, M, F, dtype=dtype) * 1.5
+    dp = torch.zeros(M, F, dtype=dtype)
+    loss2 = torch.zeros(2)
+    cpu3, gpu3 = run_both(dtype, "featloss_fwd_bwd", [pred, cent, cid, vmu, cpu[3], dp, loss2, B, V, F])
+    close(gpu3[6], cpu3[6], torch.float32, "feat loss", f32_tol=1e-5)
+    close(gpu3[5], cpu3[5], dtype, "feat dpred", f32_tol=1e-5)
+
+
+# ---------------------------------------------------------------- optimizer side
+@pytest.mark.parametrize("dtype", DT)
+def test_sumsq_adamw_cast(dtype):
+    g = torch.Generator().manual_seed(17)
+    n = 256 * 37
+    p, gr = rnd(g, n), rnd(g, n) * 3
+    m, v = rnd(g, n).abs() * 0.1, rnd(g, n).abs() * 0.1
+    ss = torch.zeros(1)
+    cpu, gpu = run_both(dtype, "sumsq", [gr, ss, n])
+    close(gpu[1], cpu[1], torch.float32, "sumsq", f32_tol=1e-5)
+    flags = (torch.rand(n // 256, generator=g) < 0.5).to(torch.uint8)
+    pc = torch.zeros(n, dtype=dtype)
+    lrs = torch.tensor([1e-3, 1 - 0.9 ** 3, 1 - 0.999 ** 3, 0.0])
+    args = [p, gr, m, v, pc, flags, cpu[1], lrs, n, 0.9, 0.999, 1e-6, 0.01, 1.0]
+    cpu2, gpu2 = run_both(dtype, "adamw", args, dict(grad_scale=0.5))
+    for i, nm in ((0, "p"), (2, "m"), (3, "v")):
+        close(gpu2[i], cpu2[i], torch.float32, "adamw " + nm, f32_tol=2e-6)
+    if dtype == torch.bfloat16:
+        close(gpu2[4], cpu2[0], dtype, "adamw compute copy", bf16_tol=4e-3)
+    src = rnd(g, 1000)
+    dst = torch.zeros(1000, dtype=dtype)
+    cpu3, gpu3 = run_both(dtype, "cast_from_f32", [src, dst, 1000])
+    assert torch.equal(gpu3[1], cpu3[1])              # round-to-nearest-even, bit exact
+    back = torch.zeros(1000)
+    cpu4, gpu4 = run_both(dtype, "cast_to_f32", [cpu3[1], back, 1000])
+    assert torch.equal(gpu4[1], cpu4[1])
+
+
+def test_error_reporting():
+    from xlxmert_amd._lib import XlError
+    ops = hip(torch.float32)
+    x = torch.zeros(4, 6, device="cuda")
+    with pytest.raises(XlError, match="multiple"):
+        ops.layernorm_fwd(x, x, x, x, x, x, 4, 6, 1e-12)          # row length not a multiple of 4
+    with pytest.raises(XlError, match="CPU tensor"):
+        ops.colsum(torch.zeros(4, 8), x, 4, 8, 8)

@@ -1,0 +1,112 @@
+"""Step semantics and the data-parallel exchange, on CPU: kernels replaced by FakeOps,
+collectives over gloo with world_size 2."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import lxmert_oracle as O
+from fake_ops import FakeOps
+from xlxmert_amd.config import XLxmertConfig
+from xlxmert_amd.params import ParamStore
+from xlxmert_amd.trainer import PretrainStep, linear_schedule, synthetic_batch
+
+TINY = dict(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128, max_position_embeddings=32,
+            visual_feat_dim=32, num_clusters=56, l_layers=2, x_layers=2, r_layers=1)
+
+
+def oracle_cfg(cfg):
+    return O.OracleConfig(**{k: getattr(cfg, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                         "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                         "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                         "visual_pos_dim", "num_clusters")})
+
+
+def make_step(cfg, B, L, grid, seed=3, **kw):
+    store = ParamStore(cfg, "cpu", torch.float32, task="vis_mask")
+    sd = O.make_state_dict(oracle_cfg(cfg), seed)
+    store.load_named(sd)
+    return PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store,
+                        ops=FakeOps(torch.float32), total_steps=10, **kw), sd
+
+
+def oracle_grads(cfg, sd, batch):
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and k != "vis_emb.weight") for k, v in sd.items()}
+    sd["obj_predict_head.out_cluster.weight"] = sd["vis_emb.weight"]
+    out = O.xlxmert_vis_mask_forward(sd, oracle_cfg(cfg), batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                     batch["cluster_ids"], batch["vis_mask"], batch["obj_labels"])
+    out["total_loss"].backward()
+    return {k: v.grad for k, v in sd.items() if v.grad is not None}, out
+
+
+def test_two_steps_match_closed_form():
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 3, 8, 4
+    tr, sd = make_step(cfg, B, L, grid, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2)
+    ref = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in ref.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in ref.items()}
+    for t in (1, 2):
+        batch = synthetic_batch(cfg, B, L, grid, seed=100 + t)
+        losses = tr.step(batch)
+        grads, out = oracle_grads(cfg, ref, batch)
+        assert abs(losses[0].item() - out["obj_loss"].item()) < 3e-5
+        assert abs(losses[1].item() - out["feat_loss"].item()) < 3e-5
+        names = sorted(grads)
+        norm, clipped = O.clip_grad_norm([grads[k] for k in names], 1.0)
+        assert abs(tr.grad_norm() - norm.item()) < 1e-4 * max(1.0, norm.item())
+        lr = 1e-2 * linear_schedule(t - 1, 2, 10)
+        for k, g in zip(names, clipped):
+            wd = 0.0 if ("bias" in k or "LayerNorm.weight" in k) else 0.01
+            ref[k], m[k], v2[k] = O.adamw_update(ref[k], g, m[k], v2[k], t, lr, weight_decay=wd)
+            ref[k] = ref[k].detach()
+        for k in names:
+            d = (tr.store.view(k) - ref[k]).abs().max().item()
+            assert d < 2e-5, (t, k, d)
+    # tensors without a gradient are never touched (the reference's AdamW skips grad-None tensors)
+    assert torch.equal(tr.store.view("bert.pooler.dense.weight"), sd["bert.pooler.dense.weight"])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 2, 8, 4
+    tr, sd = make_step(cfg, B, L, grid, lr=1e-2)
+    batch = synthetic_batch(cfg, B, L, grid, seed=500 + rank)         # disjoint per-rank minibatch
+    tr.step(batch)
+    torch.save({k: tr.store.view(k).clone() for k in tr.store.names()}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world2_gloo(tmp_path):
+    """2 ranks x different minibatches: replicas stay identical and equal one AdamW step on the MEAN of the per-rank
+    gradients (DDP semantics: mean of per-shard mean losses, SURVEY 8e caveat)."""
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    cfg = XLxmertConfig(**TINY)
+    sd = O.make_state_dict(oracle_cfg(cfg), 3)
+    gs = [oracle_grads(cfg, sd, synthetic_batch(cfg, 2, 8, 4, seed=500 + r))[0] for r in range(world)]
+    names = sorted(gs[0])
+    mean = [(gs[0][k] + gs[1][k]) / 2 for k in names]
+    _, clipped = O.clip_grad_norm(mean, 1.0)
+    lr = 1e-2 * linear_schedule(0, 0, 10)
+    for k, g in zip(names, clipped):
+        p, _, _ = O.adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr)
+        assert (r0[k] - p).abs().max().item() < 2e-5, k

@@ -1,0 +1,163 @@
+"""Masked-visual-token pretraining step on one GPU per process (data parallel over RCCL).
+
+Reproduces the INTENDED step of the reference trainer (ref x-lxmert/src/pretrain/lxmert_pretrain.py:143-225,
+295-366): labels `obj_labels[~vis_mask] = -100`, `attention_mask = word_id > 0`,
+one forward, one backward, gradient all-reduce (DDP mean), `clip_grad_norm_(1.0)`, transformers==4.1.1 AdamW
+(betas .9/.999, eps 1e-6, bias correction, decoupled decay on tensors whose name contains neither "bias" nor
+"LayerNorm.weight"), linear warm-up then linear decay, gradients dropped after the step.
+
+`weight_decay` (default 0.0 = the 4.1.1 class default) and `warmup_ratio` (default 0.05, what
+scripts/pretrain.bash suggests) have no value anywhere in the reference: assumptions.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from .config import XLxmertConfig
+from .engine import Engine
+from .ops import HipOps
+from .params import ParamStore
+
+
+def init_reference_weights(store, seed):
+    """HF `_init_weights`: Linear/Embedding weights ~ N(0, initializer_range), biases 0, LayerNorm (1, 0),
+    embedding rows at padding_idx=0 zeroed; mask_feat zeros (ref lxrt/modeling.py:92)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    std = store.cfg.initializer_range
+    with torch.no_grad():
+        for name, m in store.index.items():
+            v = store.view(name)
+            if name == "mask_feat" or name.endswith(".bias"):
+                v.zero_()
+            elif name.endswith("LayerNorm.weight") or name.endswith("layer_norm.weight"):
+                v.fill_(1.0)
+            else:
+                v.copy_((torch.randn(m.shape, generator=g) * std).to(v.device))
+                if "embeddings.weight" in name:
+                    v[0].zero_()
+
+
+def linear_schedule(step, warmup_steps, total_steps):
+    """transformers.get_linear_schedule_with_warmup (ref lxmert_pretrain.py:138-139); `step` counts completed updates."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))
+
+
+class PretrainStep:
+    def __init__(self, cfg: XLxmertConfig, batch_size, text_len=20, n_grids=64, dtype=torch.bfloat16, device=None,
+                 lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
+                 betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=True, train_dropout=False, store=None,
+                 bucket_mb=64, ops=None):
+        """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps."""
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.store = store if store is not None else ParamStore(cfg, self.device, dtype, task="vis_mask")
+        self.ops = ops if ops is not None else HipOps(dtype)
+        if store is None:
+            init_reference_weights(self.store, seed)          # same seed on every rank == DDP's rank-0 broadcast
+        self.engine = Engine(cfg, self.store, self.ops, batch_size, text_len, n_grids, need_lang=False,
+                             train_dropout=train_dropout)
+        self.engine.sync_compute_weights()
+        self.store.ensure_adam_state()
+        self.lr, self.wd, self.clip = lr, weight_decay, clip_grad_norm
+        self.betas, self.eps = betas, eps
+        self.total_steps, self.warmup_steps = total_steps, int(total_steps * warmup_ratio)
+        self.feat_loss = feat_loss
+        self.t = 0
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.lrs = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._lrs_host = torch.zeros(4, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.zeros(4)
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        if self.world > 1:
+            self._check_replicas()
+
+    def _check_replicas(self):
+        """identical initial parameters on every rank (stands in for DDP's constructor broadcast)."""
+        s = self.store.master[:self.store.n_used].double().sum().reshape(1)
+        lo, hi = s.clone(), s.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if lo.item() != hi.item():
+            dist.broadcast(self.store.master, src=0)
+            self.engine.sync_compute_weights()
+
+    def set_centroids(self, centroids):
+        self.store.set_centroids(centroids)
+
+    def allreduce_grads(self):
+        """DDP semantics: sum over ranks here, the 1/world factor is folded into the optimizer kernel."""
+        g = self.store.grad[:self.store.n_used]
+        for s in range(0, g.numel(), self.bucket_elems):
+            dist.all_reduce(g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM)
+
+    def step(self, batch):
+        """batch: dict with input_ids, attention_mask (optional), token_type_ids (optional), visual_pos,
+        cluster_ids, vis_mask, obj_labels (optional: derived from cluster_ids/vis_mask as the reference does)."""
+        eng, st, ops = self.engine, self.store, self.ops
+        ids = batch["input_ids"]
+        am = batch.get("attention_mask")
+        if am is None:
+            am = ids > 0                                       # ref lxmert_pretrain.py:206
+        labels = batch.get("obj_labels")
+        if labels is None:
+            labels = batch["cluster_ids"].clone()
+            labels[~batch["vis_mask"].bool()] = -100           # ref lxmert_pretrain.py:163-166
+        eng.set_step_seed(self.t * self.world + self.rank)
+        eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
+                       vis_mask=batch["vis_mask"], obj_labels=labels)
+        losses = eng.vis_mask_forward_backward(self.feat_loss)
+        if self.world > 1:
+            self.allreduce_grads()
+        self.optimizer_step()
+        return losses
+
+    def optimizer_step(self):
+        st, ops = self.store, self.ops
+        self.t += 1
+        b1, b2 = self.betas
+        lr = self.lr * linear_schedule(self.t - 1, self.warmup_steps, self.total_steps)
+        self._lrs_host[0] = lr
+        self._lrs_host[1] = 1.0 - b1 ** self.t
+        self._lrs_host[2] = 1.0 - b2 ** self.t
+        self.lrs.copy_(self._lrs_host, non_blocking=True)
+        n = st.n_used
+        if self.clip > 0:
+            self.sumsq.zero_()
+            ops.sumsq(st.grad, self.sumsq, n)
+        ops.adamw(st.master, st.grad, st.exp_avg, st.exp_avg_sq,
+                  st.compute if st.compute_dtype != torch.float32 else None, st.decay_flags,
+                  self.sumsq if self.clip > 0 else None, self.lrs, n, b1, b2, self.eps, self.wd, self.clip,
+                  grad_scale=1.0 / self.world)
+
+    def grad_norm(self):
+        return math.sqrt(float(self.sumsq.item())) / self.world
+
+
+def synthetic_batch(cfg, B, L=20, grid=8, seed=9595, device="cpu", ragged=True):
+    """SURVEY.md section 8d generators (torch RNG): ids with [CLS]=101 / [SEP]=102 / PAD=0, lengths U{6..L};
+    cluster ids U{0..K-1}; `--vis_mask_predict` masks (n ~ U{1..V} random positions per example)."""
+    g = torch.Generator().manual_seed(seed)
+    V = grid * grid
+    ids = torch.randint(1000 if cfg.vocab_size > 2000 else 1, cfg.vocab_size, (B, L), generator=g)
+    ids[:, 0] = min(101, cfg.vocab_size - 2)
+    lens = torch.randint(min(6, L), L + 1, (B,), generator=g) if ragged else torch.full((B,), L)
+    ar = torch.arange(L)[None, :]
+    ids[ar == (lens[:, None] - 1)] = min(102, cfg.vocab_size - 1)
+    ids[ar >= lens[:, None]] = 0
+    cid = torch.randint(0, cfg.num_clusters, (B, V), generator=g)
+    n_mask = torch.randint(1, V + 1, (B,), generator=g)
+    rank = torch.rand(B, V, generator=g).argsort(1).argsort(1)
+    vm = rank < n_mask[:, None]
+    lab = cid.clone()
+    lab[~vm] = -100
+    pos = torch.zeros(grid * grid, 4)
+    for i in range(grid):
+        for j in range(grid):
+            pos[i * grid + j] = torch.tensor([j / grid, i / grid, (j + 1) / grid, (i + 1) / grid])
+    batch = {"input_ids": ids, "attention_mask": ids > 0, "token_type_ids": torch.zeros_like(ids),
+             "cluster_ids": cid, "vis_mask": vm, "obj_labels": lab, "visual_pos": pos[None].expand(B, -1, -1).contiguous()}
+    return {k: v.to(device) for k, v in batch.items()}
