@@ -25,6 +25,18 @@ GFLOP_PER_EXAMPLE = 50.782      # necessary fwd+bwd, SURVEY.md section 8d / Appe
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (measured 2495)
 
 
+def usable_cores():
+    """cores this process may actually use: min(affinity mask, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(cfg, bs, budget_s=20.0):
     """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores: fwd + bwd + clip + AdamW."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -33,7 +45,7 @@ def cpu_baseline(cfg, bs, budget_s=20.0):
     keys = ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size", "max_position_embeddings",
             "type_vocab_size", "l_layers", "x_layers", "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")
     oc = O.OracleConfig(**{k: getattr(cfg, k) for k in keys})
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = O.make_state_dict(oc, 9595, perturb=False)
     leaf = {k: v.clone().requires_grad_(v.is_floating_point() and k != "vis_emb.weight") for k, v in sd.items()}

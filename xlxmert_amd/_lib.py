@@ -5,6 +5,8 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- must come first: loads the HIP runtime this process will use (torch bundles its own)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "xlxmert_hip.h")
 LIB_PATH = os.path.join(HERE, "libxlxmert_hip.so")
