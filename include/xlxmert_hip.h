@@ -74,7 +74,11 @@ int xl_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
  * accumulates colsum(dx) (= bias gradient of the dense layer feeding this LayerNorm). */
 int xl_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                      const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev,
-                     int M, int N, int dtype, void* stream);
+                     int M, int N, float* workspace, int dtype, void* stream);
+/* Column reductions (LayerNorm affine / bias gradients, column sums) run as a two-stage reduction through a
+ * caller-owned fp32 `workspace` of at least xl_workspace_floats(N) elements (per-block partial slabs + one
+ * combine launch); workspace == NULL falls back to fp32 atomics on the output. */
+int64_t xl_workspace_floats(int N);
 
 /* visual feature encoder tail (HF:468-476): y = (LN_v(xv) + LN_b(pos W_b^T + b_b)) / 2
  * xv = visn_fc output [M,N]; pos fp32 [M,P] (P<=8); box weights fp32 [N,P].
@@ -88,7 +92,7 @@ int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, const float
                    const float* mean_v, const float* rstd_v, const float* mean_b, const float* rstd_b,
                    void* dxv, float* dgv, float* dbv, float* dgb, float* dbb,
                    float* dwbox, float* dbbox, float* dbias_visn,
-                   int M, int N, int P, int dtype, void* stream);
+                   int M, int N, int P, float* workspace, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- embeddings (HF:191-214)
  * y[b,l] = LN(word[ids[b,l]] + pos[l] + type[tt[b,l]]); tables in `dtype`; saves pre-LN sum + stats. */
@@ -106,9 +110,10 @@ int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t* tt,
 int xl_codebook_gather(const int64_t* cluster_ids, const uint8_t* vis_mask, const void* centroids,
                        const float* mask_feat, void* feats, int M, int F, int dtype, void* stream);
 /* out[n] += sum over rows m with mask[m]!=0 of x[m,n]    (d mask_feat pre-image; also generic masked colsum) */
-int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, int dtype, void* stream);
+int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, float* workspace,
+                     int dtype, void* stream);
 /* out[n] += sum_m x[m,n]   (bias gradients) */
-int xl_colsum(const void* x, float* out, int M, int N, int ldx, int dtype, void* stream);
+int xl_colsum(const void* x, float* out, int M, int N, int ldx, float* workspace, int dtype, void* stream);
 
 /* dx = dy * gelu_erf'(pre), n elements (head transform backward, HF:582-586) */
 int xl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);

@@ -78,7 +78,10 @@ class FakeOps:
         dx = rstd[:, None] * (gd - c1 - xh * c2)
         return dx, (dy * xh).sum(0), dy.sum(0)
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N):
+    def workspace_floats(self, N):
+        return 4096 * N
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, ws=None):
         d, dg, db = self._ln_bwd(v2(dy, M, N, N).float(), v2(x, M, N, N).float(), gamma.float(), mean[:M], rstd[:M])
         v2(dx, M, N, N).copy_(d)
         dgamma.add_(dg)
@@ -94,7 +97,7 @@ class FakeOps:
         mean_v.copy_(mv); rstd_v.copy_(rv); mean_b.copy_(mb); rstd_b.copy_(rb)
 
     def visn_ln_bwd(self, dy, xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b, dxv, dgv, dbv, dgb, dbb,
-                    dwbox, dbbox, dbias_visn, M, N, P):
+                    dwbox, dbbox, dbias_visn, M, N, P, ws=None):
         dh = v2(dy, M, N, N).float() * 0.5
         d1, dg1, db1 = self._ln_bwd(dh, v2(xv, M, N, N).float(), gv, mean_v, rstd_v)
         box = pos.view(M, P) @ wbox.view(N, P).t() + bbox
@@ -129,11 +132,11 @@ class FakeOps:
             f = torch.where(vis_mask.view(-1, 1) != 0, mask_feat.view(1, -1), f)
         v2(feats, M, F, F).copy_(f)
 
-    def masked_colsum(self, x, mask, out, M, N, ldx):
+    def masked_colsum(self, x, mask, out, M, N, ldx, ws=None):
         xx = v2(x, M, N, ldx).float()
         out[:N].add_((xx * (mask.view(-1, 1) != 0)).sum(0))
 
-    def colsum(self, x, out, M, N, ldx):
+    def colsum(self, x, out, M, N, ldx, ws=None):
         torch.as_strided(out, (N,), (1,)).add_(v2(x, M, N, ldx).float().sum(0))
 
     def gelu_bwd(self, dy, pre, dx, n):

@@ -25,7 +25,8 @@ def run_both(dtype, name, args, kwargs=None):
     cpu = [a.clone() if torch.is_tensor(a) else a for a in args]
     gpu = [a.cuda() if torch.is_tensor(a) else a for a in args]
     getattr(FakeOps(dtype), name)(*cpu, **kwargs)
-    getattr(hip(dtype), name)(*gpu, **kwargs)
+    gkw = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kwargs.items()}
+    getattr(hip(dtype), name)(*gpu, **gkw)
     torch.cuda.synchronize()
     return cpu, [a.cpu() if torch.is_tensor(a) else a for a in gpu]
 
@@ -118,9 +119,10 @@ def test_gemm_in_place_residual_bf16():
 
 
 # ---------------------------------------------------------------- LayerNorm family
+@pytest.mark.parametrize("use_ws", [True, False])
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N", [(37, 768), (5, 64), (130, 1536), (64, 128)])
-def test_layernorm_fwd_bwd(M, N, dtype):
+@pytest.mark.parametrize("M,N", [(37, 768), (5, 64), (130, 1536), (64, 128), (5000, 768)])
+def test_layernorm_fwd_bwd(M, N, dtype, use_ws):
     g = torch.Generator().manual_seed(M + N)
     x = rnd(g, M, N, dtype=dtype) * 2 + 0.5
     gamma, beta = rnd(g, N) * 0.2 + 1, rnd(g, N) * 0.1
@@ -133,16 +135,18 @@ def test_layernorm_fwd_bwd(M, N, dtype):
     dy = rnd(g, M, N, dtype=dtype)
     dx = torch.zeros(M, N, dtype=dtype)
     dg, db, dbp = torch.ones(N), torch.ones(N), torch.ones(N)
-    cpu, gpu = run_both(dtype, "layernorm_bwd", [dy, x, gamma, cpu[4], cpu[5], dx, dg, db, dbp, M, N])
+    ws = torch.zeros(4096 * N) if use_ws else None      # xl_workspace_floats(N): two-stage reduction; None: atomics
+    cpu, gpu = run_both(dtype, "layernorm_bwd", [dy, x, gamma, cpu[4], cpu[5], dx, dg, db, dbp, M, N], dict(ws=ws))
     close(gpu[5], cpu[5], dtype, "ln dx")
     for i, nm in ((6, "dgamma"), (7, "dbeta"), (8, "dbias_prev")):
         close(gpu[i], cpu[i], torch.float32, "ln " + nm, f32_tol=2e-5 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("M,use_ws", [(130, False), (130, True), (3000, True)])
 @pytest.mark.parametrize("dtype", DT)
-def test_visn_ln_fwd_bwd(dtype):
+def test_visn_ln_fwd_bwd(dtype, M, use_ws):
     g = torch.Generator().manual_seed(3)
-    M, N, P = 130, 768, 4
+    N, P = 768, 4
     xv = rnd(g, M, N, dtype=dtype)
     pos = torch.rand(M, P, generator=g)
     wbox, bbox = rnd(g, N, P) * 0.5, rnd(g, N) * 0.1
@@ -156,7 +160,8 @@ def test_visn_ln_fwd_bwd(dtype):
     dy = rnd(g, M, N, dtype=dtype)
     outs = [torch.zeros(M, N, dtype=dtype)] + [torch.zeros(N) for _ in range(4)] + [torch.zeros(N, P), torch.zeros(N),
                                                                                     torch.zeros(N)]
-    cpu2, gpu2 = run_both(dtype, "visn_ln_bwd", [dy, xv, pos, wbox, bbox, gv, gb, *cpu[9:13], *outs, M, N, P])
+    cpu2, gpu2 = run_both(dtype, "visn_ln_bwd", [dy, xv, pos, wbox, bbox, gv, gb, *cpu[9:13], *outs, M, N, P],
+                          dict(ws=torch.zeros(4096 * N) if use_ws else None))
     close(gpu2[11], cpu2[11], dtype, "visn dxv")
     for i in range(12, 19):
         close(gpu2[i], cpu2[i], torch.float32, f"visn grad {i}", f32_tol=1e-4 if dtype == torch.float32 else 1e-2)
@@ -199,11 +204,16 @@ def test_codebook_colsums_gelu(dtype):
     close(gpu[4], cpu[4], dtype, "codebook gather", f32_tol=0, bf16_tol=4e-3)
     x = rnd(g, 300, 776, dtype=dtype)
     out = torch.ones(768)
-    cpu, gpu = run_both(dtype, "colsum", [x, out, 300, 768, 776])
-    close(gpu[1], cpu[1], torch.float32, "colsum", f32_tol=1e-5)
     m2 = (torch.rand(300, generator=g) < 0.5).to(torch.uint8)
-    cpu, gpu = run_both(dtype, "masked_colsum", [x, m2, out, 300, 768, 776])
-    close(gpu[2], cpu[2], torch.float32, "masked colsum", f32_tol=1e-5)
+    for ws in (None, torch.zeros(4096 * 768)):
+        cpu, gpu = run_both(dtype, "colsum", [x, out, 300, 768, 776], dict(ws=ws))
+        close(gpu[1], cpu[1], torch.float32, "colsum", f32_tol=1e-5)
+        cpu, gpu = run_both(dtype, "masked_colsum", [x, m2, out, 300, 768, 776], dict(ws=ws))
+        close(gpu[2], cpu[2], torch.float32, "masked colsum", f32_tol=1e-5)
+    xl = rnd(g, 40000, 72, dtype=dtype)                 # many row slabs (two-stage path with > 128 chunks)
+    outl = torch.zeros(64)
+    cpu, gpu = run_both(dtype, "colsum", [xl, outl, 40000, 64, 72], dict(ws=torch.zeros(4096 * 64)))
+    close(gpu[1], cpu[1], torch.float32, "colsum tall", f32_tol=1e-4)
     dy, pre, dx = rnd(g, 64, 768, dtype=dtype), rnd(g, 64, 768, dtype=dtype) * 2, torch.zeros(64, 768, dtype=dtype)
     cpu, gpu = run_both(dtype, "gelu_bwd", [dy, pre, dx, 64 * 768])
     close(gpu[2], cpu[2], dtype, "gelu bwd")

@@ -20,7 +20,7 @@ def parse_header(path=HEADER):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(xl_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(xl_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         alist = []
         if args and args != "void":
@@ -28,7 +28,7 @@ def parse_header(path=HEADER):
                 a = " ".join(a.split())
                 mm = re.match(r"(.*?)(\w+)$", a)
                 alist.append((mm.group(1).strip(), mm.group(2)))
-        protos[name] = ("char*" if "char" in ret else "int", alist)
+        protos[name] = ("char*" if "char" in ret else ret, alist)
     return protos
 
 
@@ -53,7 +53,8 @@ class Lib:
         for name, (ret, args) in self.protos.items():
             fn = getattr(self._dll, name)        # raises AttributeError if the .so lacks a declared symbol
             fn.argtypes = [_ctype(t) for t, _ in args]
-            fn.restype = ctypes.c_char_p if ret == "char*" else ctypes.c_int
+            fn.restype = {"char*": ctypes.c_char_p, "int64_t": ctypes.c_int64}.get(ret, ctypes.c_int)
+        self._checked = {n for n, (r, _) in self.protos.items() if r == "int"}
         self.path = path
 
     def call(self, name, *args):

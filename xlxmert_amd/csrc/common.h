@@ -104,6 +104,30 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// bf16-path variants: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, one exp + one rcp); the exponential
+// exp(-x^2/2) is shared between erf(x/sqrt2) and the Gaussian pdf of the derivative.
+__device__ __forceinline__ void erf_parts(float x, float& erf_v, float& e) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    e = __expf(-ax * ax);                       // = exp(-x^2/2)
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float r = 1.0f - poly * t * e;
+    erf_v = copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float er, e;
+    erf_parts(x, er, e);
+    return 0.5f * x * (1.0f + er);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float er, e;
+    erf_parts(x, er, e);
+    return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
+}
+
 // ------------------------------------------------------------------ counter-based dropout
 // keep-mask for element `idx` under (seed): two rounds of a 64->32 bit mixer (splitmix64 finaliser).
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {

@@ -3,18 +3,22 @@
 //   C[M,N] = alpha * sum_k A(m,k) B(n,k) (+bias) -> epilogue     (see include/xlxmert_hip.h: xl_gemm)
 //
 // Two kernels:
-//   gemm_bf16_mfma_kernel  bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.
-//       128x128x64 block tile, 4 waves (2x2), each wave a 64x64 tile = 2x2 MFMA fragments.
-//       Operands are staged global -> VGPR -> LDS (double buffered, one barrier per K tile).
-//       K-major operands ([rows][k]) are kept row-major in LDS with a 16-byte-chunk XOR swizzle
-//       (chunk ^= (row>>1)&7) so that ds_read_b128 fragment reads are conflict free.
-//       M-major operands ([k][rows]; the dX / dW contractions) are kept as stored and turned into
-//       MFMA fragments by ds_read_b64_tr_b16 (LDS transpose read); 64-byte XOR swizzle on k&3.
-//       The MFMA k-slot <-> k mapping is applied identically to A and B, which is all the
-//       contraction needs.
+//   gemm_bf16_mfma_kernel<AK, BKM, TR, BM, BN, WM, WN>
+//       bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Block tile BM x BN x 64 with WM x WN waves
+//       (128x128 / 2x2 waves for shapes with few tiles, 256x256 / 2x4 waves where the grid still fills the chip:
+//       a 128x128 tile at full MFMA rate would need ~39 TB/s of L2->LDS traffic, more than the L2s deliver).
+//       Operands are staged by LDS-DMA (global_load_lds, 16 B per lane) into a double-buffered LDS ring, one
+//       barrier per K tile.  K-major operands ([rows][k]) sit row-major in LDS with a 16-byte-chunk XOR swizzle
+//       (chunk ^= (row>>1)&7) so that ds_read_b128 fragment reads are conflict free; M-major operands ([k][rows];
+//       the dX / dW contractions) sit as stored and become MFMA fragments through ds_read_b64_tr_b16 (LDS
+//       transpose read) with a 64-byte XOR swizzle on k&3.  Because LDS-DMA writes lane-linear, both swizzles are
+//       applied to the per-lane SOURCE address.  The MFMA k-slot <-> k mapping is applied identically to A and B,
+//       which is all the contraction needs.
 //   gemm_generic_kernel    any dtype / any alignment, fp32 FMA, 64x64x16 tile.  It is the exact-fp32
 //       path (XL_F32: parity configuration) and the fallback for operands the MFMA loader cannot
 //       take (leading dimension not a multiple of 8 elements).
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace xl {
@@ -23,13 +27,13 @@ struct GemmParams {
     const void* A; const void* B; void* C;
     const float* bias; const void* residual; void* aux;
     int M, N, K, lda, ldb, ldc, ldr, ldx;
-    int epilogue, out_f32, atomic_out, splitk, kper;
+    int epilogue, out_f32, atomic_out, splitk, kper, vec_epi;
     float alpha, p_drop, inv_keep;
     uint64_t seed;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, ablate;
 };
 
-// ------------------------------------------------------------------ epilogue (shared by both kernels)
+// ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)
 template <typename TIn>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float v, bool add_bias) {
     v *= p.alpha;
@@ -65,7 +69,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 
 // tile id -> (tile_m, tile_n, split) with an XCD-aware remap: block b runs on XCD b%8 (observed
 // placement, speed only); give every XCD a contiguous chunk of a grouped (8 m-tiles x all n) order
-// so that the 32 tiles co-resident on one XCD share A row panels and B column panels in its L2.
+// so that the tiles co-resident on one XCD share A row panels and B column panels in its L2.
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn, int& z) {
     const int nblk = gridDim.x;
     const int b = blockIdx.x;
@@ -141,8 +145,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p, int a_k
 }
 
 // ================================================================== bf16 MFMA kernel
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;     // 16 KiB per operand tile
+constexpr int BK = 64;
 
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 v8bf16_t;
@@ -153,76 +156,87 @@ __device__ __forceinline__ bf16x4_t lds_tr_read(const uint8_t* ptr) {
     return __builtin_bit_cast(bf16x4_t, r);
 }
 
-// global -> registers: 4 x 16 bytes per thread for one 128(rows) x 64(k) operand tile
-template <bool KMAJ>
-__device__ __forceinline__ void gload_tile(const bf16_t* __restrict__ P, int ld, int row0, int rows_ext,
-                                           int k0, int kend, uint4 (&r)[4], int tid) {
+// Operand tile of ROWS x 64(k) bf16 in LDS.
+//   K-major: [row][k], row pitch 128 B, 16-byte chunk c of row r stored at chunk c ^ ((r>>1)&7).
+//   M-major: [k][row], k-row pitch ROWS*2 B, byte b of k-row kr stored at b ^ ((kr&3)<<6).
+template <bool KMAJ, int ROWS>
+struct OpTile {
+    static constexpr int BYTES = ROWS * BK * 2;
+    static constexpr int RP = ROWS * 2;               // M-major k-row pitch (bytes)
+
+    // (strided index, contiguous chunk) of the 16 bytes stored at LDS byte offset o of the tile
+    __device__ static __forceinline__ void decode(int o, int& rs, int& c) {
+        if (KMAJ) { rs = o >> 7; c = ((o >> 4) & 7) ^ ((rs >> 1) & 7); }
+        else { rs = o / RP; c = ((o % RP) ^ ((rs & 3) << 6)) >> 4; }
+    }
+    __device__ static __forceinline__ int encode(int rs, int c) {
+        if (KMAJ) return rs * 128 + ((c ^ ((rs >> 1) & 7)) << 4);
+        return rs * RP + ((c << 4) ^ ((rs & 3) << 6));
+    }
+    // MFMA operand fragment: rows [r0, r0+32) (lane -> row l&31), k-slots s*16 + (l>>5)*8 + 0..7
+    template <bool TR>
+    __device__ static __forceinline__ bf16x8_t frag(const uint8_t* tile, int r0, int s, int lane) {
+        if (KMAJ) {
+            const int row = r0 + (lane & 31);
+            return *reinterpret_cast<const bf16x8_t*>(tile + encode(row, s * 2 + (lane >> 5)));
+        } else if (TR) {
+            // 16-lane group reads a [4 k][16 rows] block; lane t supplies the address of k-row t>>2,
+            // row-chunk (t&3)*4 and receives column t (4 consecutive k).
+            const int t = lane & 15;
+            const int mb = (r0 + ((lane >> 4) & 1) * 16 + (t & 3) * 4) * 2;
+            const int k0r = s * 16 + (lane >> 5) * 8 + (t >> 2), k1r = k0r + 4;
+            bf16x4_t lo = lds_tr_read(tile + k0r * RP + (mb ^ ((k0r & 3) << 6)));
+            bf16x4_t hi = lds_tr_read(tile + k1r * RP + (mb ^ ((k1r & 3) << 6)));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            const int m = r0 + (lane & 31);
+            bf16x8_t f;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        int gr, gc, lim;              // gr: index along the strided dim, gc: start along the contiguous dim
-        bool row_ok;
-        if (KMAJ) { gr = row0 + ps * 32 + (tid >> 3); gc = k0 + (tid & 7) * 8; row_ok = gr < rows_ext; lim = kend; }
-        else      { gr = k0 + ps * 16 + (tid >> 4);   gc = row0 + (tid & 15) * 8; row_ok = gr < kend;  lim = rows_ext; }
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row_ok) {
-            const bf16_t* src = P + (size_t)gr * ld + gc;
-            if (gc + 8 <= lim) {
-                v = *reinterpret_cast<const uint4*>(src);
-            } else if (gc < lim) {            // ragged tail of the contiguous dim
-                bf16_t e[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) e[i] = (gc + i < lim) ? src[i] : (bf16_t)0;
-                v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
-                v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+            for (int j = 0; j < 8; ++j) {
+                const int k = s * 16 + (lane >> 5) * 8 + j;
+                f[j] = *reinterpret_cast<const short*>(tile + k * RP + ((m * 2) ^ ((k & 3) << 6)));
             }
+            return f;
         }
-        r[ps] = v;
     }
-}
+};
 
-template <bool KMAJ>
-__device__ __forceinline__ void lds_store_tile(uint8_t* tile, const uint4 (&r)[4], int tid) {
+// predicated (zero-filling) load of the 16 bytes that belong at LDS offset o: ragged last k-tile only
+template <bool KMAJ, int ROWS>
+__device__ __forceinline__ uint4 gload16(const bf16_t* __restrict__ P, int ld, int row0, int rows_ext, int k0, int kend, int o) {
+    int rs, c;
+    OpTile<KMAJ, ROWS>::decode(o, rs, c);
+    int gr, gc, lim;
+    bool ok;
+    if (KMAJ) { gr = row0 + rs; gc = k0 + c * 8; ok = gr < rows_ext; lim = kend; }
+    else { gr = k0 + rs; gc = row0 + c * 8; ok = gr < kend; lim = rows_ext; }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) {
+        const bf16_t* src = P + (size_t)gr * ld + gc;
+        if (gc + 8 <= lim) {
+            v = *reinterpret_cast<const uint4*>(src);
+        } else if (gc < lim) {
+            bf16_t e[8];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        int off;
-        if (KMAJ) { const int rr = ps * 32 + (tid >> 3), c = tid & 7; off = rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4); }
-        else      { const int kr = ps * 16 + (tid >> 4), c = tid & 15; off = kr * 256 + ((c << 4) ^ ((kr & 3) << 6)); }
-        *reinterpret_cast<uint4*>(tile + off) = r[ps];
-    }
-}
-
-// MFMA operand fragment: rows [r0, r0+32) of the tile (lane -> row l&31), k-slots s*16 + (l>>5)*8 + 0..7
-template <bool KMAJ, bool TR>
-__device__ __forceinline__ bf16x8_t lds_load_frag(const uint8_t* tile, int r0, int s, int lane) {
-    if (KMAJ) {
-        const int row = r0 + (lane & 31);
-        const int c = s * 2 + (lane >> 5);
-        return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-    } else if (TR) {
-        // 16-lane group g reads a [4 k][16 rows] block; lane t supplies the address of k-row t>>2,
-        // row-chunk (t&3)*4 and receives column t (4 consecutive k).
-        const int t = lane & 15;
-        const int mcol = r0 + ((lane >> 4) & 1) * 16 + (t & 3) * 4;
-        const int kb = s * 16 + (lane >> 5) * 8 + (t >> 2);
-        const int k0r = kb, k1r = kb + 4;
-        bf16x4_t lo = lds_tr_read(tile + k0r * 256 + ((mcol * 2) ^ ((k0r & 3) << 6)));
-        bf16x4_t hi = lds_tr_read(tile + k1r * 256 + ((mcol * 2) ^ ((k1r & 3) << 6)));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    } else {
-        const int m = r0 + (lane & 31);
-        bf16x8_t f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = s * 16 + (lane >> 5) * 8 + j;
-            f[j] = *reinterpret_cast<const short*>(tile + k * 256 + ((m * 2) ^ ((k & 3) << 6)));
+            for (int i = 0; i < 8; ++i) e[i] = (gc + i < lim) ? src[i] : (bf16_t)0;
+            v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+            v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
         }
-        return f;
     }
+    return v;
 }
 
-template <bool AK, bool BKM, bool TR>
-__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [2 buffers][A tile | B tile]
+template <bool AK, bool BKM, bool TR, bool DMA, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_mfma_kernel(GemmParams p) {   // >= 2 waves / SIMD
+    constexpr int NW = WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
+    constexpr int FM = WTM / 32, FN = WTN / 32;       // 32x32 MFMA fragments per wave
+    using TA = OpTile<AK, BM>;
+    using TB = OpTile<BKM, BN>;
+    constexpr int STAGE = TA::BYTES + TB::BYTES;
+    constexpr int PA = TA::BYTES / 1024 / NW, PB = TB::BYTES / 1024 / NW;     // 1 KiB DMA pieces per wave
+    static_assert(NW * 16384 <= 2 * STAGE, "epilogue needs 16 KiB of LDS per wave");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];            // [2 stages][A tile | B tile]
     int tm, tn, z;
     tile_coords(p, tm, tn, z);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -230,74 +244,234 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmParams p) {
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = (wave / WN) * WTM, wn = (wave % WN) * WTN;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[4], rb[4];
     const int nkt = (kend - kbeg + BK - 1) / BK;
-    if (nkt > 0) {
-        gload_tile<AK>(A, p.lda, m0, p.M, kbeg, kend, ra, tid);
-        gload_tile<BKM>(B, p.ldb, n0, p.N, kbeg, kend, rb, tid);
-        lds_store_tile<AK>(smem, ra, tid);
-        lds_store_tile<BKM>(smem + TILE_BYTES, rb, tid);
+    const int nfull = (kend - kbeg) / BK;          // k-tiles fully in range: staged by LDS-DMA
+    // Direct-to-LDS staging: a wave instruction moves 64 x 16 B into 1 KiB of LDS at wave-uniform base + lane*16, so the
+    // LDS image is lane-linear and the swizzles are applied to the per-lane SOURCE address.  Rows / row-chunks past
+    // the operand extent are clamped (they only feed outputs that are never stored).
+    size_t srca[PA], srcb[PB];                      // element offsets of this lane's pieces (k0 excluded)
+    const int am0 = (p.ablate & 1) ? 0 : m0, bn0 = (p.ablate & 1) ? 0 : n0;
+#pragma unroll
+    for (int t = 0; t < PA; ++t) {
+        int rs, c;
+        TA::decode((wave_u * PA + t) * 1024 + lane * 16, rs, c);
+        srca[t] = AK ? (size_t)min(am0 + rs, p.M - 1) * p.lda + c * 8 : (size_t)rs * p.lda + min(am0 + c * 8, p.lda - 8);
     }
+#pragma unroll
+    for (int t = 0; t < PB; ++t) {
+        int rs, c;
+        TB::decode((wave_u * PB + t) * 1024 + lane * 16, rs, c);
+        srcb[t] = BKM ? (size_t)min(bn0 + rs, p.N - 1) * p.ldb + c * 8 : (size_t)rs * p.ldb + min(bn0 + c * 8, p.ldb - 8);
+    }
+    uint4 ra[PA], rb[PB];                           // register staging (DMA == false, and the ragged last k-tile)
+    auto stage_issue = [&](int kt, uint8_t* buf) {
+        const int k0 = kbeg + kt * BK;
+        if (DMA && kt < nfull) {
+            const bf16_t* ga = A + (AK ? (size_t)k0 : (size_t)k0 * p.lda);
+            const bf16_t* gb = B + (BKM ? (size_t)k0 : (size_t)k0 * p.ldb);
+#pragma unroll
+            for (int t = 0; t < PA; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + srca[t]),
+                                                 (__attribute__((address_space(3))) void*)(buf + (wave_u * PA + t) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int t = 0; t < PB; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + srcb[t]),
+                                                 (__attribute__((address_space(3))) void*)(buf + TA::BYTES + (wave_u * PB + t) * 1024), 16, 0, 0);
+        } else if (kt < nfull) {                      // register staging: same clamped sources, no predication
+            const bf16_t* ga = A + (AK ? (size_t)k0 : (size_t)k0 * p.lda);
+            const bf16_t* gb = B + (BKM ? (size_t)k0 : (size_t)k0 * p.ldb);
+#pragma unroll
+            for (int t = 0; t < PA; ++t) ra[t] = *reinterpret_cast<const uint4*>(ga + srca[t]);
+#pragma unroll
+            for (int t = 0; t < PB; ++t) rb[t] = *reinterpret_cast<const uint4*>(gb + srcb[t]);
+        } else {                                      // ragged last k-tile: predicated loads (zero fill past the extents)
+#pragma unroll
+            for (int t = 0; t < PA; ++t) ra[t] = gload16<AK, BM>(A, p.lda, m0, p.M, k0, kend, (wave * PA + t) * 1024 + lane * 16);
+#pragma unroll
+            for (int t = 0; t < PB; ++t) rb[t] = gload16<BKM, BN>(B, p.ldb, n0, p.N, k0, kend, (wave * PB + t) * 1024 + lane * 16);
+        }
+    };
+    auto stage_commit = [&](int kt, uint8_t* buf) {
+        if (DMA && kt < nfull) return;
+#pragma unroll
+        for (int t = 0; t < PA; ++t) *reinterpret_cast<uint4*>(buf + (wave * PA + t) * 1024 + lane * 16) = ra[t];
+#pragma unroll
+        for (int t = 0; t < PB; ++t) *reinterpret_cast<uint4*>(buf + TA::BYTES + (wave * PB + t) * 1024 + lane * 16) = rb[t];
+    };
+    if (nkt > 0) { stage_issue(0, smem); stage_commit(0, smem); }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        const uint8_t* ta = smem + (kt & 1) * 2 * TILE_BYTES;
-        const uint8_t* tb = ta + TILE_BYTES;
-        const bool more = (kt + 1) < nkt;
-        if (more) {                                   // next tile's global loads fly under the MFMAs
-            gload_tile<AK>(A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, ra, tid);
-            gload_tile<BKM>(B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, rb, tid);
-        }
+        const uint8_t* ta = smem + (kt & 1) * STAGE;
+        const uint8_t* tb = ta + TA::BYTES;
+        const bool more = kt + 1 < nkt && !(p.ablate & 2);
+        uint8_t* nbuf = smem + ((kt + 1) & 1) * STAGE;
+        // the other buffer was last read in iteration kt-1 (barrier passed): refill it while this one is consumed
+        if (more) stage_issue(kt + 1, nbuf);
+        if (!(p.ablate & 8))
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8_t fa[2], fb[2];
-            fa[0] = lds_load_frag<AK, TR>(ta, wm, s, lane);
-            fa[1] = lds_load_frag<AK, TR>(ta, wm + 32, s, lane);
-            fb[0] = lds_load_frag<BKM, TR>(tb, wn, s, lane);
-            fb[1] = lds_load_frag<BKM, TR>(tb, wn + 32, s, lane);
+            bf16x8_t fa[FM], fb[FN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FM; ++i) fa[i] = TA::template frag<TR>(ta, wm + i * 32, s, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < FN; ++j) fb[j] = TB::template frag<TR>(tb, wn + j * 32, s, lane);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(v8bf16_t, fa[i]), __builtin_bit_cast(v8bf16_t, fb[j]), acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            uint8_t* na = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            lds_store_tile<AK>(na, ra, tid);
-            lds_store_tile<BKM>(na + TILE_BYTES, rb, tid);
-        }
-        __syncthreads();
+        if (more) stage_commit(kt + 1, nbuf);
+        __syncthreads();                              // drains this wave's DMA (vmcnt(0)) and publishes the refill
     }
-    // C/D layout of v_mfma_f32_32x32x16: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.ablate & 4) return;
+    // ---- epilogue.  C/D layout of v_mfma_f32_32x32x16: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    if (p.atomic_out) {
+        // split-K / accumulate (weight gradients; epilogue NONE): fp32 atomics straight from the accumulators -- a wave
+        // instruction covers 2 rows x 32 consecutive columns (2 cache lines), which is what the L2 atomic units want.
+        float* Cf = reinterpret_cast<float*>(p.C);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn + j * 32 + (lane & 31);
+            for (int j = 0; j < FN; ++j) {
+                const int nn = n0 + wn + j * 32 + (lane & 31);
+                const float bb = (z == 0 && p.bias != nullptr && nn < p.N) ? p.bias[nn] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M && n < p.N) epilogue_store<bf16_t>(p, m, n, acc[i][j][r], z == 0);
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (mm < p.M && nn < p.N) atomicAdd(Cf + (size_t)mm * p.ldc + nn, acc[i][j][r] * p.alpha + bb);
+                }
             }
-        }
+        return;
+    }
+    // Each wave transposes 64x64 fp32 sub-tiles through its own 16 KiB of the (now idle) staging LDS so that a lane ends
+    // up with 8 consecutive columns of one row: bias / residual / aux are read and C is written with 16-byte
+    // accesses.  16-byte chunks are XOR-swizzled by (row & 15): conflict-free both ways.
+    float* wbuf = reinterpret_cast<float*>(smem + wave * 16384);
+    const int c8 = lane & 7, rr = lane >> 3;
+    const bool add_bias = (z == 0) && p.bias != nullptr;
+    auto quad = [&](auto HI, auto HJ) {
+            constexpr int hi = decltype(HI)::value, hj = decltype(HJ)::value;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = j * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        wbuf[row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3))] = acc[hi * 2 + i][hj * 2 + j][r];
+                    }
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int n = n0 + wn + hj * 64 + c8 * 8;
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = (add_bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int row = ps * 8 + rr;
+                const int m = m0 + wm + hi * 64 + row;
+                const float4 lo = *reinterpret_cast<const float4*>(wbuf + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
+                const float4 hi4 = *reinterpret_cast<const float4*>(wbuf + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                if (m >= p.M || n >= p.N) continue;
+                if (p.vec_epi && n + 8 <= p.N) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bv[e];
+                    const size_t mn = (size_t)m;
+                    if (p.epilogue == XL_EPI_GELU) {
+                        stvec(reinterpret_cast<bf16_t*>(p.aux) + mn * p.ldx + n, v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                    } else if (p.epilogue == XL_EPI_RESIDUAL) {
+                        float rv[8];
+                        ldvec(reinterpret_cast<const bf16_t*>(p.residual) + mn * p.ldr + n, rv);
+                        if (p.p_drop > 0.0f) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                v[e] *= dropout_scale(p.seed, (uint64_t)m * (uint64_t)p.N + n + e, p.p_drop, p.inv_keep);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    } else if (p.epilogue == XL_EPI_DGELU) {
+                        float av[8];
+                        ldvec(reinterpret_cast<const bf16_t*>(p.aux) + mn * p.ldx + n, av);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast(av[e]);
+                    } else if (p.epilogue == XL_EPI_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+                    }
+                    if (p.out_f32) {
+                        float* c = reinterpret_cast<float*>(p.C) + mn * p.ldc + n;
+                        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        stvec(reinterpret_cast<bf16_t*>(p.C) + mn * p.ldc + n, v);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) epilogue_store<bf16_t>(p, m, n + e, v[e], z == 0);
+                }
+            }
+    };
+    // 64x64 quads of the wave tile, compile-time indices (the accumulators must stay in registers)
+    quad(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    if constexpr (FN / 2 > 1) quad(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    if constexpr (FM / 2 > 1) {
+        quad(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        if constexpr (FN / 2 > 1) quad(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    }
+    static_assert(FM / 2 <= 2 && FN / 2 <= 2, "epilogue handles up to 2x2 quads per wave");
+}
+
+template <bool AK, bool BKM, bool TR, bool DMA, int BM, int BN, int WM, int WN>
+static hipError_t launch_one(const GemmParams& p, int nblk, hipStream_t st) {
+    constexpr int lds = 2 * (BM + BN) * BK * 2;
+    hipError_t e = hipSuccess;
+    auto k = gemm_bf16_mfma_kernel<AK, BKM, TR, DMA, BM, BN, WM, WN>;
+    static bool attr = false;
+    if (lds > 65536 && !attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(WM * WN * 64), lds, st, p);
+    return e;
+}
+
+int g_gemm_dma = -1;     // staging mode: 1 LDS-DMA (global_load_lds), 0 registers; -1 = read XL_GEMM_DMA (default 0)
+
+template <bool AK, bool BKM, int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const GemmParams& p, int nblk, hipStream_t st) {
+    if (g_use_tr_read) {
+        if (g_gemm_dma) return launch_one<AK, BKM, true, true, BM, BN, WM, WN>(p, nblk, st);
+        return launch_one<AK, BKM, true, false, BM, BN, WM, WN>(p, nblk, st);
+    }
+    if (g_gemm_dma) return launch_one<AK, BKM, false, true, BM, BN, WM, WN>(p, nblk, st);
+    return launch_one<AK, BKM, false, false, BM, BN, WM, WN>(p, nblk, st);
 }
 
 template <bool AK, bool BKM>
-static void launch_mfma(const GemmParams& p, int nblk, hipStream_t st) {
-    if (g_use_tr_read)
-        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AK, BKM, true>), dim3(nblk), dim3(256), 4 * TILE_BYTES, st, p);
-    else
-        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AK, BKM, false>), dim3(nblk), dim3(256), 4 * TILE_BYTES, st, p);
+static hipError_t launch_mfma(const GemmParams& p, int tile, int nblk, hipStream_t st) {
+    if (tile == 256) return launch_cfg<AK, BKM, 256, 256, 2, 4>(p, nblk, st);
+    return launch_cfg<AK, BKM, 128, 128, 2, 2>(p, nblk, st);
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
 }
 
 }  // namespace xl
@@ -324,21 +498,36 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     if (accumulate) XL_CHECK_ARG(out_dtype == XL_F32 && epilogue == XL_EPI_NONE, XL_ERR_BAD_ARG,
                                  "xl_gemm: accumulate needs fp32 output and no epilogue");
 
+    static const int force_tile = env_int("XL_GEMM_TILE", 0);          // tuning / debug overrides
+    static const int ablate = env_int("XL_GEMM_ABLATE", 0);
+    if (g_gemm_dma < 0) g_gemm_dma = env_int("XL_GEMM_DMA", 0);
+    static const int big_min_blocks = env_int("XL_GEMM_BIG_MIN_BLOCKS", 1 << 30);   // 256x256 config: opt-in until its DMA/MFMA overlap is fixed
+
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux = aux;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldx = ldx;
     p.epilogue = epilogue; p.out_f32 = (out_dtype == XL_F32); p.alpha = alpha;
-    p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed;
+    p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.ablate = ablate;
 
     const bool mfma_ok = in_dtype == XL_BF16 && (lda % 8 == 0) && (ldb % 8 == 0) && aligned16(A) && aligned16(B);
-    const int tile = mfma_ok ? 128 : 64;
+    const bool may_split = mfma_ok && out_dtype == XL_F32 && epilogue == XL_EPI_NONE;
+    // tile choice: 256x256 halves the L2->LDS traffic per flop but needs enough tiles to fill 256 CUs (1 block/CU)
+    int tile = mfma_ok ? 128 : 64;
+    if (mfma_ok) {
+        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        long reach = t256;
+        if (may_split) reach = t256 * (K / 512 > 0 ? K / 512 : 1);        // split-K can multiply the block count
+        if (reach >= big_min_blocks) tile = 256;
+        if (force_tile == 128 || force_tile == 256) tile = force_tile;
+    }
     p.tiles_m = (M + tile - 1) / tile;
     p.tiles_n = (N + tile - 1) / tile;
     const int tiles = p.tiles_m * p.tiles_n;
     // split-K only for the weight-gradient shape (fp32 out, plain epilogue): few output tiles, deep K
     int splitk = 1;
-    if (mfma_ok && out_dtype == XL_F32 && epilogue == XL_EPI_NONE && tiles < 512 && K >= 1024) {
-        splitk = (768 + tiles - 1) / tiles;
+    const int want = tile == 256 ? 512 : 768;
+    if (may_split && tiles < want && K >= 1024) {
+        splitk = (want + tiles - 1) / tiles;
         const int max_split = K / 512;
         if (splitk > max_split) splitk = max_split;
         if (splitk < 1) splitk = 1;
@@ -354,11 +543,17 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: memset failed: %s", hipGetErrorString(e));
     }
     const int nblk = tiles * splitk;
+    // 16-byte epilogue accesses need 8-element (bf16) / 4-element (fp32) aligned rows of C / residual / aux
+    p.vec_epi = aligned16(C) && (out_dtype == XL_F32 ? ldc % 4 == 0 : ldc % 8 == 0);
+    if (epilogue == XL_EPI_RESIDUAL) p.vec_epi = p.vec_epi && aligned16(residual) && ldr % 8 == 0;
+    if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU) p.vec_epi = p.vec_epi && aligned16(aux) && ldx % 8 == 0;
     if (mfma_ok) {
-        if (a_kmajor && b_kmajor) launch_mfma<true, true>(p, nblk, st);
-        else if (a_kmajor && !b_kmajor) launch_mfma<true, false>(p, nblk, st);
-        else if (!a_kmajor && b_kmajor) launch_mfma<false, true>(p, nblk, st);
-        else launch_mfma<false, false>(p, nblk, st);
+        hipError_t e;
+        if (a_kmajor && b_kmajor) e = launch_mfma<true, true>(p, tile, nblk, st);
+        else if (a_kmajor && !b_kmajor) e = launch_mfma<true, false>(p, tile, nblk, st);
+        else if (!a_kmajor && b_kmajor) e = launch_mfma<false, true>(p, tile, nblk, st);
+        else e = launch_mfma<false, false>(p, tile, nblk, st);
+        XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     } else if (in_dtype == XL_BF16) {
         hipLaunchKernelGGL((gemm_generic_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, p, a_kmajor, b_kmajor);
     } else {

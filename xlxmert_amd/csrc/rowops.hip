@@ -67,9 +67,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-// per-lane column partials -> block reduce over the 4 waves -> atomics
+// per-lane column partials -> block reduce over the 4 waves -> either plain stores into this block's workspace
+// slot (two-stage reduction, finished by reduce_partials_kernel) or atomics straight into `out` (no workspace).
 template <int NIT, int VEC>
-__device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out, int N, float* red /*[WPB][64*VEC]*/) {
+__device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out, int N, float* red /*[WPB][64*VEC]*/,
+                                              float* ws_slot = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -85,10 +87,33 @@ __device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out
                     float s = 0.f;
 #pragma unroll
                     for (int w = 0; w < WPB; ++w) s += red[(w * 64 + lane) * VEC + i];
-                    atomicAdd(out + col + i, s);
+                    if (ws_slot != nullptr) ws_slot[col + i] = s;
+                    else atomicAdd(out + col + i, s);
                 }
         }
     }
+}
+
+struct ReduceOuts { float* p[16]; int stride[16]; };
+// out[v][n*stride] += sum_g ws[(g*nvec + v)*N + n].  grid = (column blocks, G-slices): each block sums one slice of the
+// partial slabs and adds it with one atomic per column (<= 16 atomics per output element).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int G, int nvec, int N, ReduceOuts outs) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nvec * N) return;
+    const int v = idx / N, n = idx - v * N;
+    if (outs.p[v] == nullptr) return;
+    const int per = (G + gridDim.y - 1) / gridDim.y;
+    const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = g0;
+    for (; g + 4 <= g1; g += 4) {
+        s0 += ws[((size_t)(g + 0) * nvec + v) * N + n];
+        s1 += ws[((size_t)(g + 1) * nvec + v) * N + n];
+        s2 += ws[((size_t)(g + 2) * nvec + v) * N + n];
+        s3 += ws[((size_t)(g + 3) * nvec + v) * N + n];
+    }
+    for (; g < g1; ++g) s0 += ws[((size_t)g * nvec + v) * N + n];
+    if (g1 > g0) atomicAdd(outs.p[v] + (size_t)n * outs.stride[v], (s0 + s1) + (s2 + s3));
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -96,7 +121,7 @@ template <typename T, int NIT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, T* __restrict__ dx,
-                                                     float* dgamma, float* dbeta, float* dbias_prev, int M, int N) {
+                                                     float* dgamma, float* dbeta, float* dbias_prev, int M, int N, float* ws) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[WPB * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -143,9 +168,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
     }
-    flush_colsums<NIT, VEC>(ag, dgamma, N, red);
-    flush_colsums<NIT, VEC>(ab, dbeta, N, red);
-    if (dbias_prev != nullptr) flush_colsums<NIT, VEC>(ax, dbias_prev, N, red);
+    float* slot = ws ? ws + (size_t)blockIdx.x * 3 * N : nullptr;
+    flush_colsums<NIT, VEC>(ag, dgamma, N, red, slot);
+    flush_colsums<NIT, VEC>(ab, dbeta, N, red, slot ? slot + N : nullptr);
+    if (dbias_prev != nullptr) flush_colsums<NIT, VEC>(ax, dbias_prev, N, red, slot ? slot + 2 * N : nullptr);
 }
 
 // ------------------------------------------------------------------ visual feature encoder tail (HF:468-476)
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(256) void visn_ln_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ rstd_v, const float* __restrict__ mean_b,
                                                           const float* __restrict__ rstd_b, T* __restrict__ dxv,
                                                           float* dgv, float* dbv, float* dgb, float* dbb, float* dwbox,
-                                                          float* dbbox, float* dbias_visn, int M, int N, int P) {
+                                                          float* dbbox, float* dbias_visn, int M, int N, int P, float* ws) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[WPB * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -259,22 +285,36 @@ __global__ __launch_bounds__(256) void visn_ln_bwd_kernel(const T* __restrict__ 
             }
         }
     }
+    if (ws == nullptr) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int col = (it * 64 + lane) * VEC;
-        if (col < N)
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i)
+                for (int i = 0; i < VEC; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < P) atomicAdd(dwbox + (size_t)(col + i) * P + q, aw[it][i][q]);
+                    for (int q = 0; q < 4; ++q)
+                        if (q < P) atomicAdd(dwbox + (size_t)(col + i) * P + q, aw[it][i][q]);
+        }
     }
-    flush_colsums<NIT, VEC>(agv, dgv, N, red);
-    flush_colsums<NIT, VEC>(abv, dbv, N, red);
-    flush_colsums<NIT, VEC>(agb, dgb, N, red);
-    flush_colsums<NIT, VEC>(abv, dbb, N, red);      // d(beta_box) = sum dh (same as d(beta_v))
-    flush_colsums<NIT, VEC>(abx, dbbox, N, red);
-    if (dbias_visn != nullptr) flush_colsums<NIT, VEC>(axv, dbias_visn, N, red);
+    float* slot = ws ? ws + (size_t)blockIdx.x * 10 * N : nullptr;
+    if (ws != nullptr) {                                  // d(box_fc.weight)[:, q] as vectors 6..9 of the slab
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t[NIT][VEC];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) t[it][i] = aw[it][i][q];
+            flush_colsums<NIT, VEC>(t, nullptr, N, red, slot + (6 + q) * N);
+        }
+    }
+    flush_colsums<NIT, VEC>(agv, dgv, N, red, slot);
+    flush_colsums<NIT, VEC>(abv, dbv, N, red, slot ? slot + N : nullptr);
+    flush_colsums<NIT, VEC>(agb, dgb, N, red, slot ? slot + 2 * N : nullptr);
+    flush_colsums<NIT, VEC>(abv, dbb, N, red, slot ? slot + 3 * N : nullptr);      // d(beta_box) = sum dh (same as d(beta_v))
+    flush_colsums<NIT, VEC>(abx, dbbox, N, red, slot ? slot + 4 * N : nullptr);
+    if (dbias_visn != nullptr) flush_colsums<NIT, VEC>(axv, dbias_visn, N, red, slot ? slot + 5 * N : nullptr);
 }
 
 // ------------------------------------------------------------------ embeddings
@@ -371,7 +411,7 @@ __global__ __launch_bounds__(256) void codebook_gather_kernel(const int64_t* __r
 // out[n] += sum_{m (masked)} x[m,n]; grid (col blocks, row chunks)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask,
-                                                     float* out, int M, int N, int ldx, int rows_per_block) {
+                                                     float* out, int M, int N, int ldx, int rows_per_block, float* ws) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[WPB * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -395,7 +435,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, co
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < WPB; ++w) s += red[(w * 64 + lane) * VEC + i];
-            atomicAdd(out + col + i, s);
+            if (ws != nullptr) ws[(size_t)blockIdx.y * N + col + i] = s;
+            else atomicAdd(out + col + i, s);
         }
 }
 
@@ -566,17 +607,31 @@ extern "C" int xl_layernorm_fwd(const void* x, const float* gamma, const float* 
     return XL_OK;
 }
 
+static void launch_reduce(const float* ws, int G, int nvec, int N, ReduceOuts outs, hipStream_t st) {
+    for (int v = 0; v < 16; ++v) if (outs.stride[v] == 0) outs.stride[v] = 1;
+    const int gy = G >= 256 ? 16 : (G >= 64 ? 8 : (G >= 16 ? 4 : 1));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nvec * N + 255) / 256, gy), dim3(256), 0, st, ws, G, nvec, N, outs);
+}
+
+extern "C" int64_t xl_workspace_floats(int N) { return (int64_t)4096 * (N > 0 ? N : 1); }
+
 extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev,
-                                int M, int N, int dtype, void* stream) {
+                                int M, int N, float* workspace, int dtype, void* stream) {
     CHECK_ROW(N, dtype);
     XL_CHECK_ARG(M > 0 && dy && x && gamma && mean && rstd && dx && dgamma && dbeta, XL_ERR_BAD_ARG, "xl_layernorm_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    const int grid = min((M + WPB - 1) / WPB, 1024);
+    const int grid = min((M + WPB - 1) / WPB, workspace ? 512 : 1024);
     DISPATCH_T(dtype, DISPATCH_NIT(T, N,
         hipLaunchKernelGGL((ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
-                           (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N);));
+                           (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace);));
     XL_CHECK_LAUNCH();
+    if (workspace) {
+        ReduceOuts o = {};
+        o.p[0] = dgamma; o.p[1] = dbeta; o.p[2] = dbias_prev;
+        launch_reduce(workspace, grid, 3, N, o, st);
+        XL_CHECK_LAUNCH();
+    }
     return XL_OK;
 }
 
@@ -599,7 +654,7 @@ extern "C" int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, 
                               const float* mean_v, const float* rstd_v, const float* mean_b, const float* rstd_b,
                               void* dxv, float* dgv, float* dbv, float* dgb, float* dbb,
                               float* dwbox, float* dbbox, float* dbias_visn,
-                              int M, int N, int P, int dtype, void* stream) {
+                              int M, int N, int P, float* workspace, int dtype, void* stream) {
     CHECK_ROW(N, dtype);
     XL_CHECK_ARG(P >= 1 && P <= 8, XL_ERR_BAD_SHAPE, "xl_visn_ln_bwd: pos dim %d not in 1..8", P);
     hipStream_t st = (hipStream_t)stream;
@@ -607,8 +662,15 @@ extern "C" int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, 
     DISPATCH_T(dtype, DISPATCH_NIT(T, N,
         hipLaunchKernelGGL((visn_ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
                            (const T*)dy, (const T*)xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b,
-                           (T*)dxv, dgv, dbv, dgb, dbb, dwbox, dbbox, dbias_visn, M, N, P);));
+                           (T*)dxv, dgv, dbv, dgb, dbb, dwbox, dbbox, dbias_visn, M, N, P, workspace);));
     XL_CHECK_LAUNCH();
+    if (workspace) {
+        ReduceOuts o = {};
+        o.p[0] = dgv; o.p[1] = dbv; o.p[2] = dgb; o.p[3] = dbb; o.p[4] = dbbox; o.p[5] = dbias_visn;
+        for (int q = 0; q < 4 && q < P; ++q) { o.p[6 + q] = dwbox + q; o.stride[6 + q] = P; }
+        launch_reduce(workspace, grid, 10, N, o, st);
+        XL_CHECK_LAUNCH();
+    }
     return XL_OK;
 }
 
@@ -650,23 +712,32 @@ extern "C" int xl_codebook_gather(const int64_t* cluster_ids, const uint8_t* vis
     return XL_OK;
 }
 
-static int colsum_impl(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, int dtype, void* stream) {
+static int colsum_impl(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, float* workspace, int dtype,
+                       void* stream) {
     XL_CHECK_ARG(N % vec_of(dtype) == 0 && ldx % vec_of(dtype) == 0, XL_ERR_BAD_SHAPE,
                  "xl_colsum: N=%d / ldx=%d must be multiples of %d", N, ldx, vec_of(dtype));
     hipStream_t st = (hipStream_t)stream;
     const int per = 64 * vec_of(dtype);
-    const int rows_per_block = 128;
+    int rows_per_block = 128;
+    if (workspace) while ((M + rows_per_block - 1) / rows_per_block > 128) rows_per_block *= 2;   // <= 128 partial slabs
     dim3 grid((N + per - 1) / per, (M + rows_per_block - 1) / rows_per_block);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, mask, out, M, N, ldx, rows_per_block););
+        hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, mask, out, M, N, ldx, rows_per_block, workspace););
     XL_CHECK_LAUNCH();
+    if (workspace) {
+        ReduceOuts o = {};
+        o.p[0] = out;
+        launch_reduce(workspace, grid.y, 1, N, o, st);
+        XL_CHECK_LAUNCH();
+    }
     return XL_OK;
 }
-extern "C" int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, int dtype, void* stream) {
-    return colsum_impl(x, mask, out, M, N, ldx, dtype, stream);
+extern "C" int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int N, int ldx, float* workspace,
+                                int dtype, void* stream) {
+    return colsum_impl(x, mask, out, M, N, ldx, workspace, dtype, stream);
 }
-extern "C" int xl_colsum(const void* x, float* out, int M, int N, int ldx, int dtype, void* stream) {
-    return colsum_impl(x, nullptr, out, M, N, ldx, dtype, stream);
+extern "C" int xl_colsum(const void* x, float* out, int M, int N, int ldx, float* workspace, int dtype, void* stream) {
+    return colsum_impl(x, nullptr, out, M, N, ldx, workspace, dtype, stream);
 }
 
 extern "C" int xl_mask_counts(const int64_t* labels, const uint8_t* vis_mask, float* counts, float* nmask,

@@ -68,7 +68,7 @@ class SelfAttBlock:
         e, p, d, M = self.e, self.p, self.e.d, self.M
         ops = e.ops
         dz = e.tmp("dz", M, d)
-        ops.layernorm_bwd(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo if e.p_hid == 0 else None, M, d)
+        ops.layernorm_bwd(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo if e.p_hid == 0 else None, M, d, ws=e.ws)
         dzm = e.drop_bwd(dz, "dzm", M, d, self.site + 1, p.gbo)
         ops.gemm(dzm, self.ctx, p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
         dctx = e.tmp("dctx", M, d)
@@ -78,7 +78,7 @@ class SelfAttBlock:
         ops.sdpa_bwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                      e.scale, e.p_attn, e.seed(self.site))
-        ops.colsum(dqkv, p.gbqkv, M, 3 * d, 3 * d)
+        ops.colsum(dqkv, p.gbqkv, M, 3 * d, 3 * d, ws=e.ws)
         ops.gemm(dqkv, self.x, p.gwqkv, None, None, None, 3 * d, d, M, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
         ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
@@ -117,13 +117,13 @@ class FFNBlock:
         ops = e.ops
         dz = e.tmp("dz", M, d)
         ops.layernorm_bwd(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb,
-                          self.gb2 if e.p_hid == 0 else None, M, d)
+                          self.gb2 if e.p_hid == 0 else None, M, d, ws=e.ws)
         dzm = e.drop_bwd(dz, "dzm", M, d, self.site, self.gb2)
         ops.gemm(dzm, self.h, self.gw2, None, None, None, d, dff, M, d, dff, dff, a_kmajor=0, b_kmajor=0, out_f32=True)
         dpre = e.tmp("dpre", M, dff)
         ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_DGELU)
-        ops.colsum(dpre, self.gb1, M, dff, dff)
+        ops.colsum(dpre, self.gb1, M, dff, dff, ws=e.ws)
         ops.gemm(dpre, self.x, self.gw1, None, None, None, dff, d, M, dff, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
@@ -173,7 +173,7 @@ class CrossAttBlock:
         dz_full = e.tmp("dz", MX, d)
         dz = dz_full[r0:]
         ops.layernorm_bwd(dY[r0:], self.z[r0:], p.g, self.mean[r0:], self.rstd[r0:], dz, p.gg, p.gb,
-                          p.gbo if e.p_hid == 0 else None, M, d)
+                          p.gbo if e.p_hid == 0 else None, M, d, ws=e.ws)
         dzm = e.drop_bwd(dz, "dzm", M, d, self.site + 2, p.gbo)
         ops.gemm(dzm, self.ctx[r0:], p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
         dctx_full = e.tmp("dctx", MX, d)
@@ -190,13 +190,13 @@ class CrossAttBlock:
             ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, dctx_full[:ML], self.lse_l, dqkv_l, dqkv_v[:, d:],
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
                          e.p_attn, e.seed(self.site))
-            ops.colsum(dqkv, p.gbqkv, MX, 3 * d, 3 * d)
+            ops.colsum(dqkv, p.gbqkv, MX, 3 * d, 3 * d, ws=e.ws)
             ops.gemm(dqkv, X, p.gwqkv, None, None, None, 3 * d, d, MX, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
             ops.gemm(dqkv, p.wqkv, dX, None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
         else:
-            ops.colsum(dqkv_v, p.gbqkv, MV, d, 3 * d)
-            ops.colsum(dqkv_l[:, d:], p.gbqkv[d:], ML, 2 * d, 3 * d)
+            ops.colsum(dqkv_v, p.gbqkv, MV, d, 3 * d, ws=e.ws)
+            ops.colsum(dqkv_l[:, d:], p.gbqkv[d:], ML, 2 * d, 3 * d, ws=e.ws)
             ops.gemm(dqkv_v, X[ML:], p.gwqkv, None, None, None, d, d, MV, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
             ops.gemm(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], None, None, None, 2 * d, d, ML, 3 * d, d, d, a_kmajor=0,
                      b_kmajor=0, out_f32=True)
@@ -293,6 +293,7 @@ class Engine:
         self.mf_tmp_c = self.act(1, d)
         # ---- activation-gradient ping-pong
         self.GA, self.GB = self.act(self.MX, d), self.act(self.MX, d)
+        self.ws = self.f32(ops.workspace_floats(max(3 * d, self.dff, self.F, self.Kp)))   # two-stage column reductions
 
     # ------------------------------------------------------------ memory helpers
     def act(self, *shape):
@@ -447,22 +448,22 @@ class Engine:
         """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis."""
         ops, d, MV, F, K = self.ops, self.d, self.MV, self.F, self.K
         hd = self.hd
-        ops.colsum(self.dlogits, hd["bc"][1], MV, self.Kp, self.Kp)      # pad columns are zero; the bias unit is padded
+        ops.colsum(self.dlogits, hd["bc"][1], MV, self.Kp, self.Kp, ws=self.ws)      # pad columns are zero; the bias unit is padded
         dfeat = self.tmp("dfeat", MV, F)
         if self.with_feat_loss:
             ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, self.dfeat, None, MV, F, K, self.Kp, F, F, ldr=F,
                      a_kmajor=1, b_kmajor=0, epilogue=EPI_RESIDUAL)
         else:
             ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, None, None, MV, F, K, self.Kp, F, F, a_kmajor=1, b_kmajor=0)
-        ops.colsum(dfeat, hd["bf"][1], MV, F, F)
+        ops.colsum(dfeat, hd["bf"][1], MV, F, F, ws=self.ws)
         ops.gemm(dfeat, self.t_y, hd["wf"][1], None, None, None, F, d, MV, F, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
         dty = self.tmp("dz", MV, d)
         ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, MV, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
         dth = self.tmp("dctx", MV, d)
-        ops.layernorm_bwd(dty, self.t_h, hd["gt"][0], self.t_mean, self.t_rstd, dth, hd["gt"][1], hd["bbt"][1], None, MV, d)
+        ops.layernorm_bwd(dty, self.t_h, hd["gt"][0], self.t_mean, self.t_rstd, dth, hd["gt"][1], hd["bbt"][1], None, MV, d, ws=self.ws)
         dtp = self.tmp("dzm", MV, d)
         ops.gelu_bwd(dth, self.t_pre, dtp, MV * d)
-        ops.colsum(dtp, hd["bt"][1], MV, d, d)
+        ops.colsum(dtp, hd["bt"][1], MV, d, d, ws=self.ws)
         ops.gemm(dtp, self.vis_final, hd["wt"][1], None, None, None, d, d, MV, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
         ops.gemm(dtp, hd["wt"][0], d_vis, None, None, None, MV, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
 
@@ -501,13 +502,13 @@ class Engine:
                         dxv, st.gview(v + ".visn_layer_norm.weight"), st.gview(v + ".visn_layer_norm.bias"),
                         st.gview(v + ".box_layer_norm.weight"), st.gview(v + ".box_layer_norm.bias"),
                         st.gview(v + ".box_fc.weight"), st.gview(v + ".box_fc.bias"), st.gview(v + ".visn_fc.bias"),
-                        MV, d, self.P)
+                        MV, d, self.P, ws=self.ws)
         ops.gemm(dxv, self.feats, st.gview(v + ".visn_fc.weight"), None, None, None, d, self.F, MV, d, self.F, self.F,
                  a_kmajor=0, b_kmajor=0, out_f32=True)
         if self.use_codebook and self.has_vmask:
             # d(mask_feat) = (sum over masked rows of d(xv)) W_visn   (ref lxrt/modeling.py:190-193: mask_feat is a Parameter)
             self.mf_tmp.zero_()
-            ops.masked_colsum(dxv, self.vmask, self.mf_tmp, MV, d, d)
+            ops.masked_colsum(dxv, self.vmask, self.mf_tmp, MV, d, d, ws=self.ws)
             ops.cast_from_f32(self.mf_tmp, self.mf_tmp_c, d)
             ops.gemm(self.mf_tmp_c, st.cview(v + ".visn_fc.weight"), st.gview("mask_feat"), None, None, None, 1, self.F, d,
                      d, self.F, self.F, a_kmajor=1, b_kmajor=0, out_f32=True, accumulate=1)
@@ -515,7 +516,7 @@ class Engine:
         e = "bert.embeddings"
         dpre = self.tmp("dz", ML, d)
         ops.layernorm_bwd(GA[:ML], self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
-                          st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d)
+                          st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d, ws=self.ws)
         ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
                       st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
                       self.B, self.L, d)

@@ -60,9 +60,13 @@ class HipOps:
         self.lib.call("xl_layernorm_fwd", self._p(x), self._p(gamma), self._p(beta), self._p(y), self._p(mean),
                       self._p(rstd), M, N, float(eps), self.dt, self._stream())
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N):
+    def workspace_floats(self, N):
+        return int(self.lib.raw("xl_workspace_floats")(int(N)))
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, ws=None):
         self.lib.call("xl_layernorm_bwd", self._p(dy), self._p(x), self._p(gamma), self._p(mean), self._p(rstd),
-                      self._p(dx), self._p(dgamma), self._p(dbeta), self._p(dbias_prev), M, N, self.dt, self._stream())
+                      self._p(dx), self._p(dgamma), self._p(dbeta), self._p(dbias_prev), M, N, self._p(ws), self.dt,
+                      self._stream())
 
     def visn_ln_fwd(self, xv, pos, wbox, bbox, gv, bv, gb, bb, y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps):
         self.lib.call("xl_visn_ln_fwd", self._p(xv), self._p(pos), self._p(wbox), self._p(bbox), self._p(gv),
@@ -70,11 +74,11 @@ class HipOps:
                       self._p(mean_b), self._p(rstd_b), M, N, P, float(eps), self.dt, self._stream())
 
     def visn_ln_bwd(self, dy, xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b, dxv, dgv, dbv, dgb, dbb,
-                    dwbox, dbbox, dbias_visn, M, N, P):
+                    dwbox, dbbox, dbias_visn, M, N, P, ws=None):
         self.lib.call("xl_visn_ln_bwd", self._p(dy), self._p(xv), self._p(pos), self._p(wbox), self._p(bbox),
                       self._p(gv), self._p(gb), self._p(mean_v), self._p(rstd_v), self._p(mean_b), self._p(rstd_b),
                       self._p(dxv), self._p(dgv), self._p(dbv), self._p(dgb), self._p(dbb), self._p(dwbox),
-                      self._p(dbbox), self._p(dbias_visn), M, N, P, self.dt, self._stream())
+                      self._p(dbbox), self._p(dbias_visn), M, N, P, self._p(ws), self.dt, self._stream())
 
     # -- embeddings / codebook
     def embed_ln_fwd(self, ids, tt, word, pos, type_, gamma, beta, y, pre, mean, rstd, B, L, N, eps):
@@ -90,11 +94,12 @@ class HipOps:
         self.lib.call("xl_codebook_gather", self._p(cluster_ids), self._p(vis_mask), self._p(centroids),
                       self._p(mask_feat), self._p(feats), M, F, self.dt, self._stream())
 
-    def masked_colsum(self, x, mask, out, M, N, ldx):
-        self.lib.call("xl_masked_colsum", self._p(x), self._p(mask), self._p(out), M, N, ldx, self.dt, self._stream())
+    def masked_colsum(self, x, mask, out, M, N, ldx, ws=None):
+        self.lib.call("xl_masked_colsum", self._p(x), self._p(mask), self._p(out), M, N, ldx, self._p(ws), self.dt,
+                      self._stream())
 
-    def colsum(self, x, out, M, N, ldx):
-        self.lib.call("xl_colsum", self._p(x), self._p(out), M, N, ldx, self.dt, self._stream())
+    def colsum(self, x, out, M, N, ldx, ws=None):
+        self.lib.call("xl_colsum", self._p(x), self._p(out), M, N, ldx, self._p(ws), self.dt, self._stream())
 
     def gelu_bwd(self, dy, pre, dx, n):
         self.lib.call("xl_gelu_bwd", self._p(dy), self._p(pre), self._p(dx), n, self.dt, self._stream())
