@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (reference --batchSize, param.py:70)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--no-dropout", action="store_true", help="eval-parity mode (the reference trains with p=0.1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,7 +132,7 @@ def main():
     cfg = XLxmertConfig()
     B = args.batch
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595,
-                      total_steps=max(1000, args.steps + args.warmup))
+                      total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout)
     g = torch.Generator().manual_seed(9595)
     tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
     batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=9595 + 17 * rank + i).items()}
@@ -169,7 +170,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]+[2]: full X-LXMERT encoder 9L/5R/5X d=768 + obj_predict_head over 10k codebook, "
                                    "masked-visual-token step fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world,
-                       "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}", "dropout": "off (eval-parity mode)",
+                       "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}",
+                       "dropout": "off (eval-parity mode)" if args.no_dropout else "0.1 hidden + 0.1 attention (training mode, 94 sites)",
                        "loss": round(loss_val, 4)},
             "step_mfma_frac": round(value / world * GFLOP_PER_EXAMPLE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_mfma_kernel (all dense contractions of one step)",

@@ -115,6 +115,11 @@ int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int 
 /* out[n] += sum_m x[m,n]   (bias gradients) */
 int xl_colsum(const void* x, float* out, int M, int N, int ldx, float* workspace, int dtype, void* stream);
 
+/* y[i] = x[i] * (keep(seed, i) ? 1/(1-p) : 0), i in [0, M*N) with i = m*N + n (rows of ldx / ldy elements): the
+ * counter-based mask used by every dropout site of the path (HF:213,258,278,340,475); calling it again with the same
+ * (seed, p) on a gradient applies the identical mask (backward).  In-place (y == x) allowed. */
+int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy, float p_drop, uint64_t seed, int dtype, void* stream);
+
 /* dx = dy * gelu_erf'(pre), n elements (head transform backward, HF:582-586) */
 int xl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
 

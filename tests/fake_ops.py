@@ -22,6 +22,21 @@ def gelu_grad(x):
     return cdf + x * pdf
 
 
+def keep_scale(seed, idx, p_drop):
+    """Host restatement of csrc/common.h dropout_scale(): splitmix64 finaliser of seed + idx*golden; keep iff the
+    32-bit draw >= p*2^32.  idx: int64 tensor.  Returns a float32 tensor of 0 or 1/(1-p)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx.numpy().astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        r = (z >> np.uint64(16)) & np.uint64(0xFFFFFFFF)
+    thr = np.uint64(int(np.float32(p_drop) * np.float32(4294967296.0)))
+    keep = (r >= thr).astype(np.float32) * np.float32(1.0 / (1.0 - p_drop))
+    return torch.from_numpy(keep)
+
+
 class FakeOps:
     def __init__(self, dtype):
         self.dtype = dtype
@@ -33,7 +48,6 @@ class FakeOps:
     def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
              out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0):
         self.calls.append(("gemm", M, N, K, a_kmajor, b_kmajor, epilogue))
-        assert p_drop == 0.0
         a = (v2(A, M, K, lda) if a_kmajor else v2(A, K, M, lda).t()).float()
         b = (v2(B, N, K, ldb) if b_kmajor else v2(B, K, N, ldb).t()).float()
         acc = alpha * (a @ b.t())
@@ -43,6 +57,9 @@ class FakeOps:
             v2(aux, M, N, ldx).copy_(acc)
             acc = torch.nn.functional.gelu(acc)
         elif epilogue == EPI_RESIDUAL:
+            if p_drop > 0:
+                idx = torch.arange(M)[:, None] * N + torch.arange(N)[None, :]
+                acc = acc * keep_scale(seed, idx, p_drop)
             acc = acc + v2(residual, M, N, ldr).float()
         elif epilogue == EPI_DGELU:
             acc = acc * gelu_grad(v2(aux, M, N, ldx).float())
@@ -139,6 +156,10 @@ class FakeOps:
     def colsum(self, x, out, M, N, ldx, ws=None):
         torch.as_strided(out, (N,), (1,)).add_(v2(x, M, N, ldx).float().sum(0))
 
+    def dropout(self, x, y, M, N, ldx, ldy, p_drop, seed):
+        idx = torch.arange(M)[:, None] * N + torch.arange(N)[None, :]
+        v2(y, M, N, ldy).copy_(v2(x, M, N, ldx).float() * keep_scale(seed, idx, p_drop))
+
     def gelu_bwd(self, dy, pre, dx, n):
         dx.view(-1)[:n].copy_(dy.reshape(-1)[:n].float() * gelu_grad(pre.reshape(-1)[:n].float()))
 
@@ -146,14 +167,20 @@ class FakeOps:
     def _heads(t, B, n, H, dh, ld):
         return torch.as_strided(t, (B, H, n, dh), (n * ld, dh, ld, 1))
 
+    @staticmethod
+    def _pmask(B, H, nq, nk, p_drop, seed):
+        if p_drop == 0:
+            return 1.0
+        idx = torch.arange(B * H * nq * nk).view(B, H, nq, nk)          # ((b*H+h)*nq+q)*nk+key
+        return keep_scale(seed, idx, p_drop)
+
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
-        assert p_drop == 0.0
         Q, K_, V_ = (self._heads(t, B, n, H, dh, ld).float() for t, n, ld in ((q, nq, ldq), (k, nk, ldk), (v, nk, ldv)))
         s = Q @ K_.transpose(-1, -2) * scale
         if key_mask is not None:
             s = s.masked_fill(key_mask.view(B, 1, 1, nk) == 0, float("-inf"))
         lse.view(B, H, nq).copy_(torch.logsumexp(s, -1))
-        self._heads(o, B, nq, H, dh, ldo).copy_(torch.softmax(s, -1) @ V_)
+        self._heads(o, B, nq, H, dh, ldo).copy_((torch.softmax(s, -1) * self._pmask(B, H, nq, nk, p_drop, seed)) @ V_)
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
                  lddv, scale, p_drop=0.0, seed=0):
@@ -163,9 +190,11 @@ class FakeOps:
         p = torch.exp(s - lse.view(B, H, nq, 1))
         if key_mask is not None:
             p = p.masked_fill(key_mask.view(B, 1, 1, nk) == 0, 0.0)
-        dp = dO @ V_.transpose(-1, -2)
+        msk = self._pmask(B, H, nq, nk, p_drop, seed)
+        dp = (dO @ V_.transpose(-1, -2)) * msk
         delta = (p * dp).sum(-1, keepdim=True)
         ds = p * (dp - delta) * scale
+        p = p * msk
         self._heads(dq, B, nq, H, dh, lddq).copy_(ds @ K_)
         self._heads(dk, B, nk, H, dh, lddk).copy_(ds.transpose(-1, -2) @ Q)
         self._heads(dv, B, nk, H, dh, lddv).copy_(p.transpose(-1, -2) @ dO)

@@ -77,3 +77,53 @@ def test_need_lang_engine_gives_same_vis_grads():
     eng.encoder_backward(have_lang_grad=True)
     for k in [str(n) for n in g["grad_names"]]:
         assert maxdiff(eng.store.gview(k), g["grad:" + k]) < 3e-5, k
+
+
+def test_dropout_backward_matches_directional_derivative():
+    """Training mode (hidden + attention-probability dropout, counter-based masks): the hand-derived backward agrees
+    with a central finite difference of the loss along a random parameter direction (masks are a pure function of
+    (seed, index), so the loss is smooth in the parameters)."""
+    g = load_golden("tiny_222")
+
+    def run(master=None, grads=True):
+        oc = golden_cfg(g)
+        cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                          "intermediate_size", "max_position_embeddings",
+                                                          "type_vocab_size", "l_layers", "x_layers", "r_layers",
+                                                          "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+        inp = golden_inputs(g)
+        B, L = inp["input_ids"].shape
+        store = ParamStore(cfg, "cpu", torch.float32)
+        store.load_named(O.make_state_dict(oc, int(g["seed"])))
+        if master is not None:
+            store.master.copy_(master)
+        eng = Engine(cfg, store, FakeOps(torch.float32), B, L, inp["cluster_ids"].shape[1], need_lang=False,
+                     train_dropout=True)
+        assert eng.p_hid == 0.1 and eng.p_attn == 0.1
+        eng.set_step_seed(7)
+        eng.set_inputs(inp["input_ids"], inp["attention_mask"], inp["token_type_ids"], inp["visual_pos"],
+                       cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], obj_labels=inp["obj_labels"])
+        if grads:
+            losses = eng.vis_mask_forward_backward()
+        else:
+            eng.encoder_forward(want_pooled=False)
+            eng.head_forward()
+            losses = eng.losses_forward_backward(want_grad=False)
+        return losses[0].double().item() + losses[1].double().item(), store
+
+    loss0, st0 = run()
+    assert abs(loss0 - (g["obj_loss"].item() + g["feat_loss"].item())) > 1e-3      # dropout really changed the forward
+    torch.manual_seed(0)
+    gflat = st0.grad[:st0.n_used].double()
+    u = torch.randn(st0.n_used, dtype=torch.float64)
+    u[gflat == 0] = 0                               # frozen rows / padding carry no gradient
+    u = u / u.norm()
+    eps = 2e-2
+    mp, mm = st0.master.clone(), st0.master.clone()
+    mp[:st0.n_used] += (eps * u).float()
+    mm[:st0.n_used] -= (eps * u).float()
+    lp, _ = run(mp, grads=False)
+    lm, _ = run(mm, grads=False)
+    fd = (lp - lm) / (2 * eps)
+    an = (gflat * u).sum().item()
+    assert abs(fd - an) <= 5e-3 * max(1.0, abs(an)), (fd, an)

@@ -192,3 +192,43 @@ def test_full_size_step_properties_bf16():
     assert torch.isfinite(tr.store.grad[:tr.store.n_used]).all()
     assert torch.isfinite(tr.store.master).all()
     assert 0.0 < tr.grad_norm() < 1e5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_training_mode_dropout_step_matches_host_restatement(dtype, tol):
+    """Dropout on (p=0.1 hidden and attention): the counter-based masks are reproducible on the host, so the whole
+    training-mode step (loss + every gradient) is compared with the same engine driven by tests/fake_ops.FakeOps."""
+    from fake_ops import FakeOps
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import Engine
+    from xlxmert_amd.ops import HipOps
+    from xlxmert_amd.params import ParamStore
+    g = load_golden("tiny_222")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in CFG_KEYS})
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    inp = golden_inputs(g)
+    B, L = inp["input_ids"].shape
+    V = inp["cluster_ids"].shape[1]
+    res = {}
+    for dev, ops in (("cpu", FakeOps(torch.float32)), ("cuda", HipOps(dtype))):
+        store = ParamStore(cfg, dev, torch.float32 if dev == "cpu" else dtype)
+        store.load_named(sd)
+        eng = Engine(cfg, store, ops, B, L, V, need_lang=False, train_dropout=True)
+        eng.sync_compute_weights()
+        eng.set_step_seed(11)
+        x = {k: v.to(dev) for k, v in inp.items()}
+        eng.set_inputs(x["input_ids"], x["attention_mask"], x["token_type_ids"], x["visual_pos"],
+                       cluster_ids=x["cluster_ids"], vis_mask=x["vis_mask"], obj_labels=x["obj_labels"])
+        losses = eng.vis_mask_forward_backward()
+        res[dev] = (losses.cpu().clone(), store.grad[:store.n_used].cpu().clone(), store)
+    assert abs(res["cpu"][0][0] - res["cuda"][0][0]).item() < (1e-4 if dtype == torch.float32 else 3e-2)
+    st = res["cpu"][2]
+    for name in st.names():
+        m = st.index[name]
+        if m.offset >= st.n_used:
+            continue
+        a = res["cpu"][1][m.offset:m.offset + st.view(name).numel()].double()
+        b = res["cuda"][1][m.offset:m.offset + st.view(name).numel()].double()
+        rel = (a - b).norm().item() / max(a.norm().item(), 1e-4)
+        assert rel < tol, (name, rel)

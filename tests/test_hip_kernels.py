@@ -345,3 +345,48 @@ def test_error_reporting():
         ops.layernorm_fwd(x, x, x, x, x, x, 4, 6, 1e-12)          # row length not a multiple of 4
     with pytest.raises(XlError, match="CPU tensor"):
         ops.colsum(torch.zeros(4, 8), x, 4, 8, 8)
+
+
+# ---------------------------------------------------------------- dropout (counter-based masks, training mode)
+@pytest.mark.parametrize("dtype", DT)
+def test_dropout_mask_matches_host_restatement(dtype):
+    g = torch.Generator().manual_seed(23)
+    M, N = 257, 768
+    x = rnd(g, M, N + 8, dtype=dtype)
+    y = torch.zeros(M, N, dtype=dtype)
+    cpu, gpu = run_both(dtype, "dropout", [x, y, M, N, N + 8, N, 0.1, 123456789])
+    assert torch.equal(gpu[1] == 0, cpu[1] == 0)                 # identical keep mask
+    close(gpu[1], cpu[1], dtype, "dropout values", bf16_tol=4e-3)
+    keep = (gpu[1] != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01, keep
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_residual_dropout(dtype):
+    g = torch.Generator().manual_seed(29)
+    M, N, K = 256, 128, 64
+    A, B = rnd(g, M, K, dtype=dtype, s=0.3), rnd(g, N, K, dtype=dtype, s=0.3)
+    C, res, bias = torch.zeros(M, N, dtype=dtype), rnd(g, M, N, dtype=dtype), rnd(g, N)
+    cpu, gpu = run_both(dtype, "gemm", [A, B, C, bias, res, None, M, N, K, K, K, N],
+                        dict(ldr=N, epilogue=2, p_drop=0.1, seed=987654321))
+    close(gpu[2], cpu[2], dtype, "gemm residual+dropout")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nq,nk,dh", [(20, 64, 64), (64, 64, 64), (64, 20, 64), (8, 16, 16)])
+def test_sdpa_dropout_fwd_bwd(nq, nk, dh, dtype):
+    g = torch.Generator().manual_seed(31 + nq)
+    B, H = 2, 3
+    d = H * dh
+    q, k, v = (rnd(g, B * n, d, dtype=dtype) for n in (nq, nk, nk))
+    o, lse = torch.zeros(B * nq, d, dtype=dtype), torch.zeros(B * H * nq)
+    scale, pd, seed = 1.0 / math.sqrt(dh), 0.1, 424242
+    cpu, gpu = run_both(dtype, "sdpa_fwd", [q, k, v, None, o, lse, B, H, nq, nk, dh, d, d, d, d, scale],
+                        dict(p_drop=pd, seed=seed))
+    close(gpu[4], cpu[4], dtype, "sdpa dropout o")
+    dout = rnd(g, B * nq, d, dtype=dtype)
+    dq, dk, dv = torch.zeros(B * nq, d, dtype=dtype), torch.zeros(B * nk, d, dtype=dtype), torch.zeros(B * nk, d, dtype=dtype)
+    cpu2, gpu2 = run_both(dtype, "sdpa_bwd", [q, k, v, None, dout, cpu[5], dq, dk, dv, B, H, nq, nk, dh, d, d, d, d, d, d, d,
+                                              scale], dict(p_drop=pd, seed=seed))
+    for i, nm in ((6, "dq"), (7, "dk"), (8, "dv")):
+        close(gpu2[i], cpu2[i], dtype, "sdpa dropout " + nm, bf16_tol=2.5e-2)

@@ -453,6 +453,22 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy,
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int M, int N, int ldx, int ldy,
+                                                      float p_drop, float inv_keep, uint64_t seed) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cpr = N / VEC;                                   // chunks per row
+    const int64_t total = (int64_t)M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / cpr), c = (int)(i - (int64_t)m * cpr) * VEC;
+        float v[VEC];
+        ldvec(x + (size_t)m * ldx + c, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] *= dropout_scale(seed, (uint64_t)m * (uint64_t)N + c + j, p_drop, inv_keep);
+        stvec(y + (size_t)m * ldy + c, v);
+    }
+}
+
 // ------------------------------------------------------------------ head losses
 __global__ __launch_bounds__(256) void mask_counts_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ vis_mask,
                                                           float* counts, float* nmask, int B, int V) {
@@ -782,6 +798,21 @@ extern "C" int xl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n,
     if (grid > 4096) grid = 4096;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3((int)grid), dim3(256), 0, st, (const T*)dy, (const T*)pre, (T*)dx, nvec););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy, float p_drop, uint64_t seed, int dtype,
+                          void* stream) {
+    CHECK_ROW(N, dtype);
+    XL_CHECK_ARG(x && y && M > 0 && ldx % vec_of(dtype) == 0 && ldy % vec_of(dtype) == 0 && p_drop >= 0.f && p_drop < 1.f,
+                 XL_ERR_BAD_ARG, "xl_dropout: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t grid = ((int64_t)M * (N / vec_of(dtype)) + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((dropout_kernel<T>), dim3((int)grid), dim3(256), 0, st, (const T*)x, (T*)y, M, N, ldx, ldy, p_drop,
+                           1.0f / (1.0f - p_drop), seed););
     XL_CHECK_LAUNCH();
     return XL_OK;
 }

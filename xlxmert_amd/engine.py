@@ -225,7 +225,7 @@ class Engine:
         self.need_lang = need_lang
         self.p_hid = cfg.hidden_dropout_prob if train_dropout else 0.0
         self.p_attn = cfg.attention_probs_dropout_prob if train_dropout else 0.0
-        self._n_sites = 0
+        self._n_sites = 2               # sites 0 / 1: embedding and visual-feature-encoder output dropout
         self._seed = 0
         self._tmp = {}
         self.act_bytes = 0
@@ -326,7 +326,10 @@ class Engine:
         """gradient through a hidden dropout site: with p == 0 it is the identity (bias gradient was fused in LN bwd)."""
         if self.p_hid == 0:
             return dz
-        raise NotImplementedError("hidden dropout backward: enable once xl_dropout lands")
+        dzm = self.tmp(name, M, N)
+        self.ops.dropout(dz, dzm, M, N, N, N, self.p_hid, self.seed(site))       # same (seed, index) mask as the forward
+        self.ops.colsum(dzm, gbias, M, N, N, ws=self.ws)
+        return dzm
 
     def sync_compute_weights(self):
         """refresh the compute-dtype copy of the master parameters (after load_state_dict / init)."""
@@ -369,6 +372,8 @@ class Engine:
                          st.cview(e + ".token_type_embeddings.weight"), st.view(e + ".LayerNorm.weight"),
                          st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
                          self.B, self.L, d, self.eps)
+        if self.p_hid > 0:              # HF:213
+            ops.dropout(self.emb_y, self.emb_y, ML, d, d, d, self.p_hid, self.seed(0))
         if self.use_codebook:
             ops.codebook_gather(self.cid, self.vmask if self.has_vmask else None, st.centroids_c, st.view("mask_feat"),
                                 self.feats, MV, self.F)
@@ -379,6 +384,8 @@ class Engine:
                         st.view(v + ".visn_layer_norm.weight"), st.view(v + ".visn_layer_norm.bias"),
                         st.view(v + ".box_layer_norm.weight"), st.view(v + ".box_layer_norm.bias"),
                         self.vis0, *self.vn_stats, MV, d, self.P, self.eps)
+        if self.p_hid > 0:              # HF:475
+            ops.dropout(self.vis0, self.vis0, MV, d, d, d, self.p_hid, self.seed(1))
         X0 = self.X[0]
         x = self.emb_y
         for i, (sa, ffn) in enumerate(self.lang_layers):
@@ -497,6 +504,9 @@ class Engine:
         # visual feature encoder (HF:468-476) + codebook input
         v = "bert.encoder.visn_fc"
         dxv = self.tmp("dctx", MV, d)
+        if self.p_hid > 0:
+            ops.dropout(GA[ML:], GA[ML:], MV, d, d, d, self.p_hid, self.seed(1))
+            ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
         ops.visn_ln_bwd(GA[ML:], self.xv, self.pos, st.view(v + ".box_fc.weight"), st.view(v + ".box_fc.bias"),
                         st.view(v + ".visn_layer_norm.weight"), st.view(v + ".box_layer_norm.weight"), *self.vn_stats,
                         dxv, st.gview(v + ".visn_layer_norm.weight"), st.gview(v + ".visn_layer_norm.bias"),

@@ -101,6 +101,10 @@ class HipOps:
     def colsum(self, x, out, M, N, ldx, ws=None):
         self.lib.call("xl_colsum", self._p(x), self._p(out), M, N, ldx, self._p(ws), self.dt, self._stream())
 
+    def dropout(self, x, y, M, N, ldx, ldy, p_drop, seed):
+        self.lib.call("xl_dropout", self._p(x), self._p(y), M, N, ldx, ldy, float(p_drop), int(seed), self.dt,
+                      self._stream())
+
     def gelu_bwd(self, dy, pre, dx, n):
         self.lib.call("xl_gelu_bwd", self._p(dy), self._p(pre), self._p(dx), n, self.dt, self._stream())
 
