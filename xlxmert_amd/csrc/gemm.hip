@@ -501,7 +501,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     static const int force_tile = env_int("XL_GEMM_TILE", 0);          // tuning / debug overrides
     static const int ablate = env_int("XL_GEMM_ABLATE", 0);
     if (g_gemm_dma < 0) g_gemm_dma = env_int("XL_GEMM_DMA", 0);
-    static const int big_min_blocks = env_int("XL_GEMM_BIG_MIN_BLOCKS", 1 << 30);   // 256x256 config: opt-in until its DMA/MFMA overlap is fixed
+    static const int big_min_blocks = env_int("XL_GEMM_BIG_MIN_BLOCKS", 512);
 
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux = aux;
@@ -515,9 +515,9 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     int tile = mfma_ok ? 128 : 64;
     if (mfma_ok) {
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-        long reach = t256;
-        if (may_split) reach = t256 * (K / 512 > 0 ? K / 512 : 1);        // split-K can multiply the block count
-        if (reach >= big_min_blocks) tile = 256;
+        // measured (tools/gemm_bench.py): 256x256 wins only when >= 2 full rounds of tiles AND a deep K amortise its
+        // longer prologue/epilogue (the two 10k-codebook contractions); 128x128 wins everywhere else
+        if (t256 >= big_min_blocks && K >= 2048 && !may_split) tile = 256;
         if (force_tile == 128 || force_tile == 256) tile = force_tile;
     }
     p.tiles_m = (M + tile - 1) / tile;
