@@ -23,17 +23,22 @@ def gelu_grad(x):
 
 
 def keep_scale(seed, idx, p_drop):
-    """Host restatement of csrc/common.h dropout_scale(): splitmix64 finaliser of seed + idx*golden; keep iff the
-    32-bit draw >= p*2^32.  idx: int64 tensor.  Returns a float32 tensor of 0 or 1/(1-p)."""
+    """Host restatement of csrc/common.h hash_u32()/dropout_scale(): 32-bit multiply-xorshift mixer of the index folded
+    with both halves of the seed; keep iff the draw >= p*2^32.  idx: int64 tensor.  Returns float32 0 or 1/(1-p)."""
     import numpy as np
+    u32 = np.uint32
+    i64 = idx.numpy().astype(np.uint64)
+    lo, hi = (i64 & np.uint64(0xFFFFFFFF)).astype(u32), (i64 >> np.uint64(32)).astype(u32)
+    s_lo, s_hi = u32(seed & 0xFFFFFFFF), u32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        z = np.uint64(seed) + idx.numpy().astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-        r = (z >> np.uint64(16)) & np.uint64(0xFFFFFFFF)
+        h = lo * u32(0x9E3779B1) ^ hi * u32(0x85EBCA77) ^ s_lo
+        h ^= h >> u32(16); h = h * u32(0x7FEB352D)
+        h ^= h >> u32(15); h = h * u32(0x846CA68B)
+        h ^= h >> u32(16); h ^= s_hi * u32(0xC2B2AE3D)
+        h ^= h >> u32(15); h = h * u32(0x2C1B3C6D)
+        h ^= h >> u32(13)
     thr = np.uint64(int(np.float32(p_drop) * np.float32(4294967296.0)))
-    keep = (r >= thr).astype(np.float32) * np.float32(1.0 / (1.0 - p_drop))
+    keep = (h.astype(np.uint64) >= thr).astype(np.float32) * np.float32(1.0 / (1.0 - p_drop))
     return torch.from_numpy(keep)
 
 

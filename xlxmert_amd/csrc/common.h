@@ -37,15 +37,17 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // ------------------------------------------------------------------ bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// round-to-nearest-even (NaN kept quiet)
+// fp32 -> bf16, round-to-nearest-even, through the gfx950 conversion instruction (v_cvt_pk_bf16_f32): a hand-written
+// bit-trick with a NaN test compiles to a divergent branch PER ELEMENT (it was ~30 % of the attention kernels' code).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_hw_t));
 }
 
 template <typename T> struct Elem;
@@ -129,13 +131,16 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 }
 
 // ------------------------------------------------------------------ counter-based dropout
-// keep-mask for element `idx` under (seed): two rounds of a 64->32 bit mixer (splitmix64 finaliser).
+// keep-mask draw for element `idx` under (seed): a 32-bit multiply-xorshift mixer (two rounds, "lowbias32" constants)
+// over the index folded with both halves of the seed -- ~10 integer instructions per element.
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 16);
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
+    h ^= h >> 16; h *= 0x7FEB352Du;
+    h ^= h >> 15; h *= 0x846CA68Bu;
+    h ^= h >> 16; h ^= (uint32_t)(seed >> 32) * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
 }
 // returns 1/(1-p) if kept, 0 if dropped
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {

@@ -5,11 +5,11 @@
 //   sdpa_*_mfma         bf16 operands on v_mfma_f32_32x32x16_bf16.  The scores are computed TRANSPOSED
 //                       (S^T = K Q^T) so that a lane owns one query column: softmax needs a single
 //                       lane^32 exchange, and the probabilities are already laid out as the B operand of
-//                       O^T = V^T P^T (no cross-lane movement).  Q/K/dO fragments with the contraction
-//                       along dh are read straight from global memory (16 B per lane); operands that are
-//                       contracted along the sequence (V^T, K^T, Q^T, dO^T) are staged once in LDS and
-//                       gathered (ds_read_b64_tr_b16 or 16-bit reads).  The k-slot <-> index mapping of the
-//                       MFMA is applied identically to both operands.
+//                       O^T = V^T P^T (no cross-lane movement).  Q, K, V (and dO) head tiles are staged ONCE per
+//                       problem into LDS with coalesced 16-byte loads; fragments contracted along dh are
+//                       ds_read_b128 rows of those tiles, operands contracted along the sequence
+//                       (V^T, K^T, Q^T, dO^T) are gathered from the same tiles (ds_read_b64_tr_b16 or 16-bit
+//                       reads).  The k-slot <-> index mapping of the MFMA is applied identically to both operands.
 #include "common.h"
 
 namespace xl {
@@ -131,6 +131,8 @@ __device__ __forceinline__ bf16x8_t gfrag(const bf16_t* __restrict__ base, int l
     return f;
 }
 
+// (the transposed-operand gathers and the K-major fragments below both read tiles staged ONCE per problem with coalesced
+//  16-byte loads: per-lane strided global fragment loads touch 64 cache lines per instruction and were ~6x slower)
 template <int DH> struct Tile {
     static constexpr int DHP = DH < 32 ? 32 : DH;       // padded so that every MFMA row d<32 exists (zeros)
     static constexpr int PITCH = DHP * 2 + 16;          // bytes per sequence row
@@ -148,6 +150,12 @@ __device__ __forceinline__ void stage_tile(uint8_t* tile, const bf16_t* __restri
         if (row < n && c * 8 < DH) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c0 + c * 8);
         *reinterpret_cast<uint4*>(tile + row * Tile<DH>::PITCH + c * 16) = v;
     }
+}
+
+// K-major fragment from a staged tile: row `row`, 8 features at d = s*16 + (lane>>5)*8 (rows >= n are zero in the tile)
+template <int DH>
+__device__ __forceinline__ bf16x8_t lfrag(const uint8_t* tile, int row, int s, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * Tile<DH>::PITCH + (s * 16 + (lane >> 5) * 8) * 2);
 }
 
 // A operand "X^T": MFMA row = feature d0+(lane&31); k-slots j=0..7 <-> sequence index
@@ -203,19 +211,24 @@ __device__ __forceinline__ void store_rows(const f32x16_t& a, bf16_t* __restrict
     }
 }
 
-template <int DH, int NQF, int NKF, bool TR>
+template <int DH, int NQF, int NKF, bool TR, bool DROP>
 __global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     bf16_t* __restrict__ o, float* __restrict__ lse, int H, int nq, int nk,
                                                     int ldq, int ldk, int ldv, int ldo, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed) {
     __shared__ __attribute__((aligned(16))) uint8_t vt[Tile<DH>::BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t kt[Tile<DH>::BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t qt[Tile<DH>::BYTES];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
     const bf16_t* qb = q + (size_t)b * nq * ldq;
     const bf16_t* kb = k + (size_t)b * nk * ldk;
     const bf16_t* vb = v + (size_t)b * nk * ldv;
+    stage_tile<DH>(kt, kb, ldk, nk, h * DH, lane);
+    stage_tile<DH>(qt, qb, ldq, nq, h * DH, lane);
     stage_tile<DH>(vt, vb, ldv, nk, h * DH, lane);
+    __syncthreads();
 
     // S^T[key][q]
     f32x16_t st[NKF][NQF];
@@ -227,9 +240,9 @@ __global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q
     for (int s = 0; s < DH / 16; ++s) {
         bf16x8_t fk[NKF], fq[NQF];
 #pragma unroll
-        for (int i = 0; i < NKF; ++i) fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, h * DH + s * 16 + hi * 8);
+        for (int i = 0; i < NKF; ++i) fk[i] = lfrag<DH>(kt, i * 32 + l31, s, lane);
 #pragma unroll
-        for (int j = 0; j < NQF; ++j) fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, h * DH + s * 16 + hi * 8);
+        for (int j = 0; j < NQF; ++j) fq[j] = lfrag<DH>(qt, j * 32 + l31, s, lane);
 #pragma unroll
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pv = st[i][j][r] * inv;
-                if (p_drop > 0.f)
+                if (DROP)
                     pv *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
                 st[i][j][r] = pv;
             }
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q
     }
 }
 
-template <int DH, int NQF, int NKF, bool TR>
+template <int DH, int NQF, int NKF, bool TR, bool DROP>
 __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q
     __shared__ __attribute__((aligned(16))) uint8_t tk[Tile<DH>::BYTES];     // K   [key][d]
     __shared__ __attribute__((aligned(16))) uint8_t tq[Tile<DH>::BYTES];     // Q   [q][d]
     __shared__ __attribute__((aligned(16))) uint8_t tdo[Tile<DH>::BYTES];    // dO  [q][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tv[Tile<DH>::BYTES];     // V   [key][d]
     __shared__ float s_delta[MAXN];
     __shared__ float s_lse[MAXN];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -322,8 +336,10 @@ __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q
     stage_tile<DH>(tk, kb, ldk, nk, h * DH, lane);
     stage_tile<DH>(tq, qb, ldq, nq, h * DH, lane);
     stage_tile<DH>(tdo, dob, ldo, nq, h * DH, lane);
+    stage_tile<DH>(tv, vb, ldv, nk, h * DH, lane);
     s_lse[lane] = lane < nq ? lse[(size_t)bh * nq + lane] : 0.f;
     constexpr int ND = (DH + 31) / 32;
+    __syncthreads();
 
     // ---------------- phase 1: lane owns a query column.  dQ and delta.
     {
@@ -337,9 +353,9 @@ __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q
             const int col = h * DH + s * 16 + hi * 8;
             bf16x8_t fk[NKF], fv[NKF], fq[NQF], fdo[NQF];
 #pragma unroll
-            for (int i = 0; i < NKF; ++i) { fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, col); fv[i] = gfrag(vb, ldv, i * 32 + l31, nk, col); }
+            for (int i = 0; i < NKF; ++i) { fk[i] = lfrag<DH>(tk, i * 32 + l31, s, lane); fv[i] = lfrag<DH>(tv, i * 32 + l31, s, lane); }
 #pragma unroll
-            for (int j = 0; j < NQF; ++j) { fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, col); fdo[j] = gfrag(dob, ldo, j * 32 + l31, nq, col); }
+            for (int j = 0; j < NQF; ++j) { fq[j] = lfrag<DH>(tq, j * 32 + l31, s, lane); fdo[j] = lfrag<DH>(tdo, j * 32 + l31, s, lane); }
 #pragma unroll
             for (int i = 0; i < NKF; ++i)
 #pragma unroll
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q
                 for (int r = 0; r < 16; ++r) {
                     float pv = ((kval >> (i * 16 + r)) & 1u) ? __expf(st[i][j][r] * scale - l) : 0.f;
                     float dp = dpt[i][j][r];
-                    if (p_drop > 0.f)
+                    if (DROP)
                         dp *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
                     st[i][j][r] = pv;
                     dpt[i][j][r] = dp;
@@ -412,9 +428,9 @@ __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q
             const int col = h * DH + s * 16 + hi * 8;
             bf16x8_t fk[NKF], fv[NKF], fq[NQF], fdo[NQF];
 #pragma unroll
-            for (int i = 0; i < NKF; ++i) { fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, col); fv[i] = gfrag(vb, ldv, i * 32 + l31, nk, col); }
+            for (int i = 0; i < NKF; ++i) { fk[i] = lfrag<DH>(tk, i * 32 + l31, s, lane); fv[i] = lfrag<DH>(tv, i * 32 + l31, s, lane); }
 #pragma unroll
-            for (int j = 0; j < NQF; ++j) { fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, col); fdo[j] = gfrag(dob, ldo, j * 32 + l31, nq, col); }
+            for (int j = 0; j < NQF; ++j) { fq[j] = lfrag<DH>(tq, j * 32 + l31, s, lane); fdo[j] = lfrag<DH>(tdo, j * 32 + l31, s, lane); }
 #pragma unroll
             for (int j = 0; j < NQF; ++j)
 #pragma unroll
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q
                     const int qi = j * 32 + acc_row(r, hi);
                     float pv = (kok && qi < nq) ? __expf(s2[j][i][r] * scale - s_lse[qi]) : 0.f;
                     float msk = 1.f;
-                    if (p_drop > 0.f) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
+                    if (DROP) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
                     const float dp = dp2[j][i][r] * msk;
                     dp2[j][i][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
                     s2[j][i][r] = pv * msk;                              // P~[q][key]
@@ -472,31 +488,30 @@ struct SdpaArgs {
     float scale, p_drop, inv_keep; uint64_t seed;
 };
 
+template <int DH, int NQF, int NKF, bool TR, bool DROP>
+static void launch_fwd2(const SdpaArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(64), 0, st, (const bf16_t*)a.q,
+                       (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk,
+                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed);
+}
+template <int DH, int NQF, int NKF, bool TR, bool DROP>
+static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(64), 0, st, (const bf16_t*)a.q,
+                       (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq,
+                       (bf16_t*)a.dk, (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv,
+                       a.scale, a.p_drop, a.inv_keep, a.seed);
+}
 template <int DH, int NQF, int NKF>
 static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
-    dim3 grid(a.B * a.H), block(64);
-    if (g_use_tr_read)
-        hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, true>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
-                           (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo,
-                           a.scale, a.p_drop, a.inv_keep, a.seed);
-    else
-        hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, false>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
-                           (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo,
-                           a.scale, a.p_drop, a.inv_keep, a.seed);
+    const bool drop = a.p_drop > 0.f;
+    if (g_use_tr_read) { if (drop) launch_fwd2<DH, NQF, NKF, true, true>(a, st); else launch_fwd2<DH, NQF, NKF, true, false>(a, st); }
+    else { if (drop) launch_fwd2<DH, NQF, NKF, false, true>(a, st); else launch_fwd2<DH, NQF, NKF, false, false>(a, st); }
 }
 template <int DH, int NQF, int NKF>
 static void launch_bwd(const SdpaArgs& a, hipStream_t st) {
-    dim3 grid(a.B * a.H), block(64);
-    if (g_use_tr_read)
-        hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, true>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
-                           (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq, (bf16_t*)a.dk,
-                           (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv, a.scale,
-                           a.p_drop, a.inv_keep, a.seed);
-    else
-        hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, false>), grid, block, 0, st, (const bf16_t*)a.q, (const bf16_t*)a.k,
-                           (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq, (bf16_t*)a.dk,
-                           (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv, a.scale,
-                           a.p_drop, a.inv_keep, a.seed);
+    const bool drop = a.p_drop > 0.f;
+    if (g_use_tr_read) { if (drop) launch_bwd2<DH, NQF, NKF, true, true>(a, st); else launch_bwd2<DH, NQF, NKF, true, false>(a, st); }
+    else { if (drop) launch_bwd2<DH, NQF, NKF, false, true>(a, st); else launch_bwd2<DH, NQF, NKF, false, false>(a, st); }
 }
 
 template <bool FWD, int DH>
