@@ -5,10 +5,10 @@
 //   sdpa_*_mfma         bf16 operands on v_mfma_f32_32x32x16_bf16.  The scores are computed TRANSPOSED
 //                       (S^T = K Q^T) so that a lane owns one query column: softmax needs a single
 //                       lane^32 exchange, and the probabilities are already laid out as the B operand of
-//                       O^T = V^T P^T (no cross-lane movement).  Q, K, V (and dO) head tiles are staged ONCE per
-//                       problem into LDS with coalesced 16-byte loads; fragments contracted along dh are
-//                       ds_read_b128 rows of those tiles, operands contracted along the sequence
-//                       (V^T, K^T, Q^T, dO^T) are gathered from the same tiles (ds_read_b64_tr_b16 or 16-bit
+//                       O^T = V^T P^T (no cross-lane movement).  Forward: Q/K fragments (contraction along dh)
+//                       come straight from global memory, V is staged in LDS and gathered transposed.  Backward:
+//                       the Q, K, V, dO head tiles are staged once in LDS (coalesced 16-byte loads) and serve both
+//                       the ds_read_b128 row fragments and the transposed gathers (ds_read_b64_tr_b16 or 16-bit
 //                       reads).  The k-slot <-> index mapping of the MFMA is applied identically to both operands.
 #include "common.h"
 
@@ -218,17 +218,12 @@ __global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q
                                                     int ldq, int ldk, int ldv, int ldo, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed) {
     __shared__ __attribute__((aligned(16))) uint8_t vt[Tile<DH>::BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t kt[Tile<DH>::BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t qt[Tile<DH>::BYTES];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
     const bf16_t* qb = q + (size_t)b * nq * ldq;
     const bf16_t* kb = k + (size_t)b * nk * ldk;
     const bf16_t* vb = v + (size_t)b * nk * ldv;
-    stage_tile<DH>(kt, kb, ldk, nk, h * DH, lane);
-    stage_tile<DH>(qt, qb, ldq, nq, h * DH, lane);
     stage_tile<DH>(vt, vb, ldv, nk, h * DH, lane);
-    __syncthreads();
 
     // S^T[key][q]
     f32x16_t st[NKF][NQF];
@@ -240,9 +235,9 @@ __global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q
     for (int s = 0; s < DH / 16; ++s) {
         bf16x8_t fk[NKF], fq[NQF];
 #pragma unroll
-        for (int i = 0; i < NKF; ++i) fk[i] = lfrag<DH>(kt, i * 32 + l31, s, lane);
+        for (int i = 0; i < NKF; ++i) fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, h * DH + s * 16 + hi * 8);
 #pragma unroll
-        for (int j = 0; j < NQF; ++j) fq[j] = lfrag<DH>(qt, j * 32 + l31, s, lane);
+        for (int j = 0; j < NQF; ++j) fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, h * DH + s * 16 + hi * 8);
 #pragma unroll
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
