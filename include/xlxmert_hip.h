@@ -70,11 +70,14 @@ int xl_gemm(const void* A, const void* B, void* C, const float* bias,
  * y = (x-mean)*rstd*gamma+beta over the last dim N; saves mean,rstd (fp32 [M]).  */
 int xl_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                      float* mean, float* rstd, int M, int N, float eps, int dtype, void* stream);
-/* dx from dy; dgamma/dbeta (fp32 [N]) are ACCUMULATED (atomics).  If dbias_prev != NULL it also
- * accumulates colsum(dx) (= bias gradient of the dense layer feeding this LayerNorm). */
+/* dx from dy; dgamma/dbeta (fp32 [N]) are ACCUMULATED.  The LayerNorm input was `dropout(dense(.)) + residual`
+ * (HF:277-279, 339-341): if dx_dropped != NULL and p_drop > 0 the kernel also writes dx_dropped = dx * mask(seed, m*N+n)
+ * (the gradient entering the dense layer; same counter-based mask as the forward epilogue) .  If dbias_prev != NULL it
+ * accumulates the column sums of that tensor (dx_dropped if written, else dx) = the dense layer's bias gradient. */
 int xl_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                      const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev,
-                     int M, int N, float* workspace, int dtype, void* stream);
+                     int M, int N, float* workspace, void* dx_dropped, float p_drop, uint64_t seed,
+                     int dtype, void* stream);
 /* Column reductions (LayerNorm affine / bias gradients, column sums) run as a two-stage reduction through a
  * caller-owned fp32 `workspace` of at least xl_workspace_floats(N) elements (per-block partial slabs + one
  * combine launch); workspace == NULL falls back to fp32 atomics on the output. */

@@ -103,13 +103,18 @@ class FakeOps:
     def workspace_floats(self, N):
         return 4096 * N
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, ws=None):
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, ws=None, dx_dropped=None,
+                      p_drop=0.0, seed=0):
         d, dg, db = self._ln_bwd(v2(dy, M, N, N).float(), v2(x, M, N, N).float(), gamma.float(), mean[:M], rstd[:M])
         v2(dx, M, N, N).copy_(d)
         dgamma.add_(dg)
         dbeta.add_(db)
+        if dx_dropped is not None and p_drop > 0:
+            idx = torch.arange(M)[:, None] * N + torch.arange(N)[None, :]
+            d = d * keep_scale(seed, idx, p_drop)                           # the kernel masks the fp32 value, then rounds
+            v2(dx_dropped, M, N, N).copy_(d)
         if dbias_prev is not None:
-            dbias_prev.add_(v2(dx, M, N, N).float().sum(0) if False else d.sum(0))
+            dbias_prev.add_(d.sum(0))
 
     def visn_ln_fwd(self, xv, pos, wbox, bbox, gv, bv, gb, bb, y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps):
         a, mv, rv = self._ln(v2(xv, M, N, N).float(), gv, bv, eps)

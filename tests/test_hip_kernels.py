@@ -390,3 +390,21 @@ def test_sdpa_dropout_fwd_bwd(nq, nk, dh, dtype):
                                               scale], dict(p_drop=pd, seed=seed))
     for i, nm in ((6, "dq"), (7, "dk"), (8, "dv")):
         close(gpu2[i], cpu2[i], dtype, "sdpa dropout " + nm, bf16_tol=2.5e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm_bwd_fused_dropout(dtype):
+    """LN backward that also emits the dropout-masked gradient of the dense layer and its bias gradient."""
+    g = torch.Generator().manual_seed(41)
+    M, N = 4100, 768
+    x = rnd(g, M, N, dtype=dtype) * 2
+    gamma, beta = rnd(g, N) * 0.2 + 1, rnd(g, N) * 0.1
+    y, mean, rstd = torch.zeros(M, N, dtype=dtype), torch.zeros(M), torch.zeros(M)
+    cpu, _ = run_both(dtype, "layernorm_fwd", [x, gamma, beta, y, mean, rstd, M, N, 1e-12])
+    dy, dx, dxm = rnd(g, M, N, dtype=dtype), torch.zeros(M, N, dtype=dtype), torch.zeros(M, N, dtype=dtype)
+    dg, db, dbp = torch.zeros(N), torch.zeros(N), torch.zeros(N)
+    cpu2, gpu2 = run_both(dtype, "layernorm_bwd", [dy, x, gamma, cpu[4], cpu[5], dx, dg, db, dbp, M, N],
+                          dict(ws=torch.zeros(4096 * N), dx_dropped=dxm, p_drop=0.1, seed=777))
+    close(gpu2[5], cpu2[5], dtype, "dx")
+    # the masked tensor itself is checked through its column sums here and element-wise by the training-mode engine test
+    close(gpu2[8], cpu2[8], torch.float32, "dbias of the masked gradient", f32_tol=3e-5, bf16_tol=2e-2)

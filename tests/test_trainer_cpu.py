@@ -84,9 +84,10 @@ def _dp_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     cfg = XLxmertConfig(**TINY)
     B, L, grid = 2, 8, 4
-    tr, sd = make_step(cfg, B, L, grid, lr=1e-2)
+    tr, sd = make_step(cfg, B, L, grid, lr=1e-2, bucket_mb=0.05)       # several overlapped buckets
     batch = synthetic_batch(cfg, B, L, grid, seed=500 + rank)         # disjoint per-rank minibatch
     tr.step(batch)
+    assert len(tr._works) > 3, len(tr._works)
     torch.save({k: tr.store.view(k).clone() for k in tr.store.names()}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

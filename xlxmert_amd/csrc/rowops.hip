@@ -121,7 +121,8 @@ template <typename T, int NIT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, T* __restrict__ dx,
-                                                     float* dgamma, float* dbeta, float* dbias_prev, int M, int N, float* ws) {
+                                                     float* dgamma, float* dbeta, float* dbias_prev, int M, int N, float* ws,
+                                                     T* __restrict__ dx_drop, float p_drop, float inv_keep, uint64_t seed) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[WPB * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -160,11 +161,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             if (col < N) {
                 float o[VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    o[i] = rstd * (g[it][i] * dv[it][i] - c1 - xv[it][i] * c2);
-                    ax[it][i] += o[i];
-                }
+                for (int i = 0; i < VEC; ++i) o[i] = rstd * (g[it][i] * dv[it][i] - c1 - xv[it][i] * c2);
                 stvec(dx + (size_t)row * N + col, o);
+                if (dx_drop != nullptr) {          // gradient through the dropout of the dense layer feeding this LN
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        o[i] *= dropout_scale(seed, (uint64_t)row * (uint64_t)N + col + i, p_drop, inv_keep);
+                    stvec(dx_drop + (size_t)row * N + col, o);
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) ax[it][i] += o[i];
             }
         }
     }
@@ -633,14 +639,18 @@ extern "C" int64_t xl_workspace_floats(int N) { return (int64_t)4096 * (N > 0 ? 
 
 extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev,
-                                int M, int N, float* workspace, int dtype, void* stream) {
+                                int M, int N, float* workspace, void* dx_dropped, float p_drop, uint64_t seed,
+                                int dtype, void* stream) {
     CHECK_ROW(N, dtype);
     XL_CHECK_ARG(M > 0 && dy && x && gamma && mean && rstd && dx && dgamma && dbeta, XL_ERR_BAD_ARG, "xl_layernorm_bwd: bad args");
+    XL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, XL_ERR_BAD_ARG, "xl_layernorm_bwd: p_drop %f", p_drop);
+    if (p_drop == 0.f) dx_dropped = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int grid = min((M + WPB - 1) / WPB, workspace ? 512 : 1024);
     DISPATCH_T(dtype, DISPATCH_NIT(T, N,
         hipLaunchKernelGGL((ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
-                           (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace);));
+                           (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace,
+                           (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed);));
     XL_CHECK_LAUNCH();
     if (workspace) {
         ReduceOuts o = {};

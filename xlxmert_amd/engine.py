@@ -68,9 +68,8 @@ class SelfAttBlock:
         e, p, d, M = self.e, self.p, self.e.d, self.M
         ops = e.ops
         dz = e.tmp("dz", M, d)
-        ops.layernorm_bwd(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo if e.p_hid == 0 else None, M, d, ws=e.ws)
-        dzm = e.drop_bwd(dz, "dzm", M, d, self.site + 1, p.gbo)
-        ops.gemm(dzm, self.ctx, p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        dzm = e.ln_bwd_dense(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo, M, d, self.site + 1)
+        ops.gemm(dzm, self.ctx, p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dctx = e.tmp("dctx", M, d)
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         dqkv = e.tmp("dqkv", M, 3 * d)
@@ -79,7 +78,7 @@ class SelfAttBlock:
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                      e.scale, e.p_attn, e.seed(self.site))
         ops.colsum(dqkv, p.gbqkv, M, 3 * d, 3 * d, ws=e.ws)
-        ops.gemm(dqkv, self.x, p.gwqkv, None, None, None, 3 * d, d, M, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        ops.gemm(dqkv, self.x, p.gwqkv, None, None, None, 3 * d, d, M, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -116,15 +115,13 @@ class FFNBlock:
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
         ops = e.ops
         dz = e.tmp("dz", M, d)
-        ops.layernorm_bwd(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb,
-                          self.gb2 if e.p_hid == 0 else None, M, d, ws=e.ws)
-        dzm = e.drop_bwd(dz, "dzm", M, d, self.site, self.gb2)
-        ops.gemm(dzm, self.h, self.gw2, None, None, None, d, dff, M, d, dff, dff, a_kmajor=0, b_kmajor=0, out_f32=True)
+        dzm = e.ln_bwd_dense(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb, self.gb2, M, d, self.site)
+        ops.gemm(dzm, self.h, self.gw2, None, None, None, d, dff, M, d, dff, dff, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dpre = e.tmp("dpre", M, dff)
         ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_DGELU)
         ops.colsum(dpre, self.gb1, M, dff, dff, ws=e.ws)
-        ops.gemm(dpre, self.x, self.gw1, None, None, None, dff, d, M, dff, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        ops.gemm(dpre, self.x, self.gw1, None, None, None, dff, d, M, dff, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -172,10 +169,9 @@ class CrossAttBlock:
         r0, M = (0, MX) if self.need_lang else (ML, MV)
         dz_full = e.tmp("dz", MX, d)
         dz = dz_full[r0:]
-        ops.layernorm_bwd(dY[r0:], self.z[r0:], p.g, self.mean[r0:], self.rstd[r0:], dz, p.gg, p.gb,
-                          p.gbo if e.p_hid == 0 else None, M, d, ws=e.ws)
-        dzm = e.drop_bwd(dz, "dzm", M, d, self.site + 2, p.gbo)
-        ops.gemm(dzm, self.ctx[r0:], p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        dzm = e.ln_bwd_dense(dY[r0:], self.z[r0:], p.g, self.mean[r0:], self.rstd[r0:], dz, p.gg, p.gb, p.gbo, M, d,
+                             self.site + 2)
+        ops.gemm(dzm, self.ctx[r0:], p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dctx_full = e.tmp("dctx", MX, d)
         dctx = dctx_full[r0:]
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
@@ -191,15 +187,15 @@ class CrossAttBlock:
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
                          e.p_attn, e.seed(self.site))
             ops.colsum(dqkv, p.gbqkv, MX, 3 * d, 3 * d, ws=e.ws)
-            ops.gemm(dqkv, X, p.gwqkv, None, None, None, 3 * d, d, MX, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+            ops.gemm(dqkv, X, p.gwqkv, None, None, None, 3 * d, d, MX, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
             ops.gemm(dqkv, p.wqkv, dX, None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
         else:
             ops.colsum(dqkv_v, p.gbqkv, MV, d, 3 * d, ws=e.ws)
             ops.colsum(dqkv_l[:, d:], p.gbqkv[d:], ML, 2 * d, 3 * d, ws=e.ws)
-            ops.gemm(dqkv_v, X[ML:], p.gwqkv, None, None, None, d, d, MV, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+            ops.gemm(dqkv_v, X[ML:], p.gwqkv, None, None, None, d, d, MV, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
             ops.gemm(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], None, None, None, 2 * d, d, ML, 3 * d, d, d, a_kmajor=0,
-                     b_kmajor=0, out_f32=True)
+                     b_kmajor=0, out_f32=True, accumulate=1)
             ops.gemm(dqkv_v, p.wqkv, dX[ML:], None, dz, None, MV, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
             ops.gemm(dqkv_l[:, d:], p.wqkv[d:], dX[:ML], None, None, None, ML, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
@@ -225,6 +221,7 @@ class Engine:
         self.need_lang = need_lang
         self.p_hid = cfg.hidden_dropout_prob if train_dropout else 0.0
         self.p_attn = cfg.attention_probs_dropout_prob if train_dropout else 0.0
+        self.grad_ready = None          # optional callback(hi): gradients in flat range [0, hi) are final
         self._n_sites = 2               # sites 0 / 1: embedding and visual-feature-encoder output dropout
         self._seed = 0
         self._tmp = {}
@@ -322,14 +319,20 @@ class Engine:
     def set_step_seed(self, seed):
         self._seed = int(seed)
 
-    def drop_bwd(self, dz, name, M, N, site, gbias):
-        """gradient through a hidden dropout site: with p == 0 it is the identity (bias gradient was fused in LN bwd)."""
+    def ln_bwd_dense(self, dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, site):
+        """LayerNorm backward of a `LN(dropout(dense(.)) + residual)` block: returns the gradient entering the dense layer
+        (dz itself when dropout is off, else the masked copy written by the same kernel); the dense bias gradient is fused."""
         if self.p_hid == 0:
+            self.ops.layernorm_bwd(dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, ws=self.ws)
             return dz
-        dzm = self.tmp(name, M, N)
-        self.ops.dropout(dz, dzm, M, N, N, N, self.p_hid, self.seed(site))       # same (seed, index) mask as the forward
-        self.ops.colsum(dzm, gbias, M, N, N, ws=self.ws)
+        dzm = self.tmp("dzm", M, N)
+        self.ops.layernorm_bwd(dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, ws=self.ws, dx_dropped=dzm,
+                               p_drop=self.p_hid, seed=self.seed(site))
         return dzm
+
+    def _ready(self, prefix):
+        if self.grad_ready is not None:
+            self.grad_ready(self.store.range_of(prefix)[1])
 
     def sync_compute_weights(self):
         """refresh the compute-dtype copy of the master parameters (after load_state_dict / init)."""
@@ -463,7 +466,7 @@ class Engine:
         else:
             ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, None, None, MV, F, K, self.Kp, F, F, a_kmajor=1, b_kmajor=0)
         ops.colsum(dfeat, hd["bf"][1], MV, F, F, ws=self.ws)
-        ops.gemm(dfeat, self.t_y, hd["wf"][1], None, None, None, F, d, MV, F, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        ops.gemm(dfeat, self.t_y, hd["wf"][1], None, None, None, F, d, MV, F, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dty = self.tmp("dz", MV, d)
         ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, MV, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
         dth = self.tmp("dctx", MV, d)
@@ -471,8 +474,9 @@ class Engine:
         dtp = self.tmp("dzm", MV, d)
         ops.gelu_bwd(dth, self.t_pre, dtp, MV * d)
         ops.colsum(dtp, hd["bt"][1], MV, d, d, ws=self.ws)
-        ops.gemm(dtp, self.vis_final, hd["wt"][1], None, None, None, d, d, MV, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        ops.gemm(dtp, self.vis_final, hd["wt"][1], None, None, None, d, d, MV, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         ops.gemm(dtp, hd["wt"][0], d_vis, None, None, None, MV, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        self._ready("obj_predict_head.")
 
     def encoder_backward(self, have_lang_grad=False):
         """d(outputs) are expected in GA ([lang ; vis] rows; the language rows are ignored unless have_lang_grad)."""
@@ -490,17 +494,20 @@ class Engine:
                 blk["ffn_l"].bwd(GA[:ML], GB[:ML])
                 blk["sa_l"].bwd(GB[:ML], GA[:ML])
             blk["cross"].bwd(GA, GB)
+            self._ready(f"bert.encoder.x_layers.{i}.")
             GA, GB = GB, GA
         # relational (visual) stack
         for i in reversed(range(cfg.r_layers)):
             sa, ffn = self.vis_layers[i]
             ffn.bwd(GA[ML:], GB[ML:])
             sa.bwd(GB[ML:], GA[ML:])
+            self._ready(f"bert.encoder.r_layers.{i}.")
         # language stack
         for i in reversed(range(cfg.l_layers)):
             sa, ffn = self.lang_layers[i]
             ffn.bwd(GA[:ML], GB[:ML])
             sa.bwd(GB[:ML], GA[:ML])
+            self._ready(f"bert.encoder.layer.{i}.")
         # visual feature encoder (HF:468-476) + codebook input
         v = "bert.encoder.visn_fc"
         dxv = self.tmp("dctx", MV, d)
@@ -514,7 +521,7 @@ class Engine:
                         st.gview(v + ".box_fc.weight"), st.gview(v + ".box_fc.bias"), st.gview(v + ".visn_fc.bias"),
                         MV, d, self.P, ws=self.ws)
         ops.gemm(dxv, self.feats, st.gview(v + ".visn_fc.weight"), None, None, None, d, self.F, MV, d, self.F, self.F,
-                 a_kmajor=0, b_kmajor=0, out_f32=True)
+                 a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         if self.use_codebook and self.has_vmask:
             # d(mask_feat) = (sum over masked rows of d(xv)) W_visn   (ref lxrt/modeling.py:190-193: mask_feat is a Parameter)
             self.mf_tmp.zero_()
@@ -530,6 +537,8 @@ class Engine:
         ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
                       st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
                       self.B, self.L, d)
+        if self.grad_ready is not None:
+            self.grad_ready(st.n_used)
 
     # ------------------------------------------------------------ whole vis_mask step (forward + backward)
     def vis_mask_forward_backward(self, feat_loss=True):

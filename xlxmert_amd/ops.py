@@ -63,10 +63,11 @@ class HipOps:
     def workspace_floats(self, N):
         return int(self.lib.raw("xl_workspace_floats")(int(N)))
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, ws=None):
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, ws=None, dx_dropped=None,
+                      p_drop=0.0, seed=0):
         self.lib.call("xl_layernorm_bwd", self._p(dy), self._p(x), self._p(gamma), self._p(mean), self._p(rstd),
-                      self._p(dx), self._p(dgamma), self._p(dbeta), self._p(dbias_prev), M, N, self._p(ws), self.dt,
-                      self._stream())
+                      self._p(dx), self._p(dgamma), self._p(dbeta), self._p(dbias_prev), M, N, self._p(ws),
+                      self._p(dx_dropped), float(p_drop), int(seed), self.dt, self._stream())
 
     def visn_ln_fwd(self, xv, pos, wbox, bbox, gv, bv, gb, bb, y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps):
         self.lib.call("xl_visn_ln_fwd", self._p(xv), self._p(pos), self._p(wbox), self._p(bbox), self._p(gv),

@@ -3,9 +3,10 @@
 All trainable tensors of the path live in ONE fp32 master buffer (plus same-shaped gradient, Adam m/v
 buffers and a compute-dtype copy), laid out so that
   * query/key/value weights (and biases) of an attention block are adjacent -> one fused [3d, d] operand;
-  * parameters whose gradient is written exactly once per step by a weight-gradient contraction ("mat")
-    come first, parameters whose gradient is accumulated by atomics ("vec": biases, LayerNorm affine,
-    embedding tables, box_fc, mask_feat) follow, so that only that tail is zeroed per step;
+  * used parameters are ordered by when backward finishes them (head first, embeddings last), so finished gradients
+    form a growing prefix and the gradient exchange overlaps with backward on contiguous buckets; the used range of
+    the gradient buffer is zeroed once per step (weight gradients accumulate through split-K atomics, vectors through
+    two-stage column reductions);
   * parameters that get no gradient on a masked-visual-token step (pooler and the language side of the last
     cross layer -- SURVEY.md section 0.6 V3) sit behind `n_used`: the optimizer and the gradient exchange
     run over [0, n_used) only (the reference's AdamW skips tensors whose .grad is None).
@@ -115,14 +116,35 @@ def build_units(cfg, task="vis_mask"):
     return units
 
 
+def _backward_rank(cfg, name):
+    """position of a tensor's block in the backward pass (stable sort keeps the order inside a block)."""
+    if name.startswith("obj_predict_head."):
+        return 0
+    if ".x_layers." in name:
+        return 1 + (cfg.x_layers - 1 - int(name.split(".x_layers.")[1].split(".")[0]))
+    base = 1 + cfg.x_layers
+    if ".r_layers." in name:
+        return base + (cfg.r_layers - 1 - int(name.split(".r_layers.")[1].split(".")[0]))
+    base += cfg.r_layers
+    if ".encoder.layer." in name:
+        return base + (cfg.l_layers - 1 - int(name.split(".encoder.layer.")[1].split(".")[0]))
+    base += cfg.l_layers
+    if name.startswith("bert.pooler."):
+        return base
+    return base + 1             # visn_fc, embeddings, mask_feat: finished by the very last kernels
+
+
 class ParamStore:
     """Flat fp32 master parameters + gradients + Adam state + compute-dtype copy, on one device."""
 
     def __init__(self, cfg, device, compute_dtype=torch.bfloat16, task="vis_mask"):
         self.cfg, self.device, self.compute_dtype, self.task = cfg, torch.device(device), compute_dtype, task
         units = build_units(cfg, task)
-        order = ([u for u in units if u.used and u.region == "mat"] + [u for u in units if u.used and u.region == "vec"]
-                 + [u for u in units if not u.used])
+        # used tensors in the order backward FINISHES them (head, cross layers N..0, visual layers, language layers,
+        # visual feature encoder, embeddings): completed gradients form a growing prefix of the flat buffer, so the
+        # data-parallel exchange can start on contiguous buckets while backward is still running.
+        order = sorted([u for u in units if u.used], key=lambda u: _backward_rank(cfg, u.members[0].name)) \
+            + [u for u in units if not u.used]
         off = 0
         self.index = {}
         for u in order:
@@ -138,7 +160,7 @@ class ParamStore:
             off += u.padded
         self.units = order
         self.n_total = off
-        self.n_mat = sum(u.padded for u in order if u.used and u.region == "mat")
+        self.n_mat = 0          # the whole used range is zeroed once per step (weight gradients accumulate: split-K)
         self.n_used = sum(u.padded for u in order if u.used)
         dev = self.device
         self.master = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
@@ -176,6 +198,11 @@ class ParamStore:
         n = sum(_numel(m.shape) for m in ms)
         flat = buf[ms[0].offset:ms[0].offset + n]
         return flat.view(-1, ms[0].shape[1]) if len(ms[0].shape) == 2 else flat
+
+    def range_of(self, prefix):
+        """[lo, hi) element range (incl. padding) covered by the units whose first member starts with `prefix`."""
+        us = [u for u in self.units if u.used and u.members[0].name.startswith(prefix)]
+        return min(u.offset for u in us), max(u.offset + u.padded for u in us)
 
     def names(self):
         return list(self.index.keys())

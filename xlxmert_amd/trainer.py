@@ -49,7 +49,7 @@ class PretrainStep:
     def __init__(self, cfg: XLxmertConfig, batch_size, text_len=20, n_grids=64, dtype=torch.bfloat16, device=None,
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=True, train_dropout=False, store=None,
-                 bucket_mb=64, ops=None):
+                 bucket_mb=128, ops=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps."""
         self.cfg = cfg
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -71,7 +71,7 @@ class PretrainStep:
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.lrs = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._lrs_host = torch.zeros(4, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.zeros(4)
-        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // 4)
         if self.world > 1:
             self._check_replicas()
 
@@ -88,11 +88,23 @@ class PretrainStep:
     def set_centroids(self, centroids):
         self.store.set_centroids(centroids)
 
-    def allreduce_grads(self):
-        """DDP semantics: sum over ranks here, the 1/world factor is folded into the optimizer kernel."""
-        g = self.store.grad[:self.store.n_used]
-        for s in range(0, g.numel(), self.bucket_elems):
-            dist.all_reduce(g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM)
+    # ---- gradient exchange (DDP semantics: SUM over ranks here, the 1/world factor is folded into the optimizer kernel).
+    # The flat gradient buffer is laid out in backward-completion order, so the engine reports a growing finished prefix
+    # [0, hi); every time >= bucket_elems new elements are final an asynchronous all-reduce of that contiguous slice is
+    # queued (RCCL runs it on its own stream behind an event), overlapping with the rest of backward.
+    def _begin_exchange(self):
+        self._sent, self._works = 0, []
+
+    def _on_grad_ready(self, hi):
+        final = hi >= self.store.n_used
+        if hi - self._sent >= self.bucket_elems or (final and hi > self._sent):
+            self._works.append(dist.all_reduce(self.store.grad[self._sent:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._sent = hi
+
+    def _finish_exchange(self):
+        assert self._sent == self.store.n_used, (self._sent, self.store.n_used)
+        for w in self._works:
+            w.wait()
 
     def step(self, batch):
         """batch: dict with input_ids, attention_mask (optional), token_type_ids (optional), visual_pos,
@@ -109,9 +121,12 @@ class PretrainStep:
         eng.set_step_seed(self.t * self.world + self.rank)
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                        vis_mask=batch["vis_mask"], obj_labels=labels)
+        if self.world > 1:
+            self._begin_exchange()
+            eng.grad_ready = self._on_grad_ready
         losses = eng.vis_mask_forward_backward(self.feat_loss)
         if self.world > 1:
-            self.allreduce_grads()
+            self._finish_exchange()
         self.optimizer_step()
         return losses
 
