@@ -149,6 +149,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = tr.step(batches[i % 4])
+    t_enqueue = time.perf_counter() - t0          # host time to queue the work (GPU-bound if << wall time)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device="cuda")
@@ -173,6 +174,7 @@ def main():
                        "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}",
                        "dropout": "off (eval-parity mode)" if args.no_dropout else "0.1 hidden + 0.1 attention (training mode, 94 sites)",
                        "loss": round(loss_val, 4)},
+            "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
             "step_mfma_frac": round(value / world * GFLOP_PER_EXAMPLE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_mfma_kernel (all dense contractions of one step)",
                          "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -205,7 +205,7 @@ class Engine:
     """Static-shape forward/backward program.  `need_lang`: whether lang/pooled outputs of the last cross layer are
     consumed (False for the masked-visual-token step)."""
 
-    def __init__(self, cfg, store, ops, B, L, V, need_lang=False, train_dropout=False):
+    def __init__(self, cfg, store, ops, B, L, V, need_lang=False, train_dropout=False, two_streams=True):
         assert cfg.l_layers >= 1 and cfg.r_layers >= 1 and cfg.x_layers >= 1
         assert L <= 64 and V <= 64, "attention kernels hold a whole (batch, head) problem on chip: n <= 64"
         self.cfg, self.store, self.ops = cfg, store, ops
@@ -290,7 +290,13 @@ class Engine:
         self.mf_tmp_c = self.act(1, d)
         # ---- activation-gradient ping-pong
         self.GA, self.GB = self.act(self.MX, d), self.act(self.MX, d)
-        self.ws = self.f32(ops.workspace_floats(max(3 * d, self.dff, self.F, self.Kp)))   # two-stage column reductions
+        # two-stage column reductions: one workspace per stream (language / visual work runs concurrently)
+        self._ws = {"v": self.f32(ops.workspace_floats(max(3 * d, self.dff, self.F, self.Kp))),
+                    "l": self.f32(ops.workspace_floats(max(3 * d, self.dff)))}
+        # The language stream (B*20 rows) fills less than half the chip per kernel; its layers are independent of the
+        # visual stream inside the L/R stacks and between two cross-attention blocks, so they run on a second HIP stream.
+        self._tag = "v"
+        self.side = torch.cuda.Stream(device=self.dev) if (two_streams and self.dev.type == "cuda") else None
 
     # ------------------------------------------------------------ memory helpers
     def act(self, *shape):
@@ -301,9 +307,41 @@ class Engine:
     def f32(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
+    @property
+    def ws(self):
+        return self._ws[self._tag]
+
+    class _LangStream:
+        def __init__(self, eng):
+            self.e = eng
+            self.ctx = torch.cuda.stream(eng.side) if eng.side is not None else None
+
+        def __enter__(self):
+            self.e._tag = "l"
+            if self.ctx is not None:
+                self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+            self.e._tag = "v"
+
+    def lang_stream(self):
+        return Engine._LangStream(self)
+
+    def fork(self):
+        """language stream waits for everything queued so far on the main (visual) stream."""
+        if self.side is not None:
+            self.side.wait_event(torch.cuda.current_stream().record_event())
+
+    def join(self):
+        """main stream waits for everything queued so far on the language stream."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_event(self.side.record_event())
+
     def tmp(self, name, M, N):
-        """backward scratch, shared by all blocks (sized for the largest user)."""
-        key = (name, N)
+        """backward scratch, shared by all blocks of one stream (sized for the largest user)."""
+        key = (name, N, self._tag)
         if key not in self._tmp:
             self._tmp[key] = torch.zeros(self.MX, N, dtype=self.cdtype, device=self.dev)
         return self._tmp[key][:M]
@@ -370,13 +408,23 @@ class Engine:
     def encoder_forward(self, want_pooled=True):
         cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
         ML, MV = self.ML, self.MV
-        e = "bert.embeddings"
-        ops.embed_ln_fwd(self.ids, self.tt, st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
-                         st.cview(e + ".token_type_embeddings.weight"), st.view(e + ".LayerNorm.weight"),
-                         st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
-                         self.B, self.L, d, self.eps)
-        if self.p_hid > 0:              # HF:213
-            ops.dropout(self.emb_y, self.emb_y, ML, d, d, d, self.p_hid, self.seed(0))
+        X0 = self.X[0]
+        self.fork()
+        with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream
+            e = "bert.embeddings"
+            ops.embed_ln_fwd(self.ids, self.tt, st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
+                             st.cview(e + ".token_type_embeddings.weight"), st.view(e + ".LayerNorm.weight"),
+                             st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
+                             self.B, self.L, d, self.eps)
+            if self.p_hid > 0:              # HF:213
+                ops.dropout(self.emb_y, self.emb_y, ML, d, d, d, self.p_hid, self.seed(0))
+            x = self.emb_y
+            for i, (sa, ffn) in enumerate(self.lang_layers):
+                sa.fwd(x, self.lang_mid[i])
+                y = X0[:ML] if i == cfg.l_layers - 1 else self.lang_out[i]
+                ffn.fwd(self.lang_mid[i], y)
+                x = y
+        # ---- visual feature encoder + relational stack (HF:513, 524-529) on the main stream
         if self.use_codebook:
             ops.codebook_gather(self.cid, self.vmask if self.has_vmask else None, st.centroids_c, st.view("mask_feat"),
                                 self.feats, MV, self.F)
@@ -389,27 +437,25 @@ class Engine:
                         self.vis0, *self.vn_stats, MV, d, self.P, self.eps)
         if self.p_hid > 0:              # HF:475
             ops.dropout(self.vis0, self.vis0, MV, d, d, d, self.p_hid, self.seed(1))
-        X0 = self.X[0]
-        x = self.emb_y
-        for i, (sa, ffn) in enumerate(self.lang_layers):
-            sa.fwd(x, self.lang_mid[i])
-            y = X0[:ML] if i == cfg.l_layers - 1 else self.lang_out[i]
-            ffn.fwd(self.lang_mid[i], y)
-            x = y
         x = self.vis0
         for i, (sa, ffn) in enumerate(self.vis_layers):
             sa.fwd(x, self.vis_mid[i])
             y = X0[ML:] if i == cfg.r_layers - 1 else self.vis_out[i]
             ffn.fwd(self.vis_mid[i], y)
             x = y
+        self.join()
         for i, blk in enumerate(self.x_layers):
             Xi, Y, S, Xo = self.X[i], self.XY[i], self.XS[i], self.X[i + 1]
             blk["cross"].fwd(Xi, Y)
+            if blk["lang_on"]:
+                self.fork()
+                with self.lang_stream():
+                    blk["sa_l"].fwd(Y[:ML], S[:ML])
+                    blk["ffn_l"].fwd(S[:ML], Xo[:ML])
             blk["sa_v"].fwd(Y[ML:], S[ML:])
             blk["ffn_v"].fwd(S[ML:], Xo[ML:])
             if blk["lang_on"]:
-                blk["sa_l"].fwd(Y[:ML], S[:ML])
-                blk["ffn_l"].fwd(S[:ML], Xo[:ML])
+                self.join()
         Xl = self.X[-1]
         self.lang_final, self.vis_final = Xl[:ML], Xl[ML:]
         if want_pooled and self.need_lang:
@@ -486,34 +532,46 @@ class Engine:
         for i in reversed(range(cfg.x_layers)):
             blk = self.x_layers[i]
             lang_on = blk["lang_on"] and (have_lang_grad or i < cfg.x_layers - 1)
-            blk["ffn_v"].bwd(GA[ML:], GB[ML:])
-            blk["sa_v"].bwd(GB[ML:], GA[ML:])
             if blk["lang_on"]:
                 if not lang_on:
                     raise RuntimeError("engine built with need_lang=True needs d(language_output)")
-                blk["ffn_l"].bwd(GA[:ML], GB[:ML])
-                blk["sa_l"].bwd(GB[:ML], GA[:ML])
+                self.fork()
+                with self.lang_stream():
+                    blk["ffn_l"].bwd(GA[:ML], GB[:ML])
+                    blk["sa_l"].bwd(GB[:ML], GA[:ML])
+            blk["ffn_v"].bwd(GA[ML:], GB[ML:])
+            blk["sa_v"].bwd(GB[ML:], GA[ML:])
+            if blk["lang_on"]:
+                self.join()
             blk["cross"].bwd(GA, GB)
             self._ready(f"bert.encoder.x_layers.{i}.")
             GA, GB = GB, GA
-        # relational (visual) stack
+        self.fork()
+        with self.lang_stream():            # ---- language stack + embeddings (HF:191-214) on the side stream
+            for i in reversed(range(cfg.l_layers)):
+                sa, ffn = self.lang_layers[i]
+                ffn.bwd(GA[:ML], GB[:ML])
+                sa.bwd(GB[:ML], GA[:ML])
+            e = "bert.embeddings"
+            if self.p_hid > 0:
+                ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
+            dpre = self.tmp("dz", ML, d)
+            ops.layernorm_bwd(GA[:ML], self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
+                              st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d, ws=self.ws)
+            ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
+                          st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
+                          self.B, self.L, d)
+        # ---- relational (visual) stack
         for i in reversed(range(cfg.r_layers)):
             sa, ffn = self.vis_layers[i]
             ffn.bwd(GA[ML:], GB[ML:])
             sa.bwd(GB[ML:], GA[ML:])
             self._ready(f"bert.encoder.r_layers.{i}.")
-        # language stack
-        for i in reversed(range(cfg.l_layers)):
-            sa, ffn = self.lang_layers[i]
-            ffn.bwd(GA[:ML], GB[:ML])
-            sa.bwd(GB[:ML], GA[:ML])
-            self._ready(f"bert.encoder.layer.{i}.")
-        # visual feature encoder (HF:468-476) + codebook input
+        # ---- visual feature encoder (HF:468-476) + codebook input
         v = "bert.encoder.visn_fc"
         dxv = self.tmp("dctx", MV, d)
         if self.p_hid > 0:
             ops.dropout(GA[ML:], GA[ML:], MV, d, d, d, self.p_hid, self.seed(1))
-            ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
         ops.visn_ln_bwd(GA[ML:], self.xv, self.pos, st.view(v + ".box_fc.weight"), st.view(v + ".box_fc.bias"),
                         st.view(v + ".visn_layer_norm.weight"), st.view(v + ".box_layer_norm.weight"), *self.vn_stats,
                         dxv, st.gview(v + ".visn_layer_norm.weight"), st.gview(v + ".visn_layer_norm.bias"),
@@ -529,14 +587,7 @@ class Engine:
             ops.cast_from_f32(self.mf_tmp, self.mf_tmp_c, d)
             ops.gemm(self.mf_tmp_c, st.cview(v + ".visn_fc.weight"), st.gview("mask_feat"), None, None, None, 1, self.F, d,
                      d, self.F, self.F, a_kmajor=1, b_kmajor=0, out_f32=True, accumulate=1)
-        # embeddings (HF:191-214)
-        e = "bert.embeddings"
-        dpre = self.tmp("dz", ML, d)
-        ops.layernorm_bwd(GA[:ML], self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
-                          st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d, ws=self.ws)
-        ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
-                      st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
-                      self.B, self.L, d)
+        self.join()                          # language-stack gradients are final from here on
         if self.grad_ready is not None:
             self.grad_ready(st.n_used)
 
