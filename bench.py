@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-dropout", action="store_true", help="eval-parity mode (the reference trains with p=0.1)")
+    ap.add_argument("--single-stream", action="store_true", help="no language/visual stream overlap (profiling)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,6 +134,8 @@ def main():
     B = args.batch
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595,
                       total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout)
+    if args.single_stream:
+        tr.engine.side = None
     g = torch.Generator().manual_seed(9595)
     tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
     batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=9595 + 17 * rank + i).items()}
@@ -158,8 +161,13 @@ def main():
     dt = tmax.item()
     loss_val = losses[0].item()
 
-    with GemmTimer(tr.ops) as gt:                         # one extra, instrumented step (not in the timed region)
+    # one extra, instrumented step (not in the timed region).  It runs single-stream so that every GEMM launch is
+    # timed alone (in the timed region language-stream kernels overlap visual-stream kernels on a second stream,
+    # which lengthens individual kernels while shortening the step).
+    side, tr.engine.side = tr.engine.side, None
+    with GemmTimer(tr.ops) as gt:
         tr.step(batches[0])
+    tr.engine.side = side
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt

@@ -5,7 +5,7 @@ TAG=${1:-rXX}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --single-stream"   # kernels timed alone (same mode as bench.py's roofline step)
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $CMD > $OUT/bench_kernel_trace.log 2>&1
 python tools/prof_summary.py /tmp/prof_kt/kt_results.db 40 > $OUT/kernel_stats.txt
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES -d /tmp/prof_a -o a -- $CMD > /dev/null 2>&1

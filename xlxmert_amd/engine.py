@@ -67,9 +67,10 @@ class SelfAttBlock:
     def bwd(self, dy, dx):
         e, p, d, M = self.e, self.p, self.e.d, self.M
         ops = e.ops
+        e.wgrad_sync()                  # the previous block's weight-gradient GEMMs still read the shared scratch
         dz = e.tmp("dz", M, d)
         dzm = e.ln_bwd_dense(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo, M, d, self.site + 1)
-        ops.gemm(dzm, self.ctx, p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad(dzm, self.ctx, p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dctx = e.tmp("dctx", M, d)
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         dqkv = e.tmp("dqkv", M, 3 * d)
@@ -78,7 +79,7 @@ class SelfAttBlock:
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                      e.scale, e.p_attn, e.seed(self.site))
         ops.colsum(dqkv, p.gbqkv, M, 3 * d, 3 * d, ws=e.ws)
-        ops.gemm(dqkv, self.x, p.gwqkv, None, None, None, 3 * d, d, M, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad(dqkv, self.x, p.gwqkv, None, None, None, 3 * d, d, M, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -114,14 +115,15 @@ class FFNBlock:
     def bwd(self, dy, dx):
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
         ops = e.ops
+        e.wgrad_sync()
         dz = e.tmp("dz", M, d)
         dzm = e.ln_bwd_dense(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb, self.gb2, M, d, self.site)
-        ops.gemm(dzm, self.h, self.gw2, None, None, None, d, dff, M, d, dff, dff, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad(dzm, self.h, self.gw2, None, None, None, d, dff, M, d, dff, dff, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dpre = e.tmp("dpre", M, dff)
         ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_DGELU)
         ops.colsum(dpre, self.gb1, M, dff, dff, ws=e.ws)
-        ops.gemm(dpre, self.x, self.gw1, None, None, None, dff, d, M, dff, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad(dpre, self.x, self.gw1, None, None, None, dff, d, M, dff, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -166,12 +168,13 @@ class CrossAttBlock:
     def bwd(self, dY, dX):
         e, p, d = self.e, self.p, self.e.d
         ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
+        e.wgrad_sync()
         r0, M = (0, MX) if self.need_lang else (ML, MV)
         dz_full = e.tmp("dz", MX, d)
         dz = dz_full[r0:]
         dzm = e.ln_bwd_dense(dY[r0:], self.z[r0:], p.g, self.mean[r0:], self.rstd[r0:], dz, p.gg, p.gb, p.gbo, M, d,
                              self.site + 2)
-        ops.gemm(dzm, self.ctx[r0:], p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad(dzm, self.ctx[r0:], p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dctx_full = e.tmp("dctx", MX, d)
         dctx = dctx_full[r0:]
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
@@ -187,14 +190,14 @@ class CrossAttBlock:
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
                          e.p_attn, e.seed(self.site))
             ops.colsum(dqkv, p.gbqkv, MX, 3 * d, 3 * d, ws=e.ws)
-            ops.gemm(dqkv, X, p.gwqkv, None, None, None, 3 * d, d, MX, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+            e.wgrad(dqkv, X, p.gwqkv, None, None, None, 3 * d, d, MX, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
             ops.gemm(dqkv, p.wqkv, dX, None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
         else:
             ops.colsum(dqkv_v, p.gbqkv, MV, d, 3 * d, ws=e.ws)
             ops.colsum(dqkv_l[:, d:], p.gbqkv[d:], ML, 2 * d, 3 * d, ws=e.ws)
-            ops.gemm(dqkv_v, X[ML:], p.gwqkv, None, None, None, d, d, MV, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
-            ops.gemm(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], None, None, None, 2 * d, d, ML, 3 * d, d, d, a_kmajor=0,
+            e.wgrad(dqkv_v, X[ML:], p.gwqkv, None, None, None, d, d, MV, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+            e.wgrad(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], None, None, None, 2 * d, d, ML, 3 * d, d, d, a_kmajor=0,
                      b_kmajor=0, out_f32=True, accumulate=1)
             ops.gemm(dqkv_v, p.wqkv, dX[ML:], None, dz, None, MV, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
@@ -297,6 +300,10 @@ class Engine:
         # visual stream inside the L/R stacks and between two cross-attention blocks, so they run on a second HIP stream.
         self._tag = "v"
         self.side = torch.cuda.Stream(device=self.dev) if (two_streams and self.dev.type == "cuda") else None
+        # Weight-gradient GEMMs (dW = dY^T X) are off the dX dependency chain: each stream gets a companion stream for
+        # them, so they co-run with the chain's next kernels (and their epilogue bursts interleave).
+        self._dw = ({"v": torch.cuda.Stream(device=self.dev), "l": torch.cuda.Stream(device=self.dev)}
+                    if (two_streams and self.dev.type == "cuda") else None)
 
     # ------------------------------------------------------------ memory helpers
     def act(self, *shape):
@@ -339,6 +346,20 @@ class Engine:
         if self.side is not None:
             torch.cuda.current_stream().wait_event(self.side.record_event())
 
+    def wgrad(self, *args, **kw):
+        """queue a weight-gradient GEMM on the companion stream of the current stream (after everything queued so far)."""
+        if self._dw is None or self.side is None:
+            return self.ops.gemm(*args, **kw)
+        dw = self._dw[self._tag]
+        dw.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(dw):
+            self.ops.gemm(*args, **kw)
+
+    def wgrad_sync(self):
+        """current stream waits for the weight-gradient GEMMs queued so far by this stream."""
+        if self._dw is not None and self.side is not None:
+            torch.cuda.current_stream().wait_event(self._dw[self._tag].record_event())
+
     def tmp(self, name, M, N):
         """backward scratch, shared by all blocks of one stream (sized for the largest user)."""
         key = (name, N, self._tag)
@@ -369,6 +390,7 @@ class Engine:
         return dzm
 
     def _ready(self, prefix):
+        self.wgrad_sync()
         if self.grad_ready is not None:
             self.grad_ready(self.store.range_of(prefix)[1])
 
@@ -512,7 +534,7 @@ class Engine:
         else:
             ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, None, None, MV, F, K, self.Kp, F, F, a_kmajor=1, b_kmajor=0)
         ops.colsum(dfeat, hd["bf"][1], MV, F, F, ws=self.ws)
-        ops.gemm(dfeat, self.t_y, hd["wf"][1], None, None, None, F, d, MV, F, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        self.wgrad(dfeat, self.t_y, hd["wf"][1], None, None, None, F, d, MV, F, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         dty = self.tmp("dz", MV, d)
         ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, MV, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
         dth = self.tmp("dctx", MV, d)
@@ -520,7 +542,7 @@ class Engine:
         dtp = self.tmp("dzm", MV, d)
         ops.gelu_bwd(dth, self.t_pre, dtp, MV * d)
         ops.colsum(dtp, hd["bt"][1], MV, d, d, ws=self.ws)
-        ops.gemm(dtp, self.vis_final, hd["wt"][1], None, None, None, d, d, MV, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        self.wgrad(dtp, self.vis_final, hd["wt"][1], None, None, None, d, d, MV, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         ops.gemm(dtp, hd["wt"][0], d_vis, None, None, None, MV, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         self._ready("obj_predict_head.")
 
@@ -539,6 +561,7 @@ class Engine:
                 with self.lang_stream():
                     blk["ffn_l"].bwd(GA[:ML], GB[:ML])
                     blk["sa_l"].bwd(GB[:ML], GA[:ML])
+                    self.wgrad_sync()
             blk["ffn_v"].bwd(GA[ML:], GB[ML:])
             blk["sa_v"].bwd(GB[ML:], GA[ML:])
             if blk["lang_on"]:
@@ -561,6 +584,7 @@ class Engine:
             ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
                           st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
                           self.B, self.L, d)
+            self.wgrad_sync()
         # ---- relational (visual) stack
         for i in reversed(range(cfg.r_layers)):
             sa, ffn = self.vis_layers[i]
@@ -587,6 +611,7 @@ class Engine:
             ops.cast_from_f32(self.mf_tmp, self.mf_tmp_c, d)
             ops.gemm(self.mf_tmp_c, st.cview(v + ".visn_fc.weight"), st.gview("mask_feat"), None, None, None, 1, self.F, d,
                      d, self.F, self.F, a_kmajor=1, b_kmajor=0, out_f32=True, accumulate=1)
+        self.wgrad_sync()
         self.join()                          # language-stack gradients are final from here on
         if self.grad_ready is not None:
             self.grad_ready(st.n_used)
