@@ -142,9 +142,10 @@ template <int DH> struct Tile {
 // stage rows [0,64) x [0,DH) of a [n, ld] matrix (head slice at column c0) into an LDS tile; rows >= n and
 // columns >= DH are zero.
 template <int DH>
-__device__ __forceinline__ void stage_tile(uint8_t* tile, const bf16_t* __restrict__ base, int ld, int n, int c0, int lane) {
+__device__ __forceinline__ void stage_tile(uint8_t* tile, const bf16_t* __restrict__ base, int ld, int n, int c0, int lane,
+                                           int nthr = 64) {
     constexpr int CH = Tile<DH>::DHP / 8;               // 16-byte chunks per row
-    for (int idx = lane; idx < MAXN * CH; idx += 64) {
+    for (int idx = lane; idx < MAXN * CH; idx += nthr) {
         const int row = idx / CH, c = idx % CH;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < n && c * 8 < DH) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c0 + c * 8);
@@ -212,104 +213,77 @@ __device__ __forceinline__ void store_rows(const f32x16_t& a, bf16_t* __restrict
 }
 
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
-__global__ __launch_bounds__(64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     bf16_t* __restrict__ o, float* __restrict__ lse, int H, int nq, int nk,
                                                     int ldq, int ldk, int ldv, int ldo, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed) {
+    // one wave per 32-query fragment (NQF waves share the staged V tile of the (batch, head) problem)
     __shared__ __attribute__((aligned(16))) uint8_t vt[Tile<DH>::BYTES];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const bf16_t* qb = q + (size_t)b * nq * ldq;
     const bf16_t* kb = k + (size_t)b * nk * ldk;
     const bf16_t* vb = v + (size_t)b * nk * ldv;
-    stage_tile<DH>(vt, vb, ldv, nk, h * DH, lane);
+    stage_tile<DH>(vt, vb, ldv, nk, h * DH, tid, NQF * 64);
 
-    // S^T[key][q]
-    f32x16_t st[NKF][NQF];
+    // S^T[key][q] for this wave's queries
+    f32x16_t st[NKF];
 #pragma unroll
-    for (int i = 0; i < NKF; ++i)
-#pragma unroll
-        for (int j = 0; j < NQF; ++j) st[i][j] = zero16();
+    for (int i = 0; i < NKF; ++i) st[i] = zero16();
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s) {
-        bf16x8_t fk[NKF], fq[NQF];
+        const bf16x8_t fq = gfrag(qb, ldq, j * 32 + l31, nq, h * DH + s * 16 + hi * 8);
 #pragma unroll
-        for (int i = 0; i < NKF; ++i) fk[i] = gfrag(kb, ldk, i * 32 + l31, nk, h * DH + s * 16 + hi * 8);
-#pragma unroll
-        for (int j = 0; j < NQF; ++j) fq[j] = gfrag(qb, ldq, j * 32 + l31, nq, h * DH + s * 16 + hi * 8);
-#pragma unroll
-        for (int i = 0; i < NKF; ++i)
-#pragma unroll
-            for (int j = 0; j < NQF; ++j) st[i][j] = mfma32(fk[i], fq[j], st[i][j]);
+        for (int i = 0; i < NKF; ++i) st[i] = mfma32(gfrag(kb, ldk, i * 32 + l31, nk, h * DH + s * 16 + hi * 8), fq, st[i]);
     }
-    // key validity of this lane's accumulator rows
-    uint32_t kval = 0;
+    const int qi = j * 32 + l31;
+    float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NKF; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = i * 32 + acc_row(r, hi);
             bool ok = key < nk;
-            if (ok && key_mask) ok = key_mask[b * nk + key] != 0;
-            kval |= (ok ? 1u : 0u) << (i * 16 + r);
+            if (key_mask != nullptr) ok = ok && key_mask[b * nk + min(key, nk - 1)] != 0;
+            const float sv = ok ? st[i][r] * scale : -INFINITY;
+            st[i][r] = sv;
+            mx = fmaxf(mx, sv);
         }
-    __syncthreads();
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;
+    float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NQF; ++j) {
-        const int qi = j * 32 + l31;
-        float mx = -INFINITY;
+    for (int i = 0; i < NKF; ++i)
 #pragma unroll
-        for (int i = 0; i < NKF; ++i)
+        for (int r = 0; r < 16; ++r) { const float e = __expf(st[i][r] - mx); st[i][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (hi == 0 && qi < nq) lse[(size_t)bh * nq + qi] = mx + __logf(sum);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float sv = ((kval >> (i * 16 + r)) & 1u) ? st[i][j][r] * scale : -INFINITY;
-                st[i][j][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (mx == -INFINITY) mx = 0.f;
-        float sum = 0.f;
+    for (int i = 0; i < NKF; ++i)
 #pragma unroll
-        for (int i = 0; i < NKF; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = __expf(st[i][j][r] - mx); st[i][j][r] = e; sum += e; }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        if (hi == 0 && qi < nq) lse[(size_t)bh * nq + qi] = mx + __logf(sum);
-#pragma unroll
-        for (int i = 0; i < NKF; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = st[i][j][r] * inv;
-                if (DROP)
-                    pv *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
-                st[i][j][r] = pv;
-            }
-    }
+        for (int r = 0; r < 16; ++r) {
+            float pv = st[i][r] * inv;
+            if (DROP) pv *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
+            st[i][r] = pv;
+        }
+    __syncthreads();                      // V tile staged by all waves
     // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
     constexpr int ND = (DH + 31) / 32;
 #pragma unroll
     for (int id = 0; id < ND; ++id) {
-        f32x16_t oa[NQF];
-#pragma unroll
-        for (int j = 0; j < NQF; ++j) oa[j] = zero16();
+        f32x16_t oa = zero16();
 #pragma unroll
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bf16x8_t fv = tfrag<DH, TR>(vt, id * 32, i * 32 + u * 16, lane);
-#pragma unroll
-                for (int j = 0; j < NQF; ++j) oa[j] = mfma32(fv, acc_to_frag(st[i][j], u), oa[j]);
-            }
-#pragma unroll
-        for (int j = 0; j < NQF; ++j)
-            store_rows<DH>(oa[j], o + (size_t)b * nq * ldo, ldo, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
+            for (int u = 0; u < 2; ++u) oa = mfma32(tfrag<DH, TR>(vt, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), oa);
+        store_rows<DH>(oa, o + (size_t)b * nq * ldo, ldo, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
     }
 }
 
-template <int DH, int NQF, int NKF, bool TR, bool DROP>
-__global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+template <int DH, int NQF, int NKF, bool TR, bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                     bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
@@ -323,155 +297,118 @@ __global__ __launch_bounds__(64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q
     __shared__ float s_delta[MAXN];
     __shared__ float s_lse[MAXN];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+    // NW waves share the staged tiles of one (batch, head) problem; the 32-query fragments of phase 1 and the 32-key
+    // fragments of phase 2 are independent tasks dealt round-robin to the waves.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const bf16_t* qb = q + (size_t)b * nq * ldq;
     const bf16_t* kb = k + (size_t)b * nk * ldk;
     const bf16_t* vb = v + (size_t)b * nk * ldv;
     const bf16_t* dob = dout + (size_t)b * nq * ldo;
-    stage_tile<DH>(tk, kb, ldk, nk, h * DH, lane);
-    stage_tile<DH>(tq, qb, ldq, nq, h * DH, lane);
-    stage_tile<DH>(tdo, dob, ldo, nq, h * DH, lane);
-    stage_tile<DH>(tv, vb, ldv, nk, h * DH, lane);
-    s_lse[lane] = lane < nq ? lse[(size_t)bh * nq + lane] : 0.f;
+    stage_tile<DH>(tk, kb, ldk, nk, h * DH, tid, NW * 64);
+    stage_tile<DH>(tq, qb, ldq, nq, h * DH, tid, NW * 64);
+    stage_tile<DH>(tdo, dob, ldo, nq, h * DH, tid, NW * 64);
+    stage_tile<DH>(tv, vb, ldv, nk, h * DH, tid, NW * 64);
+    if (tid < MAXN) s_lse[tid] = tid < nq ? lse[(size_t)bh * nq + tid] : 0.f;
     constexpr int ND = (DH + 31) / 32;
     __syncthreads();
 
-    // ---------------- phase 1: lane owns a query column.  dQ and delta.
-    {
-        f32x16_t st[NKF][NQF], dpt[NKF][NQF];
+    // ---------------- phase 1: lane owns a query column.  dQ and delta.  One 32-query fragment at a time (a runtime
+    // loop: the accumulators of one fragment are live, not all of them -> 2 waves / SIMD instead of 1).
+#pragma unroll 1
+    for (int j = wave; j < NQF; j += NW) {
+        f32x16_t st[NKF], dpt[NKF];
 #pragma unroll
-        for (int i = 0; i < NKF; ++i)
-#pragma unroll
-            for (int j = 0; j < NQF; ++j) { st[i][j] = zero16(); dpt[i][j] = zero16(); }
+        for (int i = 0; i < NKF; ++i) { st[i] = zero16(); dpt[i] = zero16(); }
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
-            const int col = h * DH + s * 16 + hi * 8;
-            bf16x8_t fk[NKF], fv[NKF], fq[NQF], fdo[NQF];
+            const bf16x8_t fq = lfrag<DH>(tq, j * 32 + l31, s, lane), fdo = lfrag<DH>(tdo, j * 32 + l31, s, lane);
 #pragma unroll
-            for (int i = 0; i < NKF; ++i) { fk[i] = lfrag<DH>(tk, i * 32 + l31, s, lane); fv[i] = lfrag<DH>(tv, i * 32 + l31, s, lane); }
-#pragma unroll
-            for (int j = 0; j < NQF; ++j) { fq[j] = lfrag<DH>(tq, j * 32 + l31, s, lane); fdo[j] = lfrag<DH>(tdo, j * 32 + l31, s, lane); }
-#pragma unroll
-            for (int i = 0; i < NKF; ++i)
-#pragma unroll
-                for (int j = 0; j < NQF; ++j) { st[i][j] = mfma32(fk[i], fq[j], st[i][j]); dpt[i][j] = mfma32(fv[i], fdo[j], dpt[i][j]); }
+            for (int i = 0; i < NKF; ++i) {
+                st[i] = mfma32(lfrag<DH>(tk, i * 32 + l31, s, lane), fq, st[i]);
+                dpt[i] = mfma32(lfrag<DH>(tv, i * 32 + l31, s, lane), fdo, dpt[i]);
+            }
         }
-        uint32_t kval = 0;
+        const int qi = j * 32 + l31;
+        const float l = s_lse[qi];
+        float delta = 0.f;
 #pragma unroll
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = i * 32 + acc_row(r, hi);
                 bool ok = key < nk;
-                if (ok && key_mask) ok = key_mask[b * nk + key] != 0;
-                kval |= (ok ? 1u : 0u) << (i * 16 + r);
+                if (key_mask != nullptr) ok = ok && key_mask[b * nk + min(key, nk - 1)] != 0;
+                const float e = __expf(st[i][r] * scale - l);
+                const float pv = ok ? e : 0.f;
+                float dp = dpt[i][r];
+                if (DROP) dp *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
+                st[i][r] = pv;
+                dpt[i][r] = dp;
+                delta += pv * dp;
             }
-        __syncthreads();
+        delta += __shfl_xor(delta, 32, 64);
+        if (hi == 0) s_delta[qi] = delta;
 #pragma unroll
-        for (int j = 0; j < NQF; ++j) {
-            const int qi = j * 32 + l31;
-            const float l = s_lse[qi];
-            float delta = 0.f;
+        for (int i = 0; i < NKF; ++i)
 #pragma unroll
-            for (int i = 0; i < NKF; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pv = ((kval >> (i * 16 + r)) & 1u) ? __expf(st[i][j][r] * scale - l) : 0.f;
-                    float dp = dpt[i][j][r];
-                    if (DROP)
-                        dp *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
-                    st[i][j][r] = pv;
-                    dpt[i][j][r] = dp;
-                    delta += pv * dp;
-                }
-            delta += __shfl_xor(delta, 32, 64);
-            if (hi == 0) s_delta[qi] = delta;
-#pragma unroll
-            for (int i = 0; i < NKF; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[i][j][r] = st[i][j][r] * (dpt[i][j][r] - delta) * scale;   // dS^T
-        }
+            for (int r = 0; r < 16; ++r) st[i][r] = st[i][r] * (dpt[i][r] - delta) * scale;       // dS^T
         // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
 #pragma unroll
         for (int id = 0; id < ND; ++id) {
-            f32x16_t qa[NQF];
-#pragma unroll
-            for (int j = 0; j < NQF; ++j) qa[j] = zero16();
+            f32x16_t qa = zero16();
 #pragma unroll
             for (int i = 0; i < NKF; ++i)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const bf16x8_t fkt = tfrag<DH, TR>(tk, id * 32, i * 32 + u * 16, lane);
-#pragma unroll
-                    for (int j = 0; j < NQF; ++j) qa[j] = mfma32(fkt, acc_to_frag(st[i][j], u), qa[j]);
-                }
-#pragma unroll
-            for (int j = 0; j < NQF; ++j)
-                store_rows<DH>(qa[j], dq + (size_t)b * nq * lddq, lddq, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
+                for (int u = 0; u < 2; ++u)
+                    qa = mfma32(tfrag<DH, TR>(tk, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), qa);
+            store_rows<DH>(qa, dq + (size_t)b * nq * lddq, lddq, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
         }
     }
     __syncthreads();
-    // ---------------- phase 2: lane owns a key column.  dV and dK.
-    {
-        f32x16_t s2[NQF][NKF], dp2[NQF][NKF];
+    // ---------------- phase 2: lane owns a key column.  dV and dK.  One 32-key fragment at a time.
+#pragma unroll 1
+    for (int i = wave; i < NKF; i += NW) {
+        f32x16_t s2[NQF], dp2[NQF];
+#pragma unroll
+        for (int j = 0; j < NQF; ++j) { s2[j] = zero16(); dp2[j] = zero16(); }
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) {
+            const bf16x8_t fk = lfrag<DH>(tk, i * 32 + l31, s, lane), fv = lfrag<DH>(tv, i * 32 + l31, s, lane);
+#pragma unroll
+            for (int j = 0; j < NQF; ++j) {
+                s2[j] = mfma32(lfrag<DH>(tq, j * 32 + l31, s, lane), fk, s2[j]);
+                dp2[j] = mfma32(lfrag<DH>(tdo, j * 32 + l31, s, lane), fv, dp2[j]);
+            }
+        }
+        const int key = i * 32 + l31;
+        bool kok = key < nk;
+        if (key_mask != nullptr) kok = kok && key_mask[b * nk + min(key, nk - 1)] != 0;
 #pragma unroll
         for (int j = 0; j < NQF; ++j)
 #pragma unroll
-            for (int i = 0; i < NKF; ++i) { s2[j][i] = zero16(); dp2[j][i] = zero16(); }
-#pragma unroll
-        for (int s = 0; s < DH / 16; ++s) {
-            const int col = h * DH + s * 16 + hi * 8;
-            bf16x8_t fk[NKF], fv[NKF], fq[NQF], fdo[NQF];
-#pragma unroll
-            for (int i = 0; i < NKF; ++i) { fk[i] = lfrag<DH>(tk, i * 32 + l31, s, lane); fv[i] = lfrag<DH>(tv, i * 32 + l31, s, lane); }
-#pragma unroll
-            for (int j = 0; j < NQF; ++j) { fq[j] = lfrag<DH>(tq, j * 32 + l31, s, lane); fdo[j] = lfrag<DH>(tdo, j * 32 + l31, s, lane); }
-#pragma unroll
-            for (int j = 0; j < NQF; ++j)
-#pragma unroll
-                for (int i = 0; i < NKF; ++i) { s2[j][i] = mfma32(fq[j], fk[i], s2[j][i]); dp2[j][i] = mfma32(fdo[j], fv[i], dp2[j][i]); }
-        }
-#pragma unroll
-        for (int i = 0; i < NKF; ++i) {
-            const int key = i * 32 + l31;
-            bool kok = key < nk;
-            if (kok && key_mask) kok = key_mask[b * nk + key] != 0;
-#pragma unroll
-            for (int j = 0; j < NQF; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qi = j * 32 + acc_row(r, hi);
-                    float pv = (kok && qi < nq) ? __expf(s2[j][i][r] * scale - s_lse[qi]) : 0.f;
-                    float msk = 1.f;
-                    if (DROP) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
-                    const float dp = dp2[j][i][r] * msk;
-                    dp2[j][i][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
-                    s2[j][i][r] = pv * msk;                              // P~[q][key]
-                }
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int qi = j * 32 + acc_row(r, hi);
+                const float e = __expf(s2[j][r] * scale - s_lse[qi]);
+                const float pv = (kok && qi < nq) ? e : 0.f;
+                float msk = 1.f;
+                if (DROP) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
+                const float dp = dp2[j][r] * msk;
+                dp2[j][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
+                s2[j][r] = pv * msk;                              // P~[q][key]
+            }
         // dV^T[d][key] = sum_q dO^T[d][q] P~[q][key] ;  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
 #pragma unroll
         for (int id = 0; id < ND; ++id) {
-            f32x16_t va[NKF], ka[NKF];
-#pragma unroll
-            for (int i = 0; i < NKF; ++i) { va[i] = zero16(); ka[i] = zero16(); }
+            f32x16_t va = zero16(), ka = zero16();
 #pragma unroll
             for (int j = 0; j < NQF; ++j)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const bf16x8_t fdot = tfrag<DH, TR>(tdo, id * 32, j * 32 + u * 16, lane);
-                    const bf16x8_t fqt = tfrag<DH, TR>(tq, id * 32, j * 32 + u * 16, lane);
-#pragma unroll
-                    for (int i = 0; i < NKF; ++i) {
-                        va[i] = mfma32(fdot, acc_to_frag(s2[j][i], u), va[i]);
-                        ka[i] = mfma32(fqt, acc_to_frag(dp2[j][i], u), ka[i]);
-                    }
+                    va = mfma32(tfrag<DH, TR>(tdo, id * 32, j * 32 + u * 16, lane), acc_to_frag(s2[j], u), va);
+                    ka = mfma32(tfrag<DH, TR>(tq, id * 32, j * 32 + u * 16, lane), acc_to_frag(dp2[j], u), ka);
                 }
-#pragma unroll
-            for (int i = 0; i < NKF; ++i) {
-                store_rows<DH>(va[i], dv + (size_t)b * nk * lddv, lddv, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
-                store_rows<DH>(ka[i], dk + (size_t)b * nk * lddk, lddk, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
-            }
+            store_rows<DH>(va, dv + (size_t)b * nk * lddv, lddv, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
+            store_rows<DH>(ka, dk + (size_t)b * nk * lddk, lddk, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
         }
     }
 }
@@ -485,13 +422,14 @@ struct SdpaArgs {
 
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_fwd2(const SdpaArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(64), 0, st, (const bf16_t*)a.q,
+    hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(NQF * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk,
                        a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed);
 }
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(64), 0, st, (const bf16_t*)a.q,
+    constexpr int NW = NQF > NKF ? NQF : NKF;
+    hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP, NW>), dim3(a.B * a.H), dim3(NW * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq,
                        (bf16_t*)a.dk, (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv,
                        a.scale, a.p_drop, a.inv_keep, a.seed);
