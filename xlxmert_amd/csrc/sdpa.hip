@@ -141,11 +141,11 @@ template <int DH> struct Tile {
 
 // stage rows [0,64) x [0,DH) of a [n, ld] matrix (head slice at column c0) into an LDS tile; rows >= n and
 // columns >= DH are zero.
-template <int DH>
+template <int DH, int ROWS = MAXN>
 __device__ __forceinline__ void stage_tile(uint8_t* tile, const bf16_t* __restrict__ base, int ld, int n, int c0, int lane,
                                            int nthr = 64) {
     constexpr int CH = Tile<DH>::DHP / 8;               // 16-byte chunks per row
-    for (int idx = lane; idx < MAXN * CH; idx += nthr) {
+    for (int idx = lane; idx < ROWS * CH; idx += nthr) {
         const int row = idx / CH, c = idx % CH;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < n && c * 8 < DH) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c0 + c * 8);
@@ -219,13 +219,13 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
                                                     int ldq, int ldk, int ldv, int ldo, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed) {
     // one wave per 32-query fragment (NQF waves share the staged V tile of the (batch, head) problem)
-    __shared__ __attribute__((aligned(16))) uint8_t vt[Tile<DH>::BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t vt[NKF * 32 * Tile<DH>::PITCH];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const bf16_t* qb = q + (size_t)b * nq * ldq;
     const bf16_t* kb = k + (size_t)b * nk * ldk;
     const bf16_t* vb = v + (size_t)b * nk * ldv;
-    stage_tile<DH>(vt, vb, ldv, nk, h * DH, tid, NQF * 64);
+    stage_tile<DH, NKF * 32>(vt, vb, ldv, nk, h * DH, tid, NQF * 64);
 
     // S^T[key][q] for this wave's queries
     f32x16_t st[NKF];
@@ -283,17 +283,17 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
 }
 
 template <int DH, int NQF, int NKF, bool TR, bool DROP, int NW>
-__global__ __launch_bounds__(NW * 64) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                     bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                     int H, int nq, int nk, int ldq, int ldk, int ldv, int ldo,
                                                     int lddq, int lddk, int lddv, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed) {
-    __shared__ __attribute__((aligned(16))) uint8_t tk[Tile<DH>::BYTES];     // K   [key][d]
-    __shared__ __attribute__((aligned(16))) uint8_t tq[Tile<DH>::BYTES];     // Q   [q][d]
-    __shared__ __attribute__((aligned(16))) uint8_t tdo[Tile<DH>::BYTES];    // dO  [q][d]
-    __shared__ __attribute__((aligned(16))) uint8_t tv[Tile<DH>::BYTES];     // V   [key][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tk[NKF * 32 * Tile<DH>::PITCH];     // K   [key][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tq[NQF * 32 * Tile<DH>::PITCH];     // Q   [q][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tdo[NQF * 32 * Tile<DH>::PITCH];    // dO  [q][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tv[NKF * 32 * Tile<DH>::PITCH];     // V   [key][d]
     __shared__ float s_delta[MAXN];
     __shared__ float s_lse[MAXN];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -304,10 +304,10 @@ __global__ __launch_bounds__(NW * 64) void sdpa_bwd_mfma(const bf16_t* __restric
     const bf16_t* kb = k + (size_t)b * nk * ldk;
     const bf16_t* vb = v + (size_t)b * nk * ldv;
     const bf16_t* dob = dout + (size_t)b * nq * ldo;
-    stage_tile<DH>(tk, kb, ldk, nk, h * DH, tid, NW * 64);
-    stage_tile<DH>(tq, qb, ldq, nq, h * DH, tid, NW * 64);
-    stage_tile<DH>(tdo, dob, ldo, nq, h * DH, tid, NW * 64);
-    stage_tile<DH>(tv, vb, ldv, nk, h * DH, tid, NW * 64);
+    stage_tile<DH, NKF * 32>(tk, kb, ldk, nk, h * DH, tid, NW * 64);
+    stage_tile<DH, NQF * 32>(tq, qb, ldq, nq, h * DH, tid, NW * 64);
+    stage_tile<DH, NQF * 32>(tdo, dob, ldo, nq, h * DH, tid, NW * 64);
+    stage_tile<DH, NKF * 32>(tv, vb, ldv, nk, h * DH, tid, NW * 64);
     if (tid < MAXN) s_lse[tid] = tid < nq ? lse[(size_t)bh * nq + tid] : 0.f;
     constexpr int ND = (DH + 31) / 32;
     __syncthreads();
