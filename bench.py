@@ -168,6 +168,11 @@ def main():
     with GemmTimer(tr.ops) as gt:
         tr.step(batches[0])
     tr.engine.side = side
+    traffic = None
+    try:        # HBM bytes per GEMM launch from the committed PMC profile of this build (cannot be collected live)
+        traffic = round(json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic.json")))["bytes_per_launch"])
+    except Exception:
+        pass
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
@@ -186,7 +191,7 @@ def main():
             "step_mfma_frac": round(value / world * GFLOP_PER_EXAMPLE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_mfma_kernel (all dense contractions of one step)",
                          "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": gt.launches, "avg_launch_us": round(gt.total_ms * 1e3 / gt.launches, 2),
                          "gemm_ms_per_step": round(gt.total_ms, 3),
                          "algorithmic_gflop_per_step": round(gt.flops / 1e9, 1),
