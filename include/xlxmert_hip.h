@@ -47,6 +47,12 @@ const char* xl_last_error(void);
 int  xl_version(void);
 /* 1: GEMM/SDPA transposed operands use ds_read_b64_tr_b16; 0: 16-bit LDS gathers (debug switch) */
 int  xl_set_lds_transpose_read(int enable);
+/* GEMM kernel choice for bf16 operands: 0 = 128x128 kernel only, 1 = by shape (default), 2 = the 256x256 ping-pong
+ * kernel whenever the operands allow it (tuning / test switch; env XL_GEMM_PP sets the initial value) */
+int  xl_set_gemm_pingpong(int mode);
+/* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
+ * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */
+int  xl_gemm_trace(void* buffer);
 
 /* ---------------------------------------------------------------- dense contractions (nn.Linear)
  * C[M,N] = alpha * sum_k A(m,k) * B(n,k)  [+ bias[n]]  -> epilogue

@@ -49,13 +49,24 @@ GEMM_SHAPES = [(128, 128, 64), (256, 384, 192), (200, 72, 136), (40, 2304, 64), 
                (768, 768, 2560)]
 
 
+@pytest.fixture(params=[1, 2], ids=["kern-auto", "kern-pingpong"])
+def pingpong(request):
+    """run the bf16 GEMM tests once with the default kernel choice and once with the 256x256 ping-pong kernel forced"""
+    ops = hip(torch.bfloat16)
+    ops.set_gemm_pingpong(request.param)
+    yield request.param
+    ops.set_gemm_pingpong(1)
+
+
 @pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0), (0, 1)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_layouts(M, N, K, layout, dtype, tr):
-    if dtype == torch.float32 and tr == 0:
-        pytest.skip("transpose-read switch only affects the bf16 MFMA kernel")
+def test_gemm_layouts(M, N, K, layout, dtype, tr, pingpong):
+    if dtype == torch.float32 and (tr == 0 or pingpong == 2):
+        pytest.skip("kernel switches only affect the bf16 MFMA kernels")
+    if tr == 0 and pingpong == 2:
+        pytest.skip("the ping-pong kernel always uses transpose reads")
     ak, bk = layout
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ak * 2 + bk)
     lda = (K if ak else M) + 8
@@ -76,7 +87,9 @@ def test_gemm_layouts(M, N, K, layout, dtype, tr):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("epi", [1, 2, 3, 4])
-def test_gemm_epilogues(epi, dtype):
+def test_gemm_epilogues(epi, dtype, pingpong):
+    if dtype == torch.float32 and pingpong == 2:
+        pytest.skip("kernel switch only affects the bf16 MFMA kernels")
     g = torch.Generator().manual_seed(epi)
     M, N, K = 192, 136, 96
     A, B = rnd(g, M, K, dtype=dtype, s=0.3), rnd(g, N, K, dtype=dtype, s=0.3)
@@ -91,8 +104,10 @@ def test_gemm_epilogues(epi, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_gemm_weight_gradient_splitk_and_accumulate(dtype):
+def test_gemm_weight_gradient_splitk_and_accumulate(dtype, pingpong):
     """dW = dY^T X with fp32 output: deep contraction (split-K + atomics) and accumulate!=0."""
+    if dtype == torch.float32 and pingpong == 2:
+        pytest.skip("kernel switch only affects the bf16 MFMA kernels")
     g = torch.Generator().manual_seed(5)
     rows, n_out, k_in = 4096, 256, 192
     dY, X = rnd(g, rows, n_out, dtype=dtype, s=0.1), rnd(g, rows, k_in, dtype=dtype)
@@ -105,7 +120,31 @@ def test_gemm_weight_gradient_splitk_and_accumulate(dtype):
     close(gpu[2], cpu[2], dtype, "dW accumulate", f32_tol=1e-4, bf16_tol=2e-3)
 
 
-def test_gemm_in_place_residual_bf16():
+@pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 128), (300, 260, 200), (520, 1030, 1000), (512, 256, 1536)])
+def test_gemm_pingpong_pipeline_depths(M, N, K, layout):
+    """1, 2, 4 (ragged), 16 (ragged) and 24 K tiles through the ping-pong kernel: prologue / steady state / drain variants;
+    integer-valued operands make the fp32 accumulation exact, so a stale or early-read LDS tile cannot hide in rounding."""
+    ak, bk = layout
+    g = torch.Generator().manual_seed(M + N + K + ak * 2 + bk)
+    A = torch.randint(-3, 4, ((M, K) if ak else (K, M)), generator=g).to(torch.bfloat16)
+    B = torch.randint(-3, 4, ((N, K) if bk else (K, N)), generator=g).to(torch.bfloat16)
+    Af, Bf = A.float(), B.float()
+    ref = (Af if ak else Af.t()) @ (Bf.t() if bk else Bf)
+    ops = hip(torch.bfloat16)
+    ops.set_gemm_pingpong(2)
+    try:
+        for rep in range(3):
+            C = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")
+            ops.gemm(A.cuda(), B.cuda(), C, None, None, None, M, N, K, A.shape[1], B.shape[1], N, a_kmajor=ak, b_kmajor=bk,
+                     out_f32=True)
+            torch.cuda.synchronize()
+            assert torch.equal(C.cpu(), ref), f"rep {rep}: max abs diff {(C.cpu() - ref).abs().max().item()}"
+    finally:
+        ops.set_gemm_pingpong(1)
+
+
+def test_gemm_in_place_residual_bf16(pingpong):
     """C aliases the residual (cross-attention context gradient accumulates into the other stream's buffer)."""
     g = torch.Generator().manual_seed(9)
     M, N, K = 256, 128, 128

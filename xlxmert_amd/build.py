@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxlxmert_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "rowops.hip", "sdpa.hip", "optim.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -44,7 +44,7 @@ def build_library(force=False, verbose=True):
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(cc, SOURCES))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], capture_output=True, text=True)
     if r.returncode != 0:

@@ -110,7 +110,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // exp(-x^2/2) is shared between erf(x/sqrt2) and the Gaussian pdf of the derivative.
 __device__ __forceinline__ void erf_parts(float x, float& erf_v, float& e) {
     const float ax = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn is an IEEE division sequence
     e = __expf(-ax * ax);                       // = exp(-x^2/2)
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);

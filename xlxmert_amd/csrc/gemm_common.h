@@ -1,0 +1,349 @@
+// Shared pieces of the dense-contraction kernels (gemm.hip: generic + 128x128 MFMA kernel and the host entry point;
+// gemm_pp.hip: 256x256 ping-pong kernel): launch parameters, XCD-aware tile order, LDS operand tiles, epilogues.
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace xl {
+
+struct GemmParams {
+    const void* A; const void* B; void* C;
+    const float* bias; const void* residual; void* aux;
+    int M, N, K, lda, ldb, ldc, ldr, ldx;
+    int epilogue, out_f32, atomic_out, splitk, kper, vec_epi;
+    float alpha, p_drop, inv_keep;
+    uint64_t seed;
+    int tiles_m, tiles_n, ablate;
+    unsigned long long* trace;        // debug: per-block timestamps (xl_gemm_trace), normally null
+};
+
+// ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)
+template <typename TIn>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float v, bool add_bias) {
+    v *= p.alpha;
+    if (p.bias != nullptr && add_bias) v += p.bias[n];
+    switch (p.epilogue) {
+        case XL_EPI_GELU: {
+            TIn* aux = reinterpret_cast<TIn*>(p.aux);
+            Elem<TIn>::st(aux + (size_t)m * p.ldx + n, v);
+            v = gelu_erf(v);
+            break;
+        }
+        case XL_EPI_RESIDUAL: {
+            if (p.p_drop > 0.0f) v *= dropout_scale(p.seed, (uint64_t)m * (uint64_t)p.N + n, p.p_drop, p.inv_keep);
+            const TIn* res = reinterpret_cast<const TIn*>(p.residual);
+            v += Elem<TIn>::ld(res + (size_t)m * p.ldr + n);
+            break;
+        }
+        case XL_EPI_DGELU: {
+            const TIn* aux = reinterpret_cast<const TIn*>(p.aux);
+            v *= gelu_erf_grad(Elem<TIn>::ld(aux + (size_t)m * p.ldx + n));
+            break;
+        }
+        case XL_EPI_TANH: v = tanhf(v); break;
+        default: break;
+    }
+    if (p.out_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        if (p.atomic_out) atomicAdd(c, v); else *c = v;
+    } else {
+        Elem<TIn>::st(reinterpret_cast<TIn*>(p.C) + (size_t)m * p.ldc + n, v);
+    }
+}
+
+// tile id -> (tile_m, tile_n, split) with an XCD-aware remap: block b runs on XCD b%8 (observed
+// placement, speed only); give every XCD a contiguous chunk of a grouped (8 m-tiles x all n) order
+// so that the tiles co-resident on one XCD share A row panels and B column panels in its L2.
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn, int& z) {
+    const int nblk = gridDim.x;
+    const int b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, pos = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    const int tiles = p.tiles_m * p.tiles_n;
+    z = L / tiles;
+    const int t = L - z * tiles;
+    constexpr int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int g = t / per_group;
+    const int in_g = t - g * per_group;
+    const int gsize = min(GM, p.tiles_m - g * GM);
+    tn = in_g / gsize;
+    tm = g * GM + (in_g - tn * gsize);
+}
+
+// ================================================================== bf16 MFMA building blocks
+constexpr int BK = 64;
+
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 v8bf16_t;
+
+__device__ __forceinline__ bf16x4_t lds_tr_read(const uint8_t* ptr) {
+    auto p = (__attribute__((address_space(3))) v4bf16_t*)(ptr);
+    v4bf16_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p);
+    return __builtin_bit_cast(bf16x4_t, r);
+}
+
+// Operand tile of ROWS x 64(k) bf16 in LDS.
+//   K-major: [row][k], row pitch 128 B, 16-byte chunk c of row r stored at chunk c ^ ((r>>1)&7).
+//   M-major: [k][row], k-row pitch ROWS*2 B, byte b of k-row kr stored at b ^ ((kr&3)<<6).
+template <bool KMAJ, int ROWS>
+struct OpTile {
+    static constexpr int BYTES = ROWS * BK * 2;
+    static constexpr int RP = ROWS * 2;               // M-major k-row pitch (bytes)
+
+    // (strided index, contiguous chunk) of the 16 bytes stored at LDS byte offset o of the tile
+    __device__ static __forceinline__ void decode(int o, int& rs, int& c) {
+        if (KMAJ) { rs = o >> 7; c = ((o >> 4) & 7) ^ ((rs >> 1) & 7); }
+        else { rs = o / RP; c = ((o % RP) ^ ((rs & 3) << 6)) >> 4; }
+    }
+    __device__ static __forceinline__ int encode(int rs, int c) {
+        if (KMAJ) return rs * 128 + ((c ^ ((rs >> 1) & 7)) << 4);
+        return rs * RP + ((c << 4) ^ ((rs & 3) << 6));
+    }
+    // MFMA operand fragment: rows [r0, r0+32) (lane -> row l&31), k-slots s*16 + (l>>5)*8 + 0..7
+    template <bool TR>
+    __device__ static __forceinline__ bf16x8_t frag(const uint8_t* tile, int r0, int s, int lane) {
+        if (KMAJ) {
+            const int row = r0 + (lane & 31);
+            return *reinterpret_cast<const bf16x8_t*>(tile + encode(row, s * 2 + (lane >> 5)));
+        } else if (TR) {
+            // 16-lane group reads a [4 k][16 rows] block; lane t supplies the address of k-row t>>2,
+            // row-chunk (t&3)*4 and receives column t (4 consecutive k).
+            const int t = lane & 15;
+            const int mb = (r0 + ((lane >> 4) & 1) * 16 + (t & 3) * 4) * 2;
+            const int k0r = s * 16 + (lane >> 5) * 8 + (t >> 2), k1r = k0r + 4;
+            bf16x4_t lo = lds_tr_read(tile + k0r * RP + (mb ^ ((k0r & 3) << 6)));
+            bf16x4_t hi = lds_tr_read(tile + k1r * RP + (mb ^ ((k1r & 3) << 6)));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            const int m = r0 + (lane & 31);
+            bf16x8_t f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = s * 16 + (lane >> 5) * 8 + j;
+                f[j] = *reinterpret_cast<const short*>(tile + k * RP + ((m * 2) ^ ((k & 3) << 6)));
+            }
+            return f;
+        }
+    }
+};
+
+// predicated (zero-filling) load of the 16 bytes that belong at LDS offset o: ragged last k-tile only
+template <bool KMAJ, int ROWS>
+__device__ __forceinline__ uint4 gload16(const bf16_t* __restrict__ P, int ld, int row0, int rows_ext, int k0, int kend, int o) {
+    int rs, c;
+    OpTile<KMAJ, ROWS>::decode(o, rs, c);
+    int gr, gc, lim;
+    bool ok;
+    if (KMAJ) { gr = row0 + rs; gc = k0 + c * 8; ok = gr < rows_ext; lim = kend; }
+    else { gr = k0 + rs; gc = row0 + c * 8; ok = gr < kend; lim = rows_ext; }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) {
+        const bf16_t* src = P + (size_t)gr * ld + gc;
+        if (gc + 8 <= lim) {
+            v = *reinterpret_cast<const uint4*>(src);
+        } else if (gc < lim) {
+            bf16_t e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = (gc + i < lim) ? src[i] : (bf16_t)0;
+            v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+            v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+        }
+    }
+    return v;
+}
+
+// ---- epilogues of the MFMA kernels.  C/D layout of v_mfma_f32_32x32x16: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// split-K / accumulate (weight gradients; epilogue NONE): fp32 atomics straight from one 32x32 accumulator -- a wave
+// instruction covers 2 rows x 32 consecutive columns (2 cache lines), which is what the L2 atomic units want.
+__device__ __forceinline__ void epilogue_atomic_frag(const GemmParams& p, int lane, bool first, int mf, int nf, const f32x16_t& acc) {
+    float* Cf = reinterpret_cast<float*>(p.C);
+    const int nn = nf + (lane & 31);
+    const float bb = (first && p.bias != nullptr && nn < p.N) ? p.bias[nn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = mf + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (mm < p.M && nn < p.N) atomicAdd(Cf + (size_t)mm * p.ldc + nn, acc[r] * p.alpha + bb);
+    }
+}
+
+// One 64x64 fp32 sub-tile (2x2 accumulators, origin (mq, nq)) goes through 16 KiB of wave-private LDS so that a lane ends
+// up with 8 consecutive columns of one row (lane -> row ps*8 + lane/8, columns (lane&7)*8 ..): bias / residual / aux are
+// read and C is written with 16-byte accesses.  Plain row-major image: the 32-lane writes are conflict-free, the 16-byte
+// reads are 2-way conflicted (cheap: 16 reads per quad), and every LDS address is one lane base + an immediate offset --
+// a per-row XOR swizzle costs 32 address registers here and pushed the kernel into scratch.
+__device__ __forceinline__ void quad_to_lds(float* wbuf, int lane, const f32x16_t& a00, const f32x16_t& a01,
+                                            const f32x16_t& a10, const f32x16_t& a11) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x16_t& a = i == 0 ? (j == 0 ? a00 : a01) : (j == 0 ? a10 : a11);
+            const int col = j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wbuf[row * 64 + col] = a[r];
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void quad_row_from_lds(const float* wbuf, int row, int c8, float (&v)[8]) {
+    const float4 lo = *reinterpret_cast<const float4*>(wbuf + row * 64 + c8 * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(wbuf + row * 64 + c8 * 8 + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
+
+// Generic quad epilogue: runtime epilogue kind, ragged edges, unaligned C (scalar fallback).
+__device__ __forceinline__ void epilogue_quad(const GemmParams& p, float* wbuf, int lane, bool first, int mq, int nq,
+                                              const f32x16_t& a00, const f32x16_t& a01, const f32x16_t& a10, const f32x16_t& a11) {
+    const int c8 = lane & 7, rr = lane >> 3;
+    const bool add_bias = first && p.bias != nullptr;
+    quad_to_lds(wbuf, lane, a00, a01, a10, a11);
+    const int n = nq + c8 * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (add_bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 8 + rr;
+        const int m = mq + row;
+        float v[8];
+        quad_row_from_lds(wbuf, row, c8, v);
+        if (m >= p.M || n >= p.N) continue;
+        if (p.vec_epi && n + 8 <= p.N) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bv[e];
+            const size_t mn = (size_t)m;
+            if (p.epilogue == XL_EPI_GELU) {
+                stvec(reinterpret_cast<bf16_t*>(p.aux) + mn * p.ldx + n, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+            } else if (p.epilogue == XL_EPI_RESIDUAL) {
+                float rv[8];
+                ldvec(reinterpret_cast<const bf16_t*>(p.residual) + mn * p.ldr + n, rv);
+                if (p.p_drop > 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] *= dropout_scale(p.seed, (uint64_t)m * (uint64_t)p.N + n + e, p.p_drop, p.inv_keep);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            } else if (p.epilogue == XL_EPI_DGELU) {
+                float av[8];
+                ldvec(reinterpret_cast<const bf16_t*>(p.aux) + mn * p.ldx + n, av);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast(av[e]);
+            } else if (p.epilogue == XL_EPI_TANH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            }
+            if (p.out_f32) {
+                float* c = reinterpret_cast<float*>(p.C) + mn * p.ldc + n;
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                stvec(reinterpret_cast<bf16_t*>(p.C) + mn * p.ldc + n, v);
+            }
+        } else {
+#pragma unroll 1
+            for (int e = 0; e < 8; ++e)
+                if (n + e < p.N) epilogue_store<bf16_t>(p, m, n + e, v[e], first);
+        }
+    }
+}
+
+// Fast quad epilogue for interior tiles with 16-byte-aligned C / residual / aux (host: p.vec_epi, device: tile fully in
+// range).  The epilogue kind is a template parameter, the operand rows (residual or aux) of the whole quad are requested
+// BEFORE the LDS transpose and nothing waits on a store: branch-free, one load latency per quad instead of eight.
+struct QuadOperand { uint4 row[8]; };      // residual (RESIDUAL) or saved pre-activation (DGELU): 8 rows x 8 bf16 per lane
+
+template <int EPI>
+__device__ __forceinline__ void quad_operand_load(const GemmParams& p, int lane, int mq, int nq, QuadOperand& op) {
+    if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU) {
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(EPI == XL_EPI_RESIDUAL ? p.residual : p.aux);
+        const int ld = EPI == XL_EPI_RESIDUAL ? p.ldr : p.ldx;
+        const bf16_t* s0 = src + (size_t)(mq + (lane >> 3)) * ld + nq + (lane & 7) * 8;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) op.row[ps] = *reinterpret_cast<const uint4*>(s0 + (size_t)(ps * 8) * ld);
+    }
+}
+
+__device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
+// rows of a quad already in LDS (quad_to_lds) -> epilogue math -> 16-byte stores
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const float* wbuf, int lane, bool first, int mq, int nq,
+                                                   const QuadOperand& op) {
+    const int c8 = lane & 7, rr = lane >> 3;
+    const int n = nq + c8 * 8;
+    float bv[8];
+    if (first && p.bias != nullptr) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    }
+    const bool drop = p.p_drop > 0.0f;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 8 + rr;
+        const size_t m = (size_t)(mq + row);
+        float v[8];
+        quad_row_from_lds(wbuf, row, c8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bv[e];
+        if constexpr (EPI == XL_EPI_GELU) {
+            stvec(reinterpret_cast<bf16_t*>(p.aux) + m * p.ldx + n, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        } else if constexpr (EPI == XL_EPI_RESIDUAL) {
+            float rv[8];
+            unpack8(op.row[ps], rv);
+            if (drop) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(p.seed, (uint64_t)m * (uint64_t)p.N + n + e, p.p_drop, p.inv_keep);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        } else if constexpr (EPI == XL_EPI_DGELU) {
+            float av[8];
+            unpack8(op.row[ps], av);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast(av[e]);
+        }
+        if (p.out_f32) {
+            float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            stvec(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one row group at a time: interleaving all eight spills
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_quad_fast(const GemmParams& p, float* wbuf, int lane, bool first, int mq, int nq,
+                                                   const QuadOperand& op, const f32x16_t& a00, const f32x16_t& a01,
+                                                   const f32x16_t& a10, const f32x16_t& a11) {
+    quad_to_lds(wbuf, lane, a00, a01, a10, a11);
+    epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op);
+}
+
+// EPIK: -1 = generic epilogue (runtime kind, ragged edges); XL_EPI_NONE / GELU / RESIDUAL / DGELU = fast epilogue, used by
+// the host for launches whose C / residual / aux rows are 16-byte aligned (interior tiles take it, edge tiles fall back)
+hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int nblk, hipStream_t st);
+
+}  // namespace xl

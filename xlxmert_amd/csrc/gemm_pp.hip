@@ -1,0 +1,246 @@
+// Dense contractions, large shapes: the 256x256 ping-pong kernel (see gemm.hip for the entry point and the 128x128 kernel).
+#include "gemm_common.h"
+
+namespace xl {
+
+// ================================================================== 256x256 ping-pong kernel
+// 8 waves (2 x 4), wave tile 128 x 64, one workgroup per CU (128 KiB LDS), two waves per SIMD.  A K tile (64) is staged by
+// LDS-DMA as four 16 KiB half-tiles (A0 | B0 | B1 | A1: 64 of every wave's 128 rows / 32 of its 64 columns) into a
+// two-deep ring and consumed in four phases, one output quadrant each ((A0,B0) (A0,B1) (A1,B1) (A1,B0): every phase needs
+// at most one new operand half).  Phase = { fragment reads of this phase + LDS-DMA of the half-tile six ahead + counted
+// vmcnt | barrier | 8 MFMAs | barrier }.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in
+// its MFMA section while its partner reads fragments and issues loads.  vmcnt is never 0 in the steady state: four
+// half-tiles (8 DMA instructions per wave) stay in flight across the barriers.
+//   RAW: half-tile h is read in phase >= h-1 and was waited for (vmcnt) in phase <= h-2 by every wave, barrier in between.
+//   WAR: the slot of half-tile h is rewritten by h+8, issued in phase h+2, two phases after its last read.
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void hard_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int V> using ic = std::integral_constant<int, V>;
+
+template <bool AK, bool BKM, int EPIK>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
+    using TA = OpTile<AK, 128>;
+    using TB = OpTile<BKM, 128>;
+    constexpr int HT = 16384, BUF = 4 * HT;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];            // [2 buffers][A0 | B0 | B1 | A1]
+    int tm, tn, z;
+    tile_coords(p, tm, tn, z);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int kbeg = z * p.kper, kend = min(p.K, kbeg + p.kper);
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane sources of this wave's two 1 KiB pieces of each half-tile (element offsets, k0 excluded), and the k
+    // coordinate of the lane's 16 bytes inside the K tile (ragged last tile: lanes past kend read zeros instead)
+    uint32_t src[4][2];
+    int kk[2][2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int o = (wave * 2 + pt) * 1024 + lane * 16;
+        int rs, c;
+        TA::decode(o, rs, c);
+        kk[0][pt] = AK ? c * 8 : rs;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int lr = AK ? rs : c * 8;                                   // local row (first of 8 when M-major)
+            const int gr = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+            src[h == 0 ? 0 : 3][pt] = AK ? (uint32_t)min(gr, p.M - 1) * (uint32_t)p.lda + c * 8
+                                         : (uint32_t)rs * (uint32_t)p.lda + min(gr, p.lda - 8);
+        }
+        TB::decode(o, rs, c);
+        kk[1][pt] = BKM ? c * 8 : rs;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int lr = BKM ? rs : c * 8;
+            const int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+            src[1 + h][pt] = BKM ? (uint32_t)min(gn, p.N - 1) * (uint32_t)p.ldb + c * 8
+                                 : (uint32_t)rs * (uint32_t)p.ldb + min(gn, p.ldb - 8);
+        }
+    }
+    auto stage = [&](auto SUB, int kt) {
+        constexpr int sub = decltype(SUB)::value;
+        constexpr bool isA = (sub == 0 || sub == 3);
+        const int k0 = kbeg + kt * BK;
+        const int krem = kend - k0;
+        uint8_t* dst = smem + (kt & 1) * BUF + sub * HT + wave * 2048;
+        const bf16_t* base = isA ? A + (AK ? (size_t)k0 : (size_t)k0 * p.lda) : B + (BKM ? (size_t)k0 : (size_t)k0 * p.ldb);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const bf16_t* g = base + src[sub][pt];
+            if (kk[isA ? 0 : 1][pt] >= krem) g = reinterpret_cast<const bf16_t*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16, 0, 0);
+        }
+    };
+    bf16x8_t fa[2][4], fb[2][4];          // A: 2 row fragments x 4 k-steps of the current A half; B: both halves
+    auto read_a = [&](const uint8_t* buf, auto H) {
+        const uint8_t* t = buf + (decltype(H)::value == 0 ? 0 : 3 * HT);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i][s] = TA::template frag<true>(t, wr * 64 + i * 32, s, lane);
+    };
+    auto read_b = [&](const uint8_t* buf, auto H) {
+        constexpr int h = decltype(H)::value;
+        const uint8_t* t = buf + (1 + h) * HT;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fb[h][s] = TB::template frag<true>(t, wc * 32, s, lane);
+    };
+    auto mma = [&](auto AH, auto BH) {
+        constexpr int ah = decltype(AH)::value, bh = decltype(BH)::value;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[ah * 2 + i][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(v8bf16_t, fa[i][s]), __builtin_bit_cast(v8bf16_t, fb[bh][s]), acc[ah * 2 + i][bh], 0, 0, 0);
+    };
+    const bool prio = !(p.ablate & 32);
+    auto phase = [&](auto X, auto WAIT, auto ISSUE, int kt) {
+        constexpr int x = decltype(X)::value;
+        const uint8_t* buf = smem + (kt & 1) * BUF;
+        if constexpr (x == 0) { read_b(buf, ic<0>{}); __builtin_amdgcn_sched_barrier(0); read_a(buf, ic<0>{}); }
+        if constexpr (x == 1) read_b(buf, ic<1>{});
+        if constexpr (x == 2) read_a(buf, ic<1>{});
+        if (decltype(ISSUE)::value != 0 && !(p.ablate & 2)) {         // half-tile (4 kt + x) + 6
+            if constexpr (x == 0) stage(ic<2>{}, kt + 1);
+            if constexpr (x == 1) stage(ic<3>{}, kt + 1);
+            if constexpr (x == 2) stage(ic<0>{}, kt + 2);
+            if constexpr (x == 3) stage(ic<1>{}, kt + 2);
+        }
+        wait_vmcnt<decltype(WAIT)::value>();
+        hard_barrier();
+        if (prio) __builtin_amdgcn_s_setprio(1);
+        if (!(p.ablate & 8)) {
+            if constexpr (x == 0) mma(ic<0>{}, ic<0>{});
+            if constexpr (x == 1) mma(ic<0>{}, ic<1>{});
+            if constexpr (x == 2) mma(ic<1>{}, ic<1>{});
+            if constexpr (x == 3) mma(ic<1>{}, ic<0>{});
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) asm volatile("" ::"v"(fa[i][s2]), "v"(fb[x == 1 || x == 2 ? 1 : 0][s2]));
+        }
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        hard_barrier();
+    };
+
+    auto stamp = [&](int i) {
+        if (p.trace != nullptr && tid == 0) p.trace[(size_t)blockIdx.x * 4 + i] = wall_clock64();
+    };
+    stamp(0);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    // prologue: half-tiles 0..5 (or 0..3 of a single K tile); the first two must have landed before phase 0
+    stage(ic<0>{}, 0); stage(ic<1>{}, 0); stage(ic<2>{}, 0); stage(ic<3>{}, 0);
+    if (nkt >= 2) { stage(ic<0>{}, 1); stage(ic<1>{}, 1); wait_vmcnt<8>(); } else { wait_vmcnt<4>(); }
+    hard_barrier();
+    stamp(1);
+    const bool stagger = !(p.ablate & 16);
+    if (stagger && wr == 1) hard_barrier();
+    for (int kt = 0; kt < nkt - 2; ++kt) {
+        phase(ic<0>{}, ic<8>{}, ic<1>{}, kt);
+        phase(ic<1>{}, ic<8>{}, ic<1>{}, kt);
+        phase(ic<2>{}, ic<8>{}, ic<1>{}, kt);
+        phase(ic<3>{}, ic<8>{}, ic<1>{}, kt);
+    }
+    if (nkt >= 2) {
+        phase(ic<0>{}, ic<8>{}, ic<1>{}, nkt - 2);
+        phase(ic<1>{}, ic<8>{}, ic<1>{}, nkt - 2);
+        phase(ic<2>{}, ic<6>{}, ic<0>{}, nkt - 2);
+        phase(ic<3>{}, ic<4>{}, ic<0>{}, nkt - 2);
+    }
+    phase(ic<0>{}, ic<2>{}, ic<0>{}, nkt - 1);
+    phase(ic<1>{}, ic<0>{}, ic<0>{}, nkt - 1);
+    phase(ic<2>{}, ic<0>{}, ic<0>{}, nkt - 1);
+    phase(ic<3>{}, ic<0>{}, ic<0>{}, nkt - 1);
+    if (stagger && wr == 0) hard_barrier();
+    stamp(2);
+    if (p.ablate & 4) return;
+    // ---- epilogue (all fragment reads of the staging LDS are behind the last barrier)
+    const bool first = (z == 0);
+    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    if (p.atomic_out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) epilogue_atomic_frag(p, lane, first, mw + i * 32, nw + j * 32, acc[i][j]);
+        return;
+    }
+    float* wbuf = reinterpret_cast<float*>(smem + wave * 16384);
+    if constexpr (EPIK >= 0) {
+        if (mw + 128 <= p.M && nw + 64 <= p.N) {
+            // the first quad's operand rows are requested before its transpose, the second quad's as soon as the first
+            // quad's accumulators are in LDS (their registers are free from then on)
+            QuadOperand op0, op1;
+            quad_operand_load<EPIK>(p, lane, mw, nw, op0);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_to_lds(wbuf, lane, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_operand_load<EPIK>(p, lane, mw + 64, nw, op1);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_to_lds(wbuf, lane, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1);
+            if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+            return;
+        }
+    }
+    epilogue_quad(p, wbuf, lane, first, mw, nw, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    epilogue_quad(p, wbuf, lane, first, mw + 64, nw, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+    if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+}
+
+template <bool AK, bool BKM, int EPIK>
+static hipError_t launch_pp_one(const GemmParams& p, int nblk, hipStream_t st) {
+    constexpr int lds = 131072;
+    hipError_t e = hipSuccess;
+    auto k = gemm_bf16_pp_kernel<AK, BKM, EPIK>;
+    static bool attr = false;
+    if (!attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(512), lds, st, p);
+    return e;
+}
+
+template <bool AK, bool BKM>
+static hipError_t launch_pp_layout(const GemmParams& p, int epik, int nblk, hipStream_t st) {
+    if constexpr (AK) {
+        switch (epik) {
+            case XL_EPI_NONE: return launch_pp_one<AK, BKM, XL_EPI_NONE>(p, nblk, st);
+            case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU>(p, nblk, st);
+            case XL_EPI_RESIDUAL: return launch_pp_one<AK, BKM, XL_EPI_RESIDUAL>(p, nblk, st);
+            case XL_EPI_DGELU: return launch_pp_one<AK, BKM, XL_EPI_DGELU>(p, nblk, st);
+            default: break;
+        }
+    }
+    return launch_pp_one<AK, BKM, -1>(p, nblk, st);
+}
+
+hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int nblk, hipStream_t st) {
+    if (a_kmajor && b_kmajor) return launch_pp_layout<true, true>(p, epik, nblk, st);
+    if (a_kmajor && !b_kmajor) return launch_pp_layout<true, false>(p, epik, nblk, st);
+    if (!a_kmajor && b_kmajor) return launch_pp_layout<false, true>(p, epik, nblk, st);
+    return launch_pp_layout<false, false>(p, epik, nblk, st);
+}
+
+}  // namespace xl
