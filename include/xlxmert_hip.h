@@ -72,6 +72,16 @@ int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             int epilogue, float alpha, int accumulate,
             float p_drop, uint64_t seed, void* stream);
 
+/* Grouped weight gradients: for i in [0, count), count <= 8:
+ *     C_i[M_i, N_i] (fp32) += sum_k A_i[k, m] * B_i[k, n]        (dW = dY^T X; both operands stored [K_i rows][features])
+ * i.e. xl_gemm(..., a_kmajor=0, b_kmajor=0, out fp32, accumulate=1) for several Linear layers in ONE launch: the output
+ * tiles of all problems are dealt to the CUs together, so a K split of 2-3 fills the chip where a single d x d weight
+ * needs 7-28 (each split is a pass of fp32 atomics over the output).  Replaces the per-parameter .grad accumulation of
+ * autograd for the Linear weights of one LXMERT block (HF:258-342).  Arrays are HOST arrays of length count. */
+int  xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const* C,
+                         const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
+                         int count, int dtype, void* stream);
+
 /* ---------------------------------------------------------------- LayerNorm (eps inside sqrt, HF:188 et al.)
  * y = (x-mean)*rstd*gamma+beta over the last dim N; saves mean,rstd (fp32 [M]).  */
 int xl_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,

@@ -78,6 +78,10 @@ class FakeOps:
         else:
             c.copy_(acc)
 
+    def gemm_wgrad_group(self, problems):
+        for (A, B, C, M, N, K, lda, ldb, ldc) in problems:
+            self.gemm(A, B, C, None, None, None, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+
     @staticmethod
     def _ln(x, g, b, eps):
         mean = x.mean(1, keepdim=True)

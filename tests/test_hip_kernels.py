@@ -144,6 +144,26 @@ def test_gemm_pingpong_pipeline_depths(M, N, K, layout):
         ops.set_gemm_pingpong(1)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows", [(2048, 2048, 2048), (1536, 640, 1536)])
+def test_gemm_wgrad_group(rows, dtype):
+    """three weight gradients of different shapes (and contraction lengths) accumulated by one grouped launch"""
+    g = torch.Generator().manual_seed(rows[1])
+    shapes = [(768, 256), (200, 520), (256, 256)]
+    probs_cpu, probs_gpu, refs = [], [], []
+    for (m, n), K in zip(shapes, rows):
+        dY = torch.randint(-2, 3, (K, m + 8), generator=g).to(dtype)
+        X = torch.randint(-2, 3, (K, n + 16), generator=g).to(dtype)
+        C = torch.randint(-5, 6, (m, n + 4), generator=g).float()
+        refs.append(C[:, :n] + dY[:, :m].float().t() @ X[:, :n].float())
+        Cg = C.cuda()
+        probs_gpu.append((dY.cuda(), X.cuda(), Cg, m, n, K, m + 8, n + 16, n + 4))
+    hip(dtype).gemm_wgrad_group(probs_gpu)
+    torch.cuda.synchronize()
+    for (m, n), pr, ref in zip(shapes, probs_gpu, refs):
+        assert torch.equal(pr[2].cpu()[:, :n], ref), f"dW {m}x{n}: max abs diff {(pr[2].cpu()[:, :n] - ref).abs().max().item()}"
+
+
 def test_gemm_in_place_residual_bf16(pingpong):
     """C aliases the residual (cross-attention context gradient accumulates into the other stream's buffer)."""
     g = torch.Generator().manual_seed(9)

@@ -337,3 +337,54 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
+
+extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const* C,
+                                   const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
+                                   int count, int dtype, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    XL_CHECK_ARG(count >= 1 && count <= 8, XL_ERR_BAD_ARG, "xl_gemm_wgrad_group: count %d (1..8)", count);
+    XL_CHECK_ARG(A && B && C && M && N && K && lda && ldb && ldc, XL_ERR_BAD_ARG, "xl_gemm_wgrad_group: null argument");
+    XL_CHECK_ARG(dtype == XL_F32 || dtype == XL_BF16, XL_ERR_BAD_DTYPE, "xl_gemm_wgrad_group: bad dtype %d", dtype);
+    if (g_gemm_pp < 0) g_gemm_pp = env_int("XL_GEMM_PP", 1);
+    bool grouped = dtype == XL_BF16 && g_gemm_pp != 0 && g_use_tr_read && count > 1;
+    long total = 0;
+    int max_split = 1 << 20;
+    for (int i = 0; i < count; ++i) {
+        XL_CHECK_ARG(A[i] && B[i] && C[i] && M[i] > 0 && N[i] > 0 && K[i] > 0 && lda[i] >= M[i] && ldb[i] >= N[i] && ldc[i] >= N[i],
+                     XL_ERR_BAD_SHAPE, "xl_gemm_wgrad_group: problem %d: bad operands / shape", i);
+        grouped = grouped && lda[i] % 8 == 0 && ldb[i] % 8 == 0 && aligned16(A[i]) && aligned16(B[i]) && K[i] % 8 == 0 &&
+                  (double)K[i] * lda[i] < 2e9 && (double)K[i] * ldb[i] < 2e9;
+        total += (long)((M[i] + 255) / 256) * ((N[i] + 255) / 256);
+        max_split = std::min(max_split, std::max(1, K[i] / 512));
+    }
+    static const int group_min_blocks = env_int("XL_GEMM_GROUP_MIN_BLOCKS", 96);
+    int splitk = total >= 256 ? 1 : (int)std::min<long>(256 / total, max_split);
+    if (splitk < 1) splitk = 1;
+    if (grouped && total * splitk < group_min_blocks) grouped = false;
+    if (!grouped) {          // one launch per problem (fp32 parity path, operands the ping-pong kernel does not take, tiny groups)
+        for (int i = 0; i < count; ++i) {
+            int rc = xl_gemm(A[i], B[i], C[i], nullptr, nullptr, nullptr, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], 0, 0,
+                             0, 0, dtype, XL_F32, XL_EPI_NONE, 1.0f, 1, 0.f, 0, stream);
+            if (rc != XL_OK) return rc;
+        }
+        return XL_OK;
+    }
+    GroupParams g;
+    g.count = count; g.splitk = splitk;
+    int acc = 0;
+    for (int i = 0; i < count; ++i) {
+        GroupProblem& pr = g.prob[i];
+        pr.A = A[i]; pr.B = B[i]; pr.C = C[i]; pr.M = M[i]; pr.N = N[i]; pr.K = K[i];
+        pr.lda = lda[i]; pr.ldb = ldb[i]; pr.ldc = ldc[i];
+        pr.tiles_m = (M[i] + 255) / 256; pr.tiles_n = (N[i] + 255) / 256;
+        int kper = (K[i] + splitk - 1) / splitk;
+        pr.kper = (kper + 63) / 64 * 64;
+        g.tile_start[i] = acc;
+        acc += pr.tiles_m * pr.tiles_n;
+    }
+    for (int i = count; i <= 8; ++i) g.tile_start[i] = acc;
+    hipError_t e = launch_pp_group(g, acc * splitk, st);
+    XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm_wgrad_group: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}

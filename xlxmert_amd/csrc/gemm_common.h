@@ -342,6 +342,17 @@ __device__ __forceinline__ void epilogue_quad_fast(const GemmParams& p, float* w
     epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op);
 }
 
+struct GroupProblem {
+    const void* A; const void* B; void* C;
+    int M, N, K, lda, ldb, ldc, kper, tiles_m, tiles_n;
+};
+struct GroupParams {
+    int count, splitk;
+    int tile_start[9];                 // prefix sums of the problems' 256x256 tile counts
+    GroupProblem prob[8];
+};
+hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st);
+
 // EPIK: -1 = generic epilogue (runtime kind, ragged edges); XL_EPI_NONE / GELU / RESIDUAL / DGELU = fast epilogue, used by
 // the host for launches whose C / residual / aux rows are 16-byte aligned (interior tiles take it, edge tiles fall back)
 hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int nblk, hipStream_t st);

@@ -25,13 +25,11 @@ __device__ __forceinline__ void hard_barrier() {
 template <int V> using ic = std::integral_constant<int, V>;
 
 template <bool AK, bool BKM, int EPIK>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
+__device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int z) {
     using TA = OpTile<AK, 128>;
     using TB = OpTile<BKM, 128>;
     constexpr int HT = 16384, BUF = 4 * HT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];            // [2 buffers][A0 | B0 | B1 | A1]
-    int tm, tn, z;
-    tile_coords(p, tm, tn, z);
     const int m0 = tm * 256, n0 = tn * 256;
     const int kbeg = z * p.kper, kend = min(p.K, kbeg + p.kper);
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
@@ -209,6 +207,47 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
     epilogue_quad(p, wbuf, lane, first, mw, nw, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
     epilogue_quad(p, wbuf, lane, first, mw + 64, nw, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
     if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+}
+
+template <bool AK, bool BKM, int EPIK>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
+    int tm, tn, z;
+    tile_coords(p, tm, tn, z);
+    pp_tile<AK, BKM, EPIK>(p, tm, tn, z);
+}
+
+// Grouped weight gradients: the output tiles of up to 8 problems C_i[M_i,N_i] += A_i^T B_i (M-major operands, fp32
+// atomics) dealt to the CUs of ONE launch.  Linear block order: XCD-contiguous chunks of [split z][problem][tile].
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams g) {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, pos = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    const int total = g.tile_start[g.count];
+    const int z = L / total;
+    const int t = L - z * total;
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < g.count && t >= g.tile_start[i + 1]) ++i;
+    const GroupProblem& pr = g.prob[i];
+    GemmParams p;
+    p.A = pr.A; p.B = pr.B; p.C = pr.C; p.bias = nullptr; p.residual = nullptr; p.aux = nullptr;
+    p.M = pr.M; p.N = pr.N; p.K = pr.K; p.lda = pr.lda; p.ldb = pr.ldb; p.ldc = pr.ldc; p.ldr = 0; p.ldx = 0;
+    p.epilogue = XL_EPI_NONE; p.out_f32 = 1; p.atomic_out = 1; p.splitk = g.splitk; p.kper = pr.kper; p.vec_epi = 0;
+    p.alpha = 1.0f; p.p_drop = 0.f; p.inv_keep = 1.f; p.seed = 0;
+    p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr;
+    if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
+    const int tl = t - g.tile_start[i];
+    pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, z);
+}
+
+hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st) {
+    constexpr int lds = 131072;
+    hipError_t e = hipSuccess;
+    static bool attr = false;
+    if (!attr) { e = hipFuncSetAttribute((const void*)gemm_bf16_pp_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(gemm_bf16_pp_group_kernel, dim3(nblk), dim3(512), lds, st, g);
+    return e;
 }
 
 template <bool AK, bool BKM, int EPIK>

@@ -70,7 +70,7 @@ class SelfAttBlock:
         e.wgrad_sync()                  # the previous block's weight-gradient GEMMs still read the shared scratch
         dz = e.tmp("dz", M, d)
         dzm = e.ln_bwd_dense(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo, M, d, self.site + 1)
-        e.wgrad(dzm, self.ctx, p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad_defer(dzm, self.ctx, p.gwo, d, d, M, d, d, d)
         dctx = e.tmp("dctx", M, d)
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         dqkv = e.tmp("dqkv", M, 3 * d)
@@ -79,7 +79,8 @@ class SelfAttBlock:
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                      e.scale, e.p_attn, e.seed(self.site))
         ops.colsum(dqkv, p.gbqkv, M, 3 * d, 3 * d, ws=e.ws)
-        e.wgrad(dqkv, self.x, p.gwqkv, None, None, None, 3 * d, d, M, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad_defer(dqkv, self.x, p.gwqkv, 3 * d, d, M, 3 * d, d, d)
+        e.wgrad_flush()
         ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -118,12 +119,13 @@ class FFNBlock:
         e.wgrad_sync()
         dz = e.tmp("dz", M, d)
         dzm = e.ln_bwd_dense(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb, self.gb2, M, d, self.site)
-        e.wgrad(dzm, self.h, self.gw2, None, None, None, d, dff, M, d, dff, dff, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad_defer(dzm, self.h, self.gw2, d, dff, M, d, dff, dff)
         dpre = e.tmp("dpre", M, dff)
         ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_DGELU)
         ops.colsum(dpre, self.gb1, M, dff, dff, ws=e.ws)
-        e.wgrad(dpre, self.x, self.gw1, None, None, None, dff, d, M, dff, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad_defer(dpre, self.x, self.gw1, dff, d, M, dff, d, d)
+        e.wgrad_flush()
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -174,7 +176,7 @@ class CrossAttBlock:
         dz = dz_full[r0:]
         dzm = e.ln_bwd_dense(dY[r0:], self.z[r0:], p.g, self.mean[r0:], self.rstd[r0:], dz, p.gg, p.gb, p.gbo, M, d,
                              self.site + 2)
-        e.wgrad(dzm, self.ctx[r0:], p.gwo, None, None, None, d, d, M, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        e.wgrad_defer(dzm, self.ctx[r0:], p.gwo, d, d, M, d, d, d)
         dctx_full = e.tmp("dctx", MX, d)
         dctx = dctx_full[r0:]
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
@@ -190,15 +192,16 @@ class CrossAttBlock:
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
                          e.p_attn, e.seed(self.site))
             ops.colsum(dqkv, p.gbqkv, MX, 3 * d, 3 * d, ws=e.ws)
-            e.wgrad(dqkv, X, p.gwqkv, None, None, None, 3 * d, d, MX, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+            e.wgrad_defer(dqkv, X, p.gwqkv, 3 * d, d, MX, 3 * d, d, d)
+            e.wgrad_flush()
             ops.gemm(dqkv, p.wqkv, dX, None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
         else:
             ops.colsum(dqkv_v, p.gbqkv, MV, d, 3 * d, ws=e.ws)
             ops.colsum(dqkv_l[:, d:], p.gbqkv[d:], ML, 2 * d, 3 * d, ws=e.ws)
-            e.wgrad(dqkv_v, X[ML:], p.gwqkv, None, None, None, d, d, MV, 3 * d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
-            e.wgrad(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], None, None, None, 2 * d, d, ML, 3 * d, d, d, a_kmajor=0,
-                     b_kmajor=0, out_f32=True, accumulate=1)
+            e.wgrad_defer(dqkv_v, X[ML:], p.gwqkv, d, d, MV, 3 * d, d, d)
+            e.wgrad_defer(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], 2 * d, d, ML, 3 * d, d, d)
+            e.wgrad_flush()
             ops.gemm(dqkv_v, p.wqkv, dX[ML:], None, dz, None, MV, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
             ops.gemm(dqkv_l[:, d:], p.wqkv[d:], dX[:ML], None, None, None, ML, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
@@ -228,6 +231,7 @@ class Engine:
         self._n_sites = 2               # sites 0 / 1: embedding and visual-feature-encoder output dropout
         self._seed = 0
         self._tmp = {}
+        self._pending = {"v": [], "l": []}
         self.act_bytes = 0
         st, d = store, self.d
         # ---- blocks
@@ -346,14 +350,23 @@ class Engine:
         if self.side is not None:
             torch.cuda.current_stream().wait_event(self.side.record_event())
 
-    def wgrad(self, *args, **kw):
-        """queue a weight-gradient GEMM on the companion stream of the current stream (after everything queued so far)."""
+    def wgrad_defer(self, dY, X, dW, M, N, K, lda, ldb, ldc):
+        """register dW[M,N] += dY[K,M]^T X[K,N]; launched with the block's other weight gradients by wgrad_flush()."""
+        self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc))
+
+    def wgrad_flush(self):
+        """queue the registered weight gradients as ONE grouped launch on the companion stream of the current stream
+        (after everything queued so far): off the dX dependency chain, and one K split of 2-7 for the whole group."""
+        probs = self._pending[self._tag]
+        if not probs:
+            return
+        self._pending[self._tag] = []
         if self._dw is None or self.side is None:
-            return self.ops.gemm(*args, **kw)
+            return self.ops.gemm_wgrad_group(probs)
         dw = self._dw[self._tag]
         dw.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(dw):
-            self.ops.gemm(*args, **kw)
+            self.ops.gemm_wgrad_group(probs)
 
     def wgrad_sync(self):
         """current stream waits for the weight-gradient GEMMs queued so far by this stream."""
@@ -534,7 +547,7 @@ class Engine:
         else:
             ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, None, None, MV, F, K, self.Kp, F, F, a_kmajor=1, b_kmajor=0)
         ops.colsum(dfeat, hd["bf"][1], MV, F, F, ws=self.ws)
-        self.wgrad(dfeat, self.t_y, hd["wf"][1], None, None, None, F, d, MV, F, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        self.wgrad_defer(dfeat, self.t_y, hd["wf"][1], F, d, MV, F, d, d)
         dty = self.tmp("dz", MV, d)
         ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, MV, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
         dth = self.tmp("dctx", MV, d)
@@ -542,7 +555,8 @@ class Engine:
         dtp = self.tmp("dzm", MV, d)
         ops.gelu_bwd(dth, self.t_pre, dtp, MV * d)
         ops.colsum(dtp, hd["bt"][1], MV, d, d, ws=self.ws)
-        self.wgrad(dtp, self.vis_final, hd["wt"][1], None, None, None, d, d, MV, d, d, d, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        self.wgrad_defer(dtp, self.vis_final, hd["wt"][1], d, d, MV, d, d, d)
+        self.wgrad_flush()
         ops.gemm(dtp, hd["wt"][0], d_vis, None, None, None, MV, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         self._ready("obj_predict_head.")
 

@@ -59,6 +59,16 @@ class HipOps:
                       XL_F32 if out_f32 else self.dt, epilogue, float(alpha), int(accumulate), float(p_drop),
                       int(seed), self._stream())
 
+    def gemm_wgrad_group(self, problems):
+        """problems: list of (dY [K, M], X [K, N], dW [M, N] fp32, M, N, K, lda, ldb, ldc): dW += dY^T X, one launch."""
+        import ctypes
+        n = len(problems)
+        vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
+        cols = list(zip(*problems))
+        ptrs = [vp(*[self._p(t) for t in cols[j]]) for j in range(3)]
+        ints = [ia(*[int(v) for v in cols[j]]) for j in range(3, 9)]
+        self.lib.call("xl_gemm_wgrad_group", *ptrs, *ints, n, self.dt, self._stream())
+
     # -- LayerNorm family
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, N, eps):
         self.lib.call("xl_layernorm_fwd", self._p(x), self._p(gamma), self._p(beta), self._p(y), self._p(mean),
