@@ -82,10 +82,10 @@ def cpu_baseline(cfg, bs, budget_s=20.0):
 
 
 class GemmTimer:
-    """Wraps HipOps.gemm with HIP events on the launch stream (torch's current stream) for ONE instrumented step."""
+    """Wraps HipOps.gemm / gemm_wgrad_group with HIP events on the launch stream (torch's current stream) for ONE instrumented step."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.rec = ops, ops.gemm, []
+        self.ops, self.orig, self.orig_group, self.rec = ops, ops.gemm, ops.gemm_wgrad_group, []
 
     def __enter__(self):
         def timed(A, B, C, bias, residual, aux, M, N, K, *a, **kw):
@@ -94,11 +94,19 @@ class GemmTimer:
             self.orig(A, B, C, bias, residual, aux, M, N, K, *a, **kw)
             e.record()
             self.rec.append((s, e, 2.0 * M * N * K))
+        def timed_group(problems):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.orig_group(problems)
+            e.record()
+            self.rec.append((s, e, sum(2.0 * pr[3] * pr[4] * pr[5] for pr in problems)))
         self.ops.gemm = timed
+        self.ops.gemm_wgrad_group = timed_group
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
+        self.ops.gemm_wgrad_group = self.orig_group
         torch.cuda.synchronize()
         self.total_ms = sum(s.elapsed_time(e) for s, e, _ in self.rec)
         self.flops = sum(f for _, _, f in self.rec)
@@ -189,7 +197,7 @@ def main():
                        "loss": round(loss_val, 4)},
             "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
             "step_mfma_frac": round(value / world * GFLOP_PER_EXAMPLE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_mfma_kernel (all dense contractions of one step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel + gemm_bf16_mfma_kernel (all dense contractions of one step, grouped weight gradients included)",
                          "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": gt.launches, "avg_launch_us": round(gt.total_ms * 1e3 / gt.launches, 2),

@@ -6,13 +6,12 @@ namespace xl {
 // ================================================================== 256x256 ping-pong kernel
 // 8 waves (2 x 4), wave tile 128 x 64, one workgroup per CU (128 KiB LDS), two waves per SIMD.  A K tile (64) is staged by
 // LDS-DMA as four 16 KiB half-tiles (A0 | B0 | B1 | A1: 64 of every wave's 128 rows / 32 of its 64 columns) into a
-// two-deep ring and consumed in four phases, one output quadrant each ((A0,B0) (A0,B1) (A1,B1) (A1,B0): every phase needs
-// at most one new operand half).  Phase = { fragment reads of this phase + LDS-DMA of the half-tile six ahead + counted
-// vmcnt | barrier | 8 MFMAs | barrier }.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in
-// its MFMA section while its partner reads fragments and issues loads.  vmcnt is never 0 in the steady state: four
-// half-tiles (8 DMA instructions per wave) stay in flight across the barriers.
-//   RAW: half-tile h is read in phase >= h-1 and was waited for (vmcnt) in phase <= h-2 by every wave, barrier in between.
-//   WAR: the slot of half-tile h is rewritten by h+8, issued in phase h+2, two phases after its last read.
+// two-deep ring and consumed in two phases of 16 MFMAs (rows A0, then rows A1, against both column halves).
+// Phase = { fragment reads + LDS-DMA issue + lgkmcnt(0) + counted vmcnt | barrier | 16 MFMAs | barrier }.  Waves 4-7 run
+// one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA section while its partner reads fragments and
+// issues loads.  vmcnt is never 0 in the steady state: four half-tiles (8 DMA instructions per wave) stay in flight
+// across the barriers.  (A four-phase variant with 8 MFMAs per section measured 1.9 us per K tile against this one's
+// figure in DESIGN.md: the barrier round trip, ~200 cycles, is the overhead to amortise.)
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
 
 template <int N>
@@ -111,32 +110,51 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
                 acc[ah * 2 + i][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     __builtin_bit_cast(v8bf16_t, fa[i][s]), __builtin_bit_cast(v8bf16_t, fb[bh][s]), acc[ah * 2 + i][bh], 0, 0, 0);
     };
+    auto mma2 = [&](auto AH) {            // 16 MFMAs over 4 independent accumulators
+        constexpr int ah = decltype(AH)::value;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[ah * 2 + i][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(v8bf16_t, fa[i][s]), __builtin_bit_cast(v8bf16_t, fb[bh][s]), acc[ah * 2 + i][bh], 0, 0, 0);
+    };
     const bool prio = !(p.ablate & 32);
+    // Two phases per K tile, 16 MFMAs each: P0 = rows A0 x (B0 | B1), P1 = rows A1 x (B1 | B0).
+    //   P0(t) reads B0, B1, A0 of tile t and issues A1(t+1);  P1(t) reads A1 of tile t and issues A0, B0, B1 of tile t+2.
+    // Every half-tile is issued two phases before the phase that waits for it (vmcnt) and three before its first read;
+    // a slot is rewritten one phase after its last read, which is safe because the fragment reads are retired
+    // (lgkmcnt(0)) BEFORE the barrier that ends the reading section.
     auto phase = [&](auto X, auto WAIT, auto ISSUE, int kt) {
         constexpr int x = decltype(X)::value;
         const uint8_t* buf = smem + (kt & 1) * BUF;
-        if constexpr (x == 0) { read_b(buf, ic<0>{}); __builtin_amdgcn_sched_barrier(0); read_a(buf, ic<0>{}); }
-        if constexpr (x == 1) read_b(buf, ic<1>{});
-        if constexpr (x == 2) read_a(buf, ic<1>{});
-        if (decltype(ISSUE)::value != 0 && !(p.ablate & 2)) {         // half-tile (4 kt + x) + 6
-            if constexpr (x == 0) stage(ic<2>{}, kt + 1);
-            if constexpr (x == 1) stage(ic<3>{}, kt + 1);
-            if constexpr (x == 2) stage(ic<0>{}, kt + 2);
-            if constexpr (x == 3) stage(ic<1>{}, kt + 2);
+        if constexpr (x == 0) {
+            read_b(buf, ic<0>{}); read_b(buf, ic<1>{});
+            read_a(buf, ic<0>{});
+        } else {
+            read_a(buf, ic<1>{});
         }
+        if (decltype(ISSUE)::value != 0 && !(p.ablate & 2)) {
+            if constexpr (x == 0) {
+                stage(ic<3>{}, kt + 1);
+            } else {
+                stage(ic<0>{}, kt + 2); stage(ic<1>{}, kt + 2); stage(ic<2>{}, kt + 2);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vmcnt<decltype(WAIT)::value>();
         hard_barrier();
         if (prio) __builtin_amdgcn_s_setprio(1);
         if (!(p.ablate & 8)) {
-            if constexpr (x == 0) mma(ic<0>{}, ic<0>{});
-            if constexpr (x == 1) mma(ic<0>{}, ic<1>{});
-            if constexpr (x == 2) mma(ic<1>{}, ic<1>{});
-            if constexpr (x == 3) mma(ic<1>{}, ic<0>{});
+            if constexpr (x == 0) mma2(ic<0>{});
+            else mma2(ic<1>{});
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) asm volatile("" ::"v"(fa[i][s2]), "v"(fb[x == 1 || x == 2 ? 1 : 0][s2]));
+                for (int s2 = 0; s2 < 4; ++s2) asm volatile("" ::"v"(fa[i][s2]), "v"(fb[0][s2]), "v"(fb[1][s2]));
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
         hard_barrier();
@@ -147,9 +165,9 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     };
     stamp(0);
     const int nkt = (kend - kbeg + BK - 1) / BK;
-    // prologue: half-tiles 0..5 (or 0..3 of a single K tile); the first two must have landed before phase 0
+    // prologue: tile 0 complete, plus A0 | B0 | B1 of tile 1; A0, B0, B1 of tile 0 must have landed before P0(0)
     stage(ic<0>{}, 0); stage(ic<1>{}, 0); stage(ic<2>{}, 0); stage(ic<3>{}, 0);
-    if (nkt >= 2) { stage(ic<0>{}, 1); stage(ic<1>{}, 1); wait_vmcnt<8>(); } else { wait_vmcnt<4>(); }
+    if (nkt >= 2) { stage(ic<0>{}, 1); stage(ic<1>{}, 1); stage(ic<2>{}, 1); wait_vmcnt<8>(); } else { wait_vmcnt<2>(); }
     hard_barrier();
     stamp(1);
     const bool stagger = !(p.ablate & 16);
@@ -157,19 +175,13 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     for (int kt = 0; kt < nkt - 2; ++kt) {
         phase(ic<0>{}, ic<8>{}, ic<1>{}, kt);
         phase(ic<1>{}, ic<8>{}, ic<1>{}, kt);
-        phase(ic<2>{}, ic<8>{}, ic<1>{}, kt);
-        phase(ic<3>{}, ic<8>{}, ic<1>{}, kt);
     }
     if (nkt >= 2) {
         phase(ic<0>{}, ic<8>{}, ic<1>{}, nkt - 2);
-        phase(ic<1>{}, ic<8>{}, ic<1>{}, nkt - 2);
-        phase(ic<2>{}, ic<6>{}, ic<0>{}, nkt - 2);
-        phase(ic<3>{}, ic<4>{}, ic<0>{}, nkt - 2);
+        phase(ic<1>{}, ic<2>{}, ic<0>{}, nkt - 2);
     }
-    phase(ic<0>{}, ic<2>{}, ic<0>{}, nkt - 1);
+    phase(ic<0>{}, ic<0>{}, ic<0>{}, nkt - 1);
     phase(ic<1>{}, ic<0>{}, ic<0>{}, nkt - 1);
-    phase(ic<2>{}, ic<0>{}, ic<0>{}, nkt - 1);
-    phase(ic<3>{}, ic<0>{}, ic<0>{}, nkt - 1);
     if (stagger && wr == 0) hard_barrier();
     stamp(2);
     if (p.ablate & 4) return;
