@@ -117,15 +117,17 @@ class FFNBlock:
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
         ops = e.ops
         e.wgrad_sync()
-        dz = e.tmp("dz", M, d)
-        dzm = e.ln_bwd_dense(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb, self.gb2, M, d, self.site)
+        # own scratch names: the two weight gradients registered here are launched together with the attention block's
+        # (which runs next on this stream and flushes), so dz / dzm / dpre must outlive that block's scratch use
+        dz = e.tmp("f_dz", M, d)
+        dzm = e.ln_bwd_dense(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb, self.gb2, M, d, self.site,
+                             tmp_name="f_dzm")
         e.wgrad_defer(dzm, self.h, self.gw2, d, dff, M, d, dff, dff)
         dpre = e.tmp("dpre", M, dff)
         ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_DGELU)
         ops.colsum(dpre, self.gb1, M, dff, dff, ws=e.ws)
         e.wgrad_defer(dpre, self.x, self.gw1, dff, d, M, dff, d, d)
-        e.wgrad_flush()
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -356,7 +358,8 @@ class Engine:
 
     def wgrad_flush(self):
         """queue the registered weight gradients as ONE grouped launch on the companion stream of the current stream
-        (after everything queued so far): off the dX dependency chain, and one K split of 2-7 for the whole group."""
+        (after everything queued so far): off the dX dependency chain, and one K split of 2-7 for the whole group.
+        An FFN block leaves its two problems pending for the attention block of the same layer: four per launch."""
         probs = self._pending[self._tag]
         if not probs:
             return
@@ -391,18 +394,19 @@ class Engine:
     def set_step_seed(self, seed):
         self._seed = int(seed)
 
-    def ln_bwd_dense(self, dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, site):
+    def ln_bwd_dense(self, dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, site, tmp_name="dzm"):
         """LayerNorm backward of a `LN(dropout(dense(.)) + residual)` block: returns the gradient entering the dense layer
         (dz itself when dropout is off, else the masked copy written by the same kernel); the dense bias gradient is fused."""
         if self.p_hid == 0:
             self.ops.layernorm_bwd(dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, ws=self.ws)
             return dz
-        dzm = self.tmp("dzm", M, N)
+        dzm = self.tmp(tmp_name, M, N)
         self.ops.layernorm_bwd(dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, ws=self.ws, dx_dropped=dzm,
                                p_drop=self.p_hid, seed=self.seed(site))
         return dzm
 
     def _ready(self, prefix):
+        assert not self._pending["v"] and not self._pending["l"], "weight gradients registered but never flushed"
         self.wgrad_sync()
         if self.grad_ready is not None:
             self.grad_ready(self.store.range_of(prefix)[1])
@@ -592,7 +596,7 @@ class Engine:
             e = "bert.embeddings"
             if self.p_hid > 0:
                 ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
-            dpre = self.tmp("dz", ML, d)
+            dpre = self.tmp("emb_dz", ML, d)      # not "dz": layer 0's weight-gradient group may still be reading it
             ops.layernorm_bwd(GA[:ML], self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
                               st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d, ws=self.ws)
             ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
