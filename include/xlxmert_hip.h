@@ -64,13 +64,17 @@ int  xl_gemm_trace(void* buffer);
  *   in_dtype: element type of A,B,residual,aux.  out_dtype: element type of C (XL_F32 allowed with bf16 inputs).
  *   bias: fp32 [N] or NULL.  residual/aux: [M,N] with ldr/ldx or NULL.
  *   dropout (XL_EPI_RESIDUAL only): keep-prob (1-p_drop), mask = hash(seed, m*N+n); p_drop=0 disables.
+ *   colsum_out: NULL, or fp32 [N]: colsum_out[n] += sum_m C[m,n] over the values as stored in C (the bias gradient of the
+ *     Linear layer whose output gradient C is, e.g. d(pre-activation) -> d(intermediate.dense.bias), HF:325-331); needs
+ *     colsum_ws with xl_workspace_floats(N) floats.  Computed in the epilogue when every output tile is interior and
+ *     aligned, by a separate pass over C otherwise -- same result either way.
  */
 int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             const void* residual, void* aux,
             int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldx,
             int a_kmajor, int b_kmajor, int in_dtype, int out_dtype,
             int epilogue, float alpha, int accumulate,
-            float p_drop, uint64_t seed, void* stream);
+            float p_drop, uint64_t seed, float* colsum_out, float* colsum_ws, void* stream);
 
 /* Grouped weight gradients: for i in [0, count), count <= 8:
  *     C_i[M_i, N_i] (fp32) += sum_k A_i[k, m] * B_i[k, n]        (dW = dY^T X; both operands stored [K_i rows][features])

@@ -51,7 +51,7 @@ class FakeOps:
         pass
 
     def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
-             out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0):
+             out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0, colsum=None, ws=None):
         self.calls.append(("gemm", M, N, K, a_kmajor, b_kmajor, epilogue))
         a = (v2(A, M, K, lda) if a_kmajor else v2(A, K, M, lda).t()).float()
         b = (v2(B, N, K, ldb) if b_kmajor else v2(B, K, N, ldb).t()).float()
@@ -77,6 +77,8 @@ class FakeOps:
             c.add_(acc)
         else:
             c.copy_(acc)
+        if colsum is not None:
+            torch.as_strided(colsum, (N,), (1,)).add_(c.float().sum(0))
 
     def gemm_wgrad_group(self, problems):
         for (A, B, C, M, N, K, lda, ldb, ldc) in problems:

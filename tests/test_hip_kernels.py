@@ -145,6 +145,27 @@ def test_gemm_pingpong_pipeline_depths(M, N, K, layout):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N", [(512, 256), (256, 512), (200, 136)])
+def test_gemm_fused_column_sums(M, N, dtype, pingpong):
+    """bias gradient from the dX epilogue (interior aligned tiles: fused; ragged: separate pass) == sum of C as stored"""
+    if dtype == torch.float32 and pingpong == 2:
+        pytest.skip("kernel switch only affects the bf16 MFMA kernels")
+    g = torch.Generator().manual_seed(M + N)
+    K = 192
+    A, B = rnd(g, M, K, dtype=dtype, s=0.3), rnd(g, K, N, dtype=dtype, s=0.3)
+    aux = rnd(g, M, N, dtype=dtype)
+    ops = hip(dtype)
+    C = torch.zeros(M, N, dtype=dtype, device="cuda")
+    out = torch.full((N,), 2.0, device="cuda")
+    ws = torch.zeros(ops.workspace_floats(N), device="cuda")
+    ops.gemm(A.cuda(), B.cuda(), C, None, None, aux.cuda(), M, N, K, K, N, N, ldx=N, a_kmajor=1, b_kmajor=0, epilogue=3,
+             colsum=out, ws=ws)
+    torch.cuda.synchronize()
+    ref = 2.0 + C.float().sum(0)
+    assert (out - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), (out - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows", [(2048, 2048, 2048), (1536, 640, 1536)])
 def test_gemm_wgrad_group(rows, dtype):
     """three weight gradients of different shapes (and contraction lengths) accumulated by one grouped launch"""

@@ -150,5 +150,7 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
 }
 
 extern int g_use_tr_read;   // set by xl_set_lds_transpose_read
+// out[n] += sum_g ws[g*N + n] (second stage of the two-stage column reductions; rowops.hip)
+void launch_colsum_reduce(const float* ws, int G, int N, float* out, hipStream_t st);
 
 }  // namespace xl

@@ -252,7 +252,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
                        int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldx,
                        int a_kmajor, int b_kmajor, int in_dtype, int out_dtype,
                        int epilogue, float alpha, int accumulate,
-                       float p_drop, uint64_t seed, void* stream) {
+                       float p_drop, uint64_t seed, float* colsum_out, float* colsum_ws, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     XL_CHECK_ARG(M > 0 && N > 0 && K > 0, XL_ERR_BAD_SHAPE, "xl_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     XL_CHECK_ARG(in_dtype == XL_F32 || in_dtype == XL_BF16, XL_ERR_BAD_DTYPE, "xl_gemm: bad in_dtype %d", in_dtype);
@@ -275,6 +275,10 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.epilogue = epilogue; p.out_f32 = (out_dtype == XL_F32); p.alpha = alpha;
     p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.ablate = ablate;
     p.trace = g_gemm_trace;
+    p.colsum_ws = nullptr;
+    if (colsum_out != nullptr)
+        XL_CHECK_ARG(colsum_ws != nullptr && !accumulate && (long)((M + 63) / 64) * N <= xl_workspace_floats(N), XL_ERR_BAD_ARG,
+                     "xl_gemm: colsum_out needs a workspace (xl_workspace_floats), accumulate = 0 and M <= 262144");
 
     const bool mfma_ok = in_dtype == XL_BF16 && (lda % 8 == 0) && (ldb % 8 == 0) && aligned16(A) && aligned16(B);
     const bool may_split = mfma_ok && out_dtype == XL_F32 && epilogue == XL_EPI_NONE;
@@ -321,6 +325,10 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // fast (templated) epilogue: aligned rows, a kind that has one, plain stores
     int epik = -1;
     if (p.vec_epi && !p.atomic_out && epilogue != XL_EPI_TANH && (bias == nullptr || aligned16(bias))) epik = epilogue;
+    // column sums of C ride in the fast epilogue when every tile takes it; otherwise a separate pass over C follows
+    const bool colsum_fused = colsum_out != nullptr && mfma_ok && epik >= 0 && splitk == 1 && a_kmajor && M % tile == 0 &&
+                              N % tile == 0;
+    if (colsum_fused) p.colsum_ws = colsum_ws;
     if (use_pp) {
         hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, nblk, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -335,6 +343,12 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         hipLaunchKernelGGL((gemm_generic_kernel<float>), dim3(nblk), dim3(256), 0, st, p, a_kmajor, b_kmajor);
     }
     XL_CHECK_LAUNCH();
+    if (colsum_fused) {
+        launch_colsum_reduce(colsum_ws, M / 64, N, colsum_out, st);
+        XL_CHECK_LAUNCH();
+    } else if (colsum_out != nullptr) {
+        return xl_colsum(C, colsum_out, M, N, ldc, colsum_ws, out_dtype, stream);
+    }
     return XL_OK;
 }
 
@@ -364,7 +378,7 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
     if (!grouped) {          // one launch per problem (fp32 parity path, operands the ping-pong kernel does not take, tiny groups)
         for (int i = 0; i < count; ++i) {
             int rc = xl_gemm(A[i], B[i], C[i], nullptr, nullptr, nullptr, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], 0, 0,
-                             0, 0, dtype, XL_F32, XL_EPI_NONE, 1.0f, 1, 0.f, 0, stream);
+                             0, 0, dtype, XL_F32, XL_EPI_NONE, 1.0f, 1, 0.f, 0, nullptr, nullptr, stream);
             if (rc != XL_OK) return rc;
         }
         return XL_OK;

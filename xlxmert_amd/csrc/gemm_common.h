@@ -16,6 +16,7 @@ struct GemmParams {
     uint64_t seed;
     int tiles_m, tiles_n, ablate;
     unsigned long long* trace;        // debug: per-block timestamps (xl_gemm_trace), normally null
+    float* colsum_ws;                 // fused column sums of C: one partial slab [N] per 64 output rows (fast epilogue only)
 };
 
 // ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)
@@ -296,6 +297,7 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
         for (int e = 0; e < 8; ++e) bv[e] = 0.f;
     }
     const bool drop = p.p_drop > 0.0f;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
         const int row = ps * 8 + rr;
@@ -327,10 +329,33 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
             float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
             *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += v[e];
         } else {
-            stvec(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, v);
+            uint4 t;
+            t.x = pack2bf(v[0], v[1]); t.y = pack2bf(v[2], v[3]); t.z = pack2bf(v[4], v[5]); t.w = pack2bf(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = t;
+            if (p.colsum_ws != nullptr) {           // sums of the values as stored (what a separate pass over C would read)
+                float sv[8];
+                unpack8(t, sv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] += sv[e];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);      // one row group at a time: interleaving all eight spills
+    }
+    if (p.colsum_ws != nullptr) {               // 64-row column sums of this quad -> its slab of the workspace
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs[e] += __shfl_xor(cs[e], 8, 64);
+            cs[e] += __shfl_xor(cs[e], 16, 64);
+            cs[e] += __shfl_xor(cs[e], 32, 64);
+        }
+        if (rr == 0) {
+            float* w = p.colsum_ws + (size_t)(mq >> 6) * p.N + n;
+            *reinterpret_cast<float4*>(w) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            *reinterpret_cast<float4*>(w + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+        }
     }
 }
 

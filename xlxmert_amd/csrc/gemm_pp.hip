@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     p.M = pr.M; p.N = pr.N; p.K = pr.K; p.lda = pr.lda; p.ldb = pr.ldb; p.ldc = pr.ldc; p.ldr = 0; p.ldx = 0;
     p.epilogue = XL_EPI_NONE; p.out_f32 = 1; p.atomic_out = 1; p.splitk = g.splitk; p.kper = pr.kper; p.vec_epi = 0;
     p.alpha = 1.0f; p.p_drop = 0.f; p.inv_keep = 1.f; p.seed = 0;
-    p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr;
+    p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr; p.colsum_ws = nullptr;
     if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
     const int tl = t - g.tile_start[i];
     pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, z);

@@ -635,6 +635,12 @@ static void launch_reduce(const float* ws, int G, int nvec, int N, ReduceOuts ou
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((nvec * N + 255) / 256, gy), dim3(256), 0, st, ws, G, nvec, N, outs);
 }
 
+void xl::launch_colsum_reduce(const float* ws, int G, int N, float* out, hipStream_t st) {
+    ReduceOuts o = {};
+    o.p[0] = out;
+    launch_reduce(ws, G, 1, N, o, st);
+}
+
 extern "C" int64_t xl_workspace_floats(int N) { return (int64_t)4096 * (N > 0 ? N : 1); }
 
 extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,

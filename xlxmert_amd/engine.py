@@ -125,8 +125,7 @@ class FFNBlock:
         e.wgrad_defer(dzm, self.h, self.gw2, d, dff, M, d, dff, dff)
         dpre = e.tmp("dpre", M, dff)
         ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
-                 epilogue=EPI_DGELU)
-        ops.colsum(dpre, self.gb1, M, dff, dff, ws=e.ws)
+                 epilogue=EPI_DGELU, colsum=self.gb1, ws=e.ws)       # d(b1) = column sums of dpre, in the same epilogue
         e.wgrad_defer(dpre, self.x, self.gw1, dff, d, M, dff, d, d)
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)

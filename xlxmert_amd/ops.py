@@ -53,11 +53,12 @@ class HipOps:
 
     # -- dense contractions
     def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
-             out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0):
+             out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0, colsum=None, ws=None):
+        """colsum: optional fp32 [N] that receives += the column sums of C (bias gradient), with workspace `ws`."""
         self.lib.call("xl_gemm", self._p(A), self._p(B), self._p(C), self._p(bias), self._p(residual), self._p(aux),
                       M, N, K, lda, ldb, ldc, ldr, ldx, int(a_kmajor), int(b_kmajor), self.dt,
                       XL_F32 if out_f32 else self.dt, epilogue, float(alpha), int(accumulate), float(p_drop),
-                      int(seed), self._stream())
+                      int(seed), self._p(colsum), self._p(ws if colsum is not None else None), self._stream())
 
     def gemm_wgrad_group(self, problems):
         """problems: list of (dY [K, M], X [K, N], dW [M, N] fp32, M, N, K, lda, ldb, ldc): dW += dY^T X, one launch."""
