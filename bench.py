@@ -93,13 +93,14 @@ class GemmTimer:
             s.record()
             self.orig(A, B, C, bias, residual, aux, M, N, K, *a, **kw)
             e.record()
-            self.rec.append((s, e, 2.0 * M * N * K))
+            self.rec.append((s, e, 2.0 * M * N * K, (M, N, K, kw.get("a_kmajor", 1), kw.get("b_kmajor", 1), kw.get("epilogue", 0))))
         def timed_group(problems):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             self.orig_group(problems)
             e.record()
-            self.rec.append((s, e, sum(2.0 * pr[3] * pr[4] * pr[5] for pr in problems)))
+            self.rec.append((s, e, sum(2.0 * pr[3] * pr[4] * pr[5] for pr in problems),
+                             ("group", len(problems), problems[0][5], sum(pr[3] * pr[4] for pr in problems) // 65536, 0, 0)))
         self.ops.gemm = timed
         self.ops.gemm_wgrad_group = timed_group
         return self
@@ -108,8 +109,8 @@ class GemmTimer:
         self.ops.gemm = self.orig
         self.ops.gemm_wgrad_group = self.orig_group
         torch.cuda.synchronize()
-        self.total_ms = sum(s.elapsed_time(e) for s, e, _ in self.rec)
-        self.flops = sum(f for _, _, f in self.rec)
+        self.total_ms = sum(r[0].elapsed_time(r[1]) for r in self.rec)
+        self.flops = sum(r[2] for r in self.rec)
         self.launches = len(self.rec)
 
 
@@ -123,6 +124,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-dropout", action="store_true", help="eval-parity mode (the reference trains with p=0.1)")
     ap.add_argument("--single-stream", action="store_true", help="no language/visual stream overlap (profiling)")
+    ap.add_argument("--gemm-table", action="store_true", help="print the instrumented step's GEMM time by shape (stderr)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,6 +183,12 @@ def main():
         traffic = round(json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic.json")))["bytes_per_launch"])
     except Exception:
         pass
+    if rank == 0 and args.gemm_table:
+        agg = {}
+        for s_, e_, f_, key in gt.rec:
+            a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += s_.elapsed_time(e_); a[2] += f_
+        for key, (c, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {str(key):44s} x{c:3d} {t:8.3f} ms  {t / c * 1e3:8.1f} us  {f / t / 1e9:7.1f} TF/s", file=sys.stderr)
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt

@@ -344,7 +344,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     }
     XL_CHECK_LAUNCH();
     if (colsum_fused) {
-        launch_colsum_reduce(colsum_ws, M / 64, N, colsum_out, st);
+        launch_colsum_reduce(colsum_ws, M / (use_pp ? 128 : 64), N, colsum_out, st);
         XL_CHECK_LAUNCH();
     } else if (colsum_out != nullptr) {
         return xl_colsum(C, colsum_out, M, N, ldc, colsum_ws, out_dtype, stream);

@@ -16,7 +16,7 @@ struct GemmParams {
     uint64_t seed;
     int tiles_m, tiles_n, ablate;
     unsigned long long* trace;        // debug: per-block timestamps (xl_gemm_trace), normally null
-    float* colsum_ws;                 // fused column sums of C: one partial slab [N] per 64 output rows (fast epilogue only)
+    float* colsum_ws;                 // fused column sums of C: one partial slab [N] per wave tile (64 / 128 rows; fast epilogue only)
 };
 
 // ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)
@@ -283,9 +283,29 @@ __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
 }
 
 // rows of a quad already in LDS (quad_to_lds) -> epilogue math -> 16-byte stores
+// Column sums of a wave's output rows, held as 8 per-lane partials (columns (lane&7)*8 + e over the rows this lane
+// stored): halving butterfly over the three row bits of the lane id (v_permlane32_swap, v_permlane16_swap, one
+// bpermute) -> every lane ends up with ONE finished column, written to the wave's slab of the workspace.
+__device__ __forceinline__ void swap_add(float& keep_lo, float& keep_hi, bool rows16) {
+    const uint32_t a = __float_as_uint(keep_lo), b = __float_as_uint(keep_hi);
+    const auto r = rows16 ? __builtin_amdgcn_permlane16_swap(a, b, false, false) : __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    keep_lo = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void colsum_flush(const GemmParams& p, int lane, int slab, int nq, float (&cs)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) swap_add(cs[e], cs[e + 4], false);      // lane bit 5: low half keeps columns 0-3, high 4-7
+#pragma unroll
+    for (int e = 0; e < 2; ++e) swap_add(cs[e], cs[e + 2], true);       // lane bit 4
+    const float x0 = __shfl_xor(cs[0], 8, 64), x1 = __shfl_xor(cs[1], 8, 64);
+    const int b3 = (lane >> 3) & 1;
+    const float tot = b3 ? cs[1] + x1 : cs[0] + x0;                     // lane bit 3
+    const int col = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + b3;
+    p.colsum_ws[(size_t)slab * p.N + nq + (lane & 7) * 8 + col] = tot;
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const float* wbuf, int lane, bool first, int mq, int nq,
-                                                   const QuadOperand& op) {
+                                                   const QuadOperand& op, float (&cs)[8]) {
     const int c8 = lane & 7, rr = lane >> 3;
     const int n = nq + c8 * 8;
     float bv[8];
@@ -297,7 +317,6 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
         for (int e = 0; e < 8; ++e) bv[e] = 0.f;
     }
     const bool drop = p.p_drop > 0.0f;
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
         const int row = ps * 8 + rr;
@@ -344,27 +363,16 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
         }
         __builtin_amdgcn_sched_barrier(0);      // one row group at a time: interleaving all eight spills
     }
-    if (p.colsum_ws != nullptr) {               // 64-row column sums of this quad -> its slab of the workspace
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            cs[e] += __shfl_xor(cs[e], 8, 64);
-            cs[e] += __shfl_xor(cs[e], 16, 64);
-            cs[e] += __shfl_xor(cs[e], 32, 64);
-        }
-        if (rr == 0) {
-            float* w = p.colsum_ws + (size_t)(mq >> 6) * p.N + n;
-            *reinterpret_cast<float4*>(w) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-            *reinterpret_cast<float4*>(w + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
-        }
-    }
 }
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_quad_fast(const GemmParams& p, float* wbuf, int lane, bool first, int mq, int nq,
                                                    const QuadOperand& op, const f32x16_t& a00, const f32x16_t& a01,
                                                    const f32x16_t& a10, const f32x16_t& a11) {
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     quad_to_lds(wbuf, lane, a00, a01, a10, a11);
-    epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op);
+    epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op, cs);
+    if (p.colsum_ws != nullptr) colsum_flush(p, lane, mq >> 6, nq, cs);          // one slab per 64 rows
 }
 
 struct GroupProblem {

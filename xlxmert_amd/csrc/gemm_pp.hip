@@ -207,11 +207,13 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
             __builtin_amdgcn_sched_barrier(0);
             quad_operand_load<EPIK>(p, lane, mw + 64, nw, op1);
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0);
+            float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs);
             __builtin_amdgcn_sched_barrier(0);
             quad_to_lds(wbuf, lane, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1);
+            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1, cs);
+            if (p.colsum_ws != nullptr) colsum_flush(p, lane, mw >> 7, nw, cs);      // one slab per 128 rows
             if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
             return;
         }
