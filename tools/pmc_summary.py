@@ -28,7 +28,7 @@ def main(path, top=14):
     g = {c: sum(a.get(c, 0) for k, a in agg.items() if "gemm_bf16" in k) for c in counters}
     ns = sum(a["ns"] for k, a in agg.items() if "gemm_bf16" in k)
     calls = sum(a["calls"] for k, a in agg.items() if "gemm_bf16" in k)
-    print(f"\nALL gemm_bf16_mfma_kernel launches: calls {calls}, total {ns / 1e6:.3f} ms")
+    print(f"\nALL gemm_bf16_* launches (ping-pong, grouped, 128x128): calls {calls}, total {ns / 1e6:.3f} ms")
     for c in counters:
         print(f"  {c}: {g[c]:.6g}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in g and "GRBM_GUI_ACTIVE" in g and g["GRBM_GUI_ACTIVE"]:

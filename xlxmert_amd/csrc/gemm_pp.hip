@@ -121,7 +121,6 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
                     acc[ah * 2 + i][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(v8bf16_t, fa[i][s]), __builtin_bit_cast(v8bf16_t, fb[bh][s]), acc[ah * 2 + i][bh], 0, 0, 0);
     };
-    const bool prio = !(p.ablate & 32);
     // Two phases per K tile, 16 MFMAs each: P0 = rows A0 x (B0 | B1), P1 = rows A1 x (B1 | B0).
     //   P0(t) reads B0, B1, A0 of tile t and issues A1(t+1);  P1(t) reads A1 of tile t and issues A0, B0, B1 of tile t+2.
     // Every half-tile is issued two phases before the phase that waits for it (vmcnt) and three before its first read;
@@ -146,7 +145,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vmcnt<decltype(WAIT)::value>();
         hard_barrier();
-        if (prio) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         if (!(p.ablate & 8)) {
             if constexpr (x == 0) mma2(ic<0>{});
             else mma2(ic<1>{});
@@ -156,7 +155,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) asm volatile("" ::"v"(fa[i][s2]), "v"(fb[0][s2]), "v"(fb[1][s2]));
         }
-        if (prio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         hard_barrier();
     };
 
