@@ -146,6 +146,16 @@ int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy, float p_d
 /* dx = dy * gelu_erf'(pre), n elements (head transform backward, HF:582-586) */
 int xl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
 
+/* dx = dy * (1 - y*y), n elements: backward of LxmertPooler's tanh (HF:566-572) given its output y */
+int xl_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+
+/* BCEWithLogitsLoss(reduction='mean') of the VQA/GQA fine-tune step (ref tasks/vqa.py:73,187; gqa.py:70,150) over fp32
+ * logits [M,N] and soft targets [M,N], plus its gradient:  loss[0] += mean(max(x,0) - x t + log(1+exp(-|x|)));
+ * dlogits (element type `dtype`, row stride ld_dlogits >= N, pad columns written as 0; NULL = loss only)
+ *   = (sigmoid(x) - t) / (M N).  `loss` must be zeroed by the caller. */
+int xl_bce_logits_fwd_bwd(const float* logits, const float* targets, void* dlogits, float* loss,
+                          int M, int N, int ld_logits, int ld_targets, int ld_dlogits, int dtype, void* stream);
+
 /* ---------------------------------------------------------------- attention core (HF:247-263)
  * per (b,h): O = softmax(Q K^T * scale, keys with key_mask==0 excluded) V ; nq,nk <= 64.
  * q/k/v/o are [B, n, H*dh]-shaped views with row strides ldq/ldk/ldv/ldo (elements); head h

@@ -188,6 +188,49 @@ def gen_blocks(seed=77):
     print("blocks done")
 
 
+def gen_vqa(name, cfg, num_answers, seed, B, L, grid):
+    """the reference's VQAModel (tasks/vqa_model.py) + BCEWithLogitsLoss (tasks/vqa.py:73,187).
+    The published class cannot be constructed (`self._init_weights(self.logit_fc)`: no such attribute -- one more
+    defect of the App. A kind); the shim supplies a no-op `logit_fc` class attribute and nothing else."""
+    from tasks.vqa_model import VQAModel
+
+    class VShim(VQAModel):
+        logit_fc = torch.nn.Identity()
+
+        def init_weights(self):
+            if not getattr(self, "_in_post", False):
+                self._in_post = True
+                self.post_init()
+            else:
+                PreTrainedModel.init_weights(self)
+
+    hf = LxmertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                      num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                      max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                      l_layers=cfg.l_layers, x_layers=cfg.x_layers, r_layers=cfg.r_layers,
+                      visual_feat_dim=cfg.visual_feat_dim, visual_pos_dim=cfg.visual_pos_dim)
+    hf.num_answers = num_answers                 # the ctor reads config.num_answers before anyone sets it (defect)
+    m = VShim(hf, num_answers)
+    sd = O.make_vqa_state_dict(cfg, num_answers, seed)
+    res = m.load_state_dict({k: v for k, v in sd.items() if k.startswith("bert.") or k.startswith("answer_head.")}, strict=True)
+    m.eval()
+    inp = O.make_vqa_inputs(cfg, num_answers, seed + 1, B, L, grid)
+    out = m(input_ids=inp["input_ids"], visual_feats=inp["visual_feats"], visual_pos=inp["visual_pos"],
+            attention_mask=inp["input_ids"] > 0)
+    logit = out["logit"]
+    loss = torch.nn.BCEWithLogitsLoss()(logit, inp["targets"])
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    d = dict(seed=np.array(seed), num_answers=np.array(num_answers), **cfg_fields(cfg), **np_inputs(inp))
+    d.update(logit=logit.detach().numpy(), loss=loss.detach().numpy())
+    d["grad_names"] = np.array(sorted(grads.keys()))
+    for k, g in grads.items():
+        d["grad:" + k] = g.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "loss", float(loss), "n_grads", len(grads))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     tiny = dict(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
@@ -197,3 +240,4 @@ if __name__ == "__main__":
     gen_tiny("tiny_955", O.OracleConfig(l_layers=9, x_layers=5, r_layers=5, **tiny), seed=4321, B=2, L=8, grid=4,
              store_grads=False)
     gen_config1()
+    gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)

@@ -212,6 +212,64 @@ def lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=No
     return lang, vis, pooled
 
 
+# --------------------------------------------------------------------------- VQA / GQA fine-tune head
+def visual_answer_head(sd, cfg, pooled, prefix="answer_head.logit_fc"):
+    """HF:602-614 LxmertVisualAnswerHead -- Linear(d, 2d) -> GeLU -> LayerNorm(2d, eps=1e-12) -> Linear(2d, num_answers)."""
+    h = F.gelu(_linear(sd, prefix + ".0", pooled))
+    h = _layer_norm(sd, prefix + ".2", h, 1e-12)
+    return _linear(sd, prefix + ".3", h)
+
+
+def vqa_forward(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=None, targets=None, token_type_ids=None):
+    """ref:x-lxmert/src/tasks/vqa_model.py:22-72 (logit = answer_head(pooled_output) on REAL grid features) and
+    ref:x-lxmert/src/tasks/vqa.py:166-187 (attention_mask = input_ids > 0; loss = BCEWithLogitsLoss()(logit, target))."""
+    if attention_mask is None:
+        attention_mask = input_ids > 0
+    lang, vis, pooled = lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask, token_type_ids)
+    logit = visual_answer_head(sd, cfg, pooled)
+    out = {"logit": logit, "pooled": pooled}
+    if targets is not None:
+        out["loss"] = F.binary_cross_entropy_with_logits(logit, targets)
+    return out
+
+
+def answer_head_shapes(cfg, num_answers):
+    d = cfg.hidden_size
+    p = "answer_head.logit_fc"
+    return [(p + ".0.weight", (2 * d, d)), (p + ".0.bias", (2 * d,)), (p + ".2.weight", (2 * d,)), (p + ".2.bias", (2 * d,)),
+            (p + ".3.weight", (num_answers, 2 * d)), (p + ".3.bias", (num_answers,))]
+
+
+def make_vqa_state_dict(cfg, num_answers, seed, perturb=True):
+    """encoder weights of make_state_dict(cfg, seed) + a deterministic answer head (same recipe, seed + 7)."""
+    sd = make_state_dict(cfg, seed, perturb)
+    rng = np.random.default_rng(seed + 7)
+    for name, shape in answer_head_shapes(cfg, num_answers):
+        if name.endswith(".2.weight"):
+            w = np.ones(shape, np.float32) + (0.1 * rng.standard_normal(shape, dtype=np.float32) if perturb else 0.0)
+        elif len(shape) == 1:
+            w = 0.05 * rng.standard_normal(shape, dtype=np.float32) if perturb else np.zeros(shape, np.float32)
+        else:
+            w = 0.02 * rng.standard_normal(shape, dtype=np.float32)
+        sd[name] = torch.from_numpy(np.asarray(w, np.float32))
+    return sd
+
+
+def make_vqa_inputs(cfg, num_answers, seed, B, L=20, grid=8):
+    """Synthetic VQA batch (ref vqa_data.py:225-262): real grid features relu(N(0,1)) [B,V,F], boxes, word ids with PAD = 0,
+    soft target scores in {0, .3, .6, .9, 1} on a few answers per question."""
+    base = make_inputs(cfg, seed, B, L, grid)
+    rng = np.random.default_rng(seed + 11)
+    V = grid * grid
+    feats = np.maximum(rng.standard_normal((B, V, cfg.visual_feat_dim), dtype=np.float32), 0.0)
+    tgt = np.zeros((B, num_answers), np.float32)
+    for b in range(B):
+        for a in rng.permutation(num_answers)[: int(rng.integers(1, 4))]:
+            tgt[b, a] = rng.choice(np.array([0.3, 0.6, 0.9, 1.0], np.float32))
+    return {"input_ids": base["input_ids"], "attention_mask": base["input_ids"] > 0, "visual_pos": base["visual_pos"],
+            "visual_feats": torch.from_numpy(feats), "targets": torch.from_numpy(tgt)}
+
+
 # --------------------------------------------------------------------------- head + losses
 def head_transform(sd, cfg, x, prefix="obj_predict_head.transform"):
     """HF:582-586 -- LN(gelu(dense(x)))."""

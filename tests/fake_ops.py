@@ -179,6 +179,18 @@ class FakeOps:
     def gelu_bwd(self, dy, pre, dx, n):
         dx.view(-1)[:n].copy_(dy.reshape(-1)[:n].float() * gelu_grad(pre.reshape(-1)[:n].float()))
 
+    def tanh_bwd(self, dy, y, dx, n):
+        yf = y.reshape(-1)[:n].float()
+        dx.view(-1)[:n].copy_(dy.reshape(-1)[:n].float() * (1.0 - yf * yf))
+
+    def bce_logits_fwd_bwd(self, logits, targets, dlogits, loss, M, N, ld_logits, ld_targets, ld_dlogits):
+        x, t = v2(logits, M, N, ld_logits).float(), v2(targets, M, N, ld_targets).float()
+        loss[0] += torch.nn.functional.binary_cross_entropy_with_logits(x, t)
+        if dlogits is not None:
+            d = v2(dlogits, M, ld_dlogits, ld_dlogits)
+            d.zero_()
+            d[:, :N].copy_((torch.sigmoid(x) - t) / float(M * N))
+
     @staticmethod
     def _heads(t, B, n, H, dh, ld):
         return torch.as_strided(t, (B, H, n, dh), (n * ld, dh, ld, 1))

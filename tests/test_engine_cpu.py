@@ -127,3 +127,44 @@ def test_dropout_backward_matches_directional_derivative():
     fd = (lp - lm) / (2 * eps)
     an = (gflat * u).sum().item()
     assert abs(fd - an) <= 5e-3 * max(1.0, abs(an)), (fd, an)
+
+
+def make_vqa_engine(g, ops, device="cpu", dtype=torch.float32):
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    A = int(g["num_answers"])
+    sd = O.make_vqa_state_dict(oc, A, int(g["seed"]))
+    inp = golden_inputs(g)
+    B, L = inp["input_ids"].shape
+    V = inp["visual_feats"].shape[1]
+    store = ParamStore(cfg, device, dtype, task="vqa", num_answers=A)
+    store.load_named(sd)
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=True)
+    eng.sync_compute_weights()
+    dev = torch.device(device)
+    eng.set_inputs(inp["input_ids"].to(dev), inp["attention_mask"].to(dev), None, inp["visual_pos"].to(dev),
+                   visual_feats=inp["visual_feats"].to(dev))
+    return eng, inp
+
+
+def test_vqa_step_vs_reference_fixture():
+    """engine sequencing of the VQA fine-tune step (answer head + pooler backward + full encoder backward
+    with d(language_output)) against the fixture generated by the reference's VQAModel."""
+    g = load_golden("vqa_tiny")
+    eng, inp = make_vqa_engine(g, FakeOps(torch.float32))
+    loss = eng.vqa_forward_backward(inp["targets"])
+    assert maxdiff(eng.answer.logit, g["logit"]) < 5e-5
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    names = [str(n) for n in g["grad_names"]]
+    for k in names:
+        ref = torch.from_numpy(g["grad:" + k])
+        got = eng.store.gview(k)
+        if "embeddings" in k and k.endswith("embeddings.weight"):
+            ref = ref.clone()
+            ref[0] = got[0]            # padding_idx = 0 rows get no gradient in the reference either (they are zero there)
+        assert maxdiff(got, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), k
+    used = {m.name for u in eng.store.units if u.used for m in u.members}
+    assert set(names) <= used and not any(n.startswith("obj_predict_head") or n == "mask_feat" for n in used)

@@ -488,3 +488,30 @@ def test_layernorm_bwd_fused_dropout(dtype):
     close(gpu2[5], cpu2[5], dtype, "dx")
     # the masked tensor itself is checked through its column sums here and element-wise by the training-mode engine test
     close(gpu2[8], cpu2[8], torch.float32, "dbias of the masked gradient", f32_tol=3e-5, bf16_tol=2e-2)
+
+
+# ---------------------------------------------------------------- VQA head pieces
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N", [(3, 37), (64, 3129), (5, 8)])
+def test_bce_with_logits_fwd_bwd(M, N, dtype):
+    g = torch.Generator().manual_seed(M * 100 + N)
+    x = rnd(g, M, N, s=3.0)
+    t = (torch.rand(M, N, generator=g) < 0.02).float() * torch.rand(M, N, generator=g)
+    Np = (N + 7) // 8 * 8
+    d = torch.full((M, Np), 9.0, dtype=dtype)
+    loss = torch.zeros(1)
+    cpu, gpu = run_both(dtype, "bce_logits_fwd_bwd", [x, t, d, loss, M, N, N, N, Np])
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(x.double(), t.double()).item()
+    assert abs(gpu[3].item() - ref) < 1e-5 * max(1.0, abs(ref))
+    close(gpu[2], cpu[2], dtype, "d(logits)", scale=1.0 / (M * N), bf16_tol=1e-2)
+    assert gpu[2][:, N:].abs().max().item() == 0 if Np > N else True
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_tanh_bwd(dtype):
+    g = torch.Generator().manual_seed(3)
+    n = 24 * 64
+    dy, y = rnd(g, n, dtype=dtype), torch.tanh(rnd(g, n)).to(dtype)
+    dx = torch.zeros(n, dtype=dtype)
+    cpu, gpu = run_both(dtype, "tanh_bwd", [dy, y, dx, n])
+    close(gpu[2], cpu[2], dtype, "tanh_bwd")

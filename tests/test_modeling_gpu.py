@@ -82,3 +82,36 @@ def test_lxmert_model_and_head_through_autograd():
         if k == "mask_feat":
             continue                      # visual_feats were built outside the module in this test
         assert maxdiff(params[k].grad.cpu(), g["grad:" + k]) < 1e-4, k
+
+
+def test_vqa_model_dropin_matches_reference_fixture():
+    """the nn.Module surface of tasks/vqa_model.py -- reference-layout state dict in, {'logit'} out, and the
+    reference's own training idiom (BCEWithLogitsLoss on the logit, .backward(), param.grad) gives the fixture's gradients."""
+    import lxmert_oracle as O
+    from _util import golden_cfg, golden_inputs, load_golden, maxdiff
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.modeling import VQAModel
+    g = load_golden("vqa_tiny")
+    oc = golden_cfg(g)
+    A = int(g["num_answers"])
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "l_layers", "x_layers",
+                                                      "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+    m = VQAModel(cfg, A, dtype=torch.float32).eval()
+    sd = O.make_vqa_state_dict(oc, A, int(g["seed"]))
+    missing, _ = m.load_state_dict({"module." + k: v for k, v in sd.items()})
+    assert not missing
+    inp = {k: v.cuda() for k, v in golden_inputs(g).items()}
+    m.zero_grad()
+    out = m(input_ids=inp["input_ids"], visual_feats=inp["visual_feats"], visual_pos=inp["visual_pos"],
+            attention_mask=inp["input_ids"] > 0)
+    assert maxdiff(out["logit"].cpu(), g["logit"]) < 1e-4
+    loss = torch.nn.BCEWithLogitsLoss()(out["logit"], inp["targets"])
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    for k in [str(n) for n in g["grad_names"]]:
+        ref = torch.from_numpy(g["grad:" + k])
+        assert maxdiff(params[k].grad.cpu(), ref) <= 1e-4 * max(1.0, ref.abs().max().item()), k
+    assert set(m.state_dict().keys()) >= {"answer_head.logit_fc.3.bias", "bert.pooler.dense.weight"}

@@ -70,6 +70,45 @@ def test_two_steps_match_closed_form():
     assert torch.equal(tr.store.view("bert.pooler.dense.weight"), sd["bert.pooler.dense.weight"])
 
 
+def test_vqa_two_steps_match_closed_form():
+    """VQA fine-tune step semantics (BCE loss, clip 1.0, 4.1.1-AdamW incl. the decayed `logit_fc.2.weight`
+    LayerNorm, linear schedule) against the oracle, two consecutive updates."""
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    B, L, grid, A = 3, 8, 4, 29
+    store = ParamStore(cfg, "cpu", torch.float32, task="vqa", num_answers=A)
+    sd = O.make_vqa_state_dict(oc, A, 5)
+    store.load_named(sd)
+    tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
+                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="vqa", num_answers=A)
+    names = [n for n in store.index if store.index[n] is not None and
+             any(m.name == n for u in store.units if u.used for m in u.members)]
+    ref = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in ref.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in ref.items()}
+    for t in (1, 2):
+        batch = O.make_vqa_inputs(oc, A, 200 + t, B, L, grid)
+        loss = tr.step(batch)
+        leaf = {k: v.clone().requires_grad_(True) for k, v in ref.items()}
+        out = O.vqa_forward(leaf, oc, batch["input_ids"], batch["visual_feats"], batch["visual_pos"], targets=batch["targets"])
+        assert abs(loss.item() - out["loss"].item()) < 3e-6
+        out["loss"].backward()
+        gn = sorted(k for k in leaf if leaf[k].grad is not None)
+        assert gn == sorted(names)          # the optimizer range == the reference's set of grad-carrying tensors
+        norm, clipped = O.clip_grad_norm([leaf[k].grad for k in gn], 1.0)
+        assert abs(tr.grad_norm() - norm.item()) < 1e-4 * max(1.0, norm.item())
+        lr = 1e-2 * linear_schedule(t - 1, 2, 10)
+        for k, g in zip(gn, clipped):
+            wd = 0.0 if ("bias" in k or "LayerNorm.weight" in k) else 0.01
+            ref[k], m[k], v2[k] = O.adamw_update(ref[k], g, m[k], v2[k], t, lr, weight_decay=wd)
+            ref[k] = ref[k].detach()
+        for k in gn:
+            d = (tr.store.view(k) - ref[k]).abs().max().item()
+            assert d < 2e-5, (t, k, d)
+    dead = "bert.encoder.x_layers.1.visn_inter.dense.weight"       # visual side of the last cross layer: never updated
+    assert torch.equal(tr.store.view(dead), sd[dead])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

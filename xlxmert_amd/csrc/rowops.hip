@@ -590,6 +590,52 @@ __global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pre
     if (lane == 0 && w != 0.f && loss_out) atomicAdd(loss_out, w * s / (float)F);
 }
 
+// ------------------------------------------------------------------ VQA answer head pieces
+// dx = dy * (1 - y^2): backward of the pooler's tanh (HF:566-572)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, int64_t nvec) {
+    constexpr int VEC = Elem<T>::VEC;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float a[VEC], b[VEC], o[VEC];
+        ldvec(dy + i * VEC, a);
+        ldvec(y + i * VEC, b);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = a[j] * (1.0f - b[j] * b[j]);
+        stvec(dx + i * VEC, o);
+    }
+}
+
+// BCEWithLogitsLoss(reduction='mean') over [M,N] fp32 logits and soft targets (ref tasks/vqa.py:73,187) + its gradient:
+//   loss += scale * sum( max(x,0) - x t + log(1 + exp(-|x|)) ),  dlogits = scale * (sigmoid(x) - t),  scale = 1/(M N).
+// One block per row slice; pad columns [N, ldd) of dlogits are written as zero (they feed a contraction over ldd).
+template <typename T>
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, const float* __restrict__ t, T* __restrict__ dx,
+                                                         float* loss, int M, int N, int ldx, int ldt, int ldd, float scale) {
+    __shared__ float red[WPB];
+    const int row = blockIdx.x;
+    float acc = 0.f;
+    for (int n = threadIdx.x; n < ldd; n += 256) {
+        float g = 0.f;
+        if (n < N) {
+            const float xv = x[(size_t)row * ldx + n], tv = t[(size_t)row * ldt + n];
+            const float e = __expf(-fabsf(xv));
+            acc += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
+            const float sg = xv >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+            g = (sg - tv) * scale;
+        }
+        if (dx != nullptr) Elem<T>::st(dx + (size_t)row * ldd + n, g);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) s += red[w];
+        atomicAdd(loss, s * scale);
+    }
+}
+
 }  // namespace xl
 
 using namespace xl;
@@ -829,6 +875,32 @@ extern "C" int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((dropout_kernel<T>), dim3((int)grid), dim3(256), 0, st, (const T*)x, (T*)y, M, N, ldx, ldy, p_drop,
                            1.0f / (1.0f - p_drop), seed););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream) {
+    XL_CHECK_ARG(dy && y && dx && n > 0 && n % vec_of(dtype) == 0, XL_ERR_BAD_SHAPE, "xl_tanh_bwd: n=%lld must be a multiple of %d",
+                 (long long)n, vec_of(dtype));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nvec = n / vec_of(dtype);
+    int64_t grid = (nvec + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((tanh_bwd_kernel<T>), dim3((int)grid), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, nvec););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_bce_logits_fwd_bwd(const float* logits, const float* targets, void* dlogits, float* loss,
+                                     int M, int N, int ld_logits, int ld_targets, int ld_dlogits, int dtype, void* stream) {
+    XL_CHECK_ARG(logits && targets && loss && M > 0 && N > 0 && ld_logits >= N && ld_targets >= N &&
+                 (dlogits == nullptr || ld_dlogits >= N), XL_ERR_BAD_ARG, "xl_bce_logits_fwd_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = 1.0f / ((float)M * (float)N);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((bce_logits_kernel<T>), dim3(M), dim3(256), 0, st, logits, targets, (T*)dlogits, loss, M, N,
+                           ld_logits, ld_targets, dlogits ? ld_dlogits : N, scale););
     XL_CHECK_LAUNCH();
     return XL_OK;
 }

@@ -208,6 +208,72 @@ class CrossAttBlock:
             ops.gemm(dqkv_l[:, d:], p.wqkv[d:], dX[:ML], None, None, None, ML, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
 
 
+class AnswerHead:
+    """LxmertVisualAnswerHead on pooled_output (HF:602-614: Linear(d,2d) -> GeLU -> LayerNorm(2d) -> Linear(2d,A)) with
+    BCEWithLogitsLoss on soft targets -- the VQA/GQA fine-tune step (ref tasks/vqa_model.py:22-72, vqa.py:166-187)."""
+
+    def __init__(self, eng, num_answers):
+        self.e, self.A = eng, num_answers
+        st, d, B = eng.store, eng.d, eng.B
+        p = "answer_head.logit_fc"
+        self.w0, self.gw0 = st.cview(p + ".0.weight"), st.gview(p + ".0.weight")
+        self.b0, self.gb0 = st.view(p + ".0.bias"), st.gview(p + ".0.bias")
+        self.g, self.gg = st.view(p + ".2.weight"), st.gview(p + ".2.weight")
+        self.b, self.gb = st.view(p + ".2.bias"), st.gview(p + ".2.bias")
+        self.w3, self.gw3 = st.cview(p + ".3.weight"), st.gview(p + ".3.weight")
+        self.b3, self.gb3 = st.view(p + ".3.bias"), st.gview(p + ".3.bias")
+        self.Ap = (num_answers + 7) // 8 * 8
+        self.pre, self.h, self.hn = eng.act(B, 2 * d), eng.act(B, 2 * d), eng.act(B, 2 * d)
+        self.mean, self.rstd = eng.f32(B), eng.f32(B)
+        self.logit = torch.zeros(B, num_answers, dtype=torch.float32, device=eng.dev)
+        self.targets = torch.zeros(B, num_answers, dtype=torch.float32, device=eng.dev)
+        self.dlogit = eng.act(B, self.Ap)
+        self.dhn, self.dh, self.dpre = eng.act(B, 2 * d), eng.act(B, 2 * d), eng.act(B, 2 * d)
+        self.dpooled, self.dz = eng.act(B, d), eng.act(B, d)
+        self.loss = eng.f32(1)
+
+    def fwd(self, pooled):
+        e, d, B, A = self.e, self.e.d, self.e.B, self.A
+        ops = e.ops
+        ops.gemm(pooled, self.w0, self.h, self.b0, None, self.pre, B, 2 * d, d, d, d, 2 * d, ldx=2 * d, epilogue=EPI_GELU)
+        ops.layernorm_fwd(self.h, self.g, self.b, self.hn, self.mean, self.rstd, B, 2 * d, 1e-12)
+        ops.gemm(self.hn, self.w3, self.logit, self.b3, None, None, B, A, 2 * d, 2 * d, 2 * d, A, out_f32=True)
+        return self.logit
+
+    def loss_fwd_bwd(self, want_grad=True):
+        B, A = self.e.B, self.A
+        self.loss.zero_()
+        self.e.ops.bce_logits_fwd_bwd(self.logit, self.targets, self.dlogit if want_grad else None, self.loss, B, A, A, A, self.Ap)
+        return self.loss
+
+    def bwd(self, pooled, cls_rows, d_cls):
+        """consumes dlogit; accumulates the head's and the pooler's parameter gradients; writes d(lang_output[:, 0]) into
+        d_cls (a [B, d] view with row stride L*d)."""
+        e, d, B, A, Ap = self.e, self.e.d, self.e.B, self.A, self.Ap
+        ops, st = e.ops, e.store
+        L = e.L
+        ops.colsum(self.dlogit, self.gb3_pad(), B, Ap, Ap, ws=e.ws)      # pad columns of dlogit are zero
+        e.wgrad_defer(self.dlogit, self.hn, self.gw3, A, 2 * d, B, Ap, 2 * d, 2 * d)
+        ops.gemm(self.dlogit, self.w3, self.dhn, None, None, None, B, 2 * d, A, Ap, 2 * d, 2 * d, a_kmajor=1, b_kmajor=0)
+        ops.layernorm_bwd(self.dhn, self.h, self.g, self.mean, self.rstd, self.dh, self.gg, self.gb, None, B, 2 * d, ws=e.ws)
+        ops.gelu_bwd(self.dh, self.pre, self.dpre, B * 2 * d)
+        ops.colsum(self.dpre, self.gb0, B, 2 * d, 2 * d, ws=e.ws)
+        e.wgrad_defer(self.dpre, pooled, self.gw0, 2 * d, d, B, 2 * d, d, d)
+        ops.gemm(self.dpre, self.w0, self.dpooled, None, None, None, B, d, 2 * d, 2 * d, d, d, a_kmajor=1, b_kmajor=0)
+        # LxmertPooler backward (HF:566-572): pooled = tanh(W_p cls + b_p)
+        ops.tanh_bwd(self.dpooled, pooled, self.dz, B * d)
+        ops.colsum(self.dz, st.gview("bert.pooler.dense.bias"), B, d, d, ws=e.ws)
+        e.wgrad_defer(self.dz, cls_rows, st.gview("bert.pooler.dense.weight"), d, d, B, d, L * d, d)
+        e.wgrad_flush()
+        ops.gemm(self.dz, st.cview("bert.pooler.dense.weight"), d_cls, None, None, None, B, d, d, d, d, L * d,
+                 a_kmajor=1, b_kmajor=0)
+
+    def gb3_pad(self):
+        """bias-gradient view padded to the 8-column granule of dlogit (the bias unit is padded in the flat buffer)."""
+        m = self.e.store.index["answer_head.logit_fc.3.bias"]
+        return self.e.store.grad[m.offset:m.offset + self.Ap]
+
+
 class Engine:
     """Static-shape forward/backward program.  `need_lang`: whether lang/pooled outputs of the last cross layer are
     consumed (False for the masked-visual-token step)."""
@@ -276,6 +342,10 @@ class Engine:
         self.cid = torch.zeros(B, V, dtype=torch.int64, device=self.dev)
         self.vmask = torch.zeros(B, V, dtype=torch.uint8, device=self.dev)
         self.labels = torch.full((B, V), -100, dtype=torch.int64, device=self.dev)
+        self.task = getattr(store, "task", "vis_mask")
+        self.answer = AnswerHead(self, store.num_answers) if self.task == "vqa" else None
+        if self.task == "vqa":
+            assert need_lang, "the VQA head reads pooled_output: build the engine with need_lang=True"
         # ---- head (ref lxrt/modeling.py:38-53) + losses
         h = "obj_predict_head"
         self.hd = {k: (st.cview(n) if c else st.view(n), st.gview(n)) for k, n, c in (
@@ -287,8 +357,9 @@ class Engine:
         self.t_pre, self.t_h, self.t_y = self.act(self.MV, d), self.act(self.MV, d), self.act(self.MV, d)
         self.t_mean, self.t_rstd = self.f32(self.MV), self.f32(self.MV)
         self.feat = self.act(self.MV, self.F)
-        self.logits = torch.zeros(self.MV, self.K, dtype=torch.float32, device=self.dev)
-        self.dlogits = self.act(self.MV, self.Kp)
+        n_head_rows = self.MV if self.task != "vqa" else 8          # the codebook head is not part of the VQA model
+        self.logits = torch.zeros(n_head_rows, self.K, dtype=torch.float32, device=self.dev)
+        self.dlogits = self.act(n_head_rows, self.Kp)
         self.dfeat = self.act(self.MV, self.F)
         self.counts, self.nmask = self.f32(4), self.f32(B)
         self.losses = self.f32(4)             # [obj_loss, feat_loss, -, -]
@@ -526,6 +597,27 @@ class Engine:
             ops.featloss_fwd_bwd(self.feat, self.store.centroids_c, self.cid, self.vmask, self.nmask,
                                  self.dfeat if want_grad else None, self.losses[1:], self.B, self.V, F, 1.0)
         return self.losses
+
+    def vqa_forward(self):
+        """VQAModel.forward (ref tasks/vqa_model.py:22-72): real grid features -> encoder -> pooled_output -> answer head."""
+        self.encoder_forward(want_pooled=True)
+        return self.answer.fwd(self.pooled)
+
+    def vqa_forward_backward(self, targets):
+        """one VQA/GQA fine-tune forward + backward (ref tasks/vqa.py:166-189): BCEWithLogitsLoss(logit, target).backward().
+        Gradients land in store.grad; returns the device loss buffer [1]."""
+        ans = self.answer
+        ans.targets.copy_(targets, non_blocking=True)
+        self.vqa_forward()
+        self.zero_accumulated_grads()
+        loss = ans.loss_fwd_bwd(True)
+        GA = self.GA
+        GA.zero_()                                   # only the [CLS] rows of the language output carry gradient
+        cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
+        ans.bwd(self.pooled, cls_rows, GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
+        self._ready("answer_head.")
+        self.encoder_backward(True)
+        return loss
 
     def predict_codes(self):
         """head -> softmax -> max over the codebook (ref tasks/imggen_model.py:229-235): (max prob, argmax) per row."""

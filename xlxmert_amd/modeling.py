@@ -308,3 +308,90 @@ class XLxmertForPretraining(nn.Module):
             self.bert._geom = key
         self.bert._engine.sync_compute_weights()
         return self.bert._engine
+
+
+# ---------------------------------------------------------------------------------------------- VQA / GQA
+class _VqaFn(torch.autograd.Function):
+    """VQAModel.forward as one engine forward; backward takes d(logit) from whatever loss the caller applied
+    (BCEWithLogitsLoss in the reference, tasks/vqa.py:187) and runs answer head + pooler + encoder backward."""
+
+    @staticmethod
+    def forward(ctx, model, anchor):
+        eng = model.bert._engine
+        logit = eng.vqa_forward()
+        ctx.model = model
+        return logit.clone()
+
+    @staticmethod
+    def backward(ctx, d_logit):
+        eng = ctx.model.bert._engine
+        ans = eng.answer
+        ans.dlogit.zero_()
+        ans.dlogit[:, :ans.A].copy_(d_logit)
+        eng.GA.zero_()
+        cls_rows = eng.lang_final.view(eng.B, eng.L * eng.d)[:, :eng.d]
+        ans.bwd(eng.pooled, cls_rows, eng.GA[:eng.ML].view(eng.B, eng.L * eng.d)[:, :eng.d])
+        eng.encoder_backward(True)            # gradients accumulate into the flat buffer: call model.zero_grad() per step
+        return None, None
+
+
+class LxmertVisualAnswerHead(_Named):
+    """HF:602-614; parameters `logit_fc.{0,2,3}.{weight,bias}` are views of the flat parameter buffer."""
+
+    def __init__(self, store):
+        super().__init__()
+        self._bind(store, "answer_head", [n for n in store.names() if n.startswith("answer_head.")])
+
+
+class VQAModel(nn.Module):
+    """ref tasks/vqa_model.py:7-72 (also the GQA model, tasks/gqa_model.py): `.bert` + `.answer_head`, forward returns
+    {'logit': [B, num_answers] fp32}.  Unlike the published class this one can be constructed (its ctor reads
+    `config.num_answers` before setting it and calls `_init_weights` on a non-existent attribute)."""
+
+    def __init__(self, config: XLxmertConfig, num_answers, num_clusters=-1, device=None, dtype=torch.bfloat16):
+        super().__init__()
+        self.config, self.num_answers = config, num_answers
+        dev = torch.device(device if device is not None else "cuda")
+        self._store = ParamStore(config, dev, dtype, task="vqa", num_answers=num_answers)
+        self.bert = LxmertModel(config, store=self._store, device=dev)
+        self.answer_head = LxmertVisualAnswerHead(self._store)
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        from .trainer import init_reference_weights
+        init_reference_weights(self._store, seed=0)
+
+    def zero_grad(self, set_to_none=False):
+        self._store.grad.zero_()
+        for name, p_ in self.named_parameters():
+            if p_.grad is None and name in self._store.index:
+                p_.grad = self._store.gview(name)
+
+    def state_dict(self, *args, prefix="", **kwargs):
+        keep = ("bert.", "answer_head.")
+        return OrderedDict((prefix + k, v.detach()) for k, v in self._store.named_state().items() if k.startswith(keep))
+
+    def load_state_dict(self, state_dict, strict=False):
+        """reference layout, with or without the DDP `module.` prefix; a pretraining checkpoint (no answer head: the
+        reference's load_lxmert_qa path, tasks/vqa.py:55-62) loads the encoder and leaves the head at its init."""
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        missing = self._store.load_named(sd, strict=False)
+        missing = [k for k in missing if k.startswith(("bert.", "answer_head."))]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:8]}...")
+        return missing, [k for k in sd if k not in self._store.index]
+
+    def forward(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None, visual_attention_mask=None,
+                token_type_ids=None, inputs_embeds=None, return_dict=True):
+        if visual_attention_mask is not None or inputs_embeds is not None:
+            raise NotImplementedError("visual_attention_mask / inputs_embeds are None in every reference caller")
+        B, L = input_ids.shape
+        V = visual_feats.shape[1]
+        key = (B, L, V, self.training, "vqa")
+        if self.bert._geom != key:
+            self.bert._engine = Engine(self.config, self._store, self.bert._ops, B, L, V, need_lang=True,
+                                       train_dropout=self.training)
+            self.bert._geom = key
+        eng = self.bert._engine
+        eng.sync_compute_weights()
+        eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats)
+        logit = _VqaFn.apply(self, self._anchor) if torch.is_grad_enabled() else eng.vqa_forward().clone()
+        return {"logit": logit}

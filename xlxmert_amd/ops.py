@@ -124,6 +124,13 @@ class HipOps:
     def gelu_bwd(self, dy, pre, dx, n):
         self.lib.call("xl_gelu_bwd", self._p(dy), self._p(pre), self._p(dx), n, self.dt, self._stream())
 
+    def tanh_bwd(self, dy, y, dx, n):
+        self.lib.call("xl_tanh_bwd", self._p(dy), self._p(y), self._p(dx), n, self.dt, self._stream())
+
+    def bce_logits_fwd_bwd(self, logits, targets, dlogits, loss, M, N, ld_logits, ld_targets, ld_dlogits):
+        self.lib.call("xl_bce_logits_fwd_bwd", self._p(logits), self._p(targets), self._p(dlogits), self._p(loss), M, N,
+                      ld_logits, ld_targets, ld_dlogits, self.dt, self._stream())
+
     # -- attention core
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
         self.lib.call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),

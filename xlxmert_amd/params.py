@@ -45,13 +45,17 @@ def _numel(shape):
 
 
 def _decays(name):
-    """ref lxmert_pretrain.py:125-135: no_decay = ["bias", "LayerNorm.weight"] (substring match)."""
+    """ref lxmert_pretrain.py:125-135: no_decay = ["bias", "LayerNorm.weight"] (substring match; so the answer head's
+    LayerNorm, called `logit_fc.2.weight`, DOES decay -- reproduced)."""
     return not ("bias" in name or "LayerNorm.weight" in name)
 
 
-def build_units(cfg, task="vis_mask"):
+def build_units(cfg, task="vis_mask", num_answers=0):
+    """task: "vis_mask" (masked-visual-token pretraining step) or "vqa" (VQA/GQA fine-tune: real features in, pooled output
+    -> LxmertVisualAnswerHead, ref tasks/vqa_model.py:7-72; the codebook head and mask_feat are not part of that model)."""
     d, dff, F, P = cfg.hidden_size, cfg.intermediate_size, cfg.visual_feat_dim, cfg.visual_pos_dim
     units = []
+    pretrain = task != "vqa"
 
     def U(region, used, *members):
         units.append(Unit([Member(n, tuple(s)) for n, s in members], region, used))
@@ -72,7 +76,7 @@ def build_units(cfg, task="vis_mask"):
         U("vec", used, (f"{po}.LayerNorm.weight", (d,)))
         U("vec", used, (f"{po}.LayerNorm.bias", (d,)))
 
-    U("vec", True, ("mask_feat", (F,)))
+    U("vec", pretrain, ("mask_feat", (F,)))
     e = "bert.embeddings"
     U("vec", True, (f"{e}.word_embeddings.weight", (cfg.vocab_size, d)))
     U("vec", True, (f"{e}.position_embeddings.weight", (cfg.max_position_embeddings, d)))
@@ -97,28 +101,39 @@ def build_units(cfg, task="vis_mask"):
         p = f"bert.encoder.x_layers.{i}"
         # vis_mask never reads the language output of the LAST cross layer
         lang_used = not (task == "vis_mask" and i == cfg.x_layers - 1)
+        # ... and the VQA step never reads the VISUAL output of the last cross layer (only pooled_output): its visual
+        # self-attention / FFN get no gradient in the reference, so the optimizer must not touch them
+        vis_used = not (task == "vqa" and i == cfg.x_layers - 1)
         att(p + ".visual_attention", "att")
         att(p + ".lang_self_att", "self", lang_used)
-        att(p + ".visn_self_att", "self")
+        att(p + ".visn_self_att", "self", vis_used)
         ffn(p + ".lang_inter", p + ".lang_output", lang_used)
-        ffn(p + ".visn_inter", p + ".visn_output")
+        ffn(p + ".visn_inter", p + ".visn_output", vis_used)
     pooled_used = task != "vis_mask"
     U("mat", pooled_used, ("bert.pooler.dense.weight", (d, d)))
     U("vec", pooled_used, ("bert.pooler.dense.bias", (d,)))
     h = "obj_predict_head"
-    U("mat", True, (f"{h}.transform.dense.weight", (d, d)))
-    U("vec", True, (f"{h}.transform.dense.bias", (d,)))
-    U("vec", True, (f"{h}.transform.LayerNorm.weight", (d,)))
-    U("vec", True, (f"{h}.transform.LayerNorm.bias", (d,)))
-    U("mat", True, (f"{h}.linear_feat.weight", (F, d)))
-    U("vec", True, (f"{h}.linear_feat.bias", (F,)))
-    U("vec", True, (f"{h}.out_cluster.bias", (cfg.num_clusters,)))
+    U("mat", pretrain, (f"{h}.transform.dense.weight", (d, d)))
+    U("vec", pretrain, (f"{h}.transform.dense.bias", (d,)))
+    U("vec", pretrain, (f"{h}.transform.LayerNorm.weight", (d,)))
+    U("vec", pretrain, (f"{h}.transform.LayerNorm.bias", (d,)))
+    U("mat", pretrain, (f"{h}.linear_feat.weight", (F, d)))
+    U("vec", pretrain, (f"{h}.linear_feat.bias", (F,)))
+    U("vec", pretrain, (f"{h}.out_cluster.bias", (cfg.num_clusters,)))
+    if task == "vqa":
+        a = "answer_head.logit_fc"                       # nn.Sequential indices of HF:606-611
+        U("mat", True, (f"{a}.0.weight", (2 * d, d)))
+        U("vec", True, (f"{a}.0.bias", (2 * d,)))
+        U("vec", True, (f"{a}.2.weight", (2 * d,)))
+        U("vec", True, (f"{a}.2.bias", (2 * d,)))
+        U("mat", True, (f"{a}.3.weight", (num_answers, 2 * d)))
+        U("vec", True, (f"{a}.3.bias", (num_answers,)))
     return units
 
 
 def _backward_rank(cfg, name):
     """position of a tensor's block in the backward pass (stable sort keeps the order inside a block)."""
-    if name.startswith("obj_predict_head."):
+    if name.startswith("obj_predict_head.") or name.startswith("answer_head."):
         return 0
     if ".x_layers." in name:
         return 1 + (cfg.x_layers - 1 - int(name.split(".x_layers.")[1].split(".")[0]))
@@ -130,16 +145,17 @@ def _backward_rank(cfg, name):
         return base + (cfg.l_layers - 1 - int(name.split(".encoder.layer.")[1].split(".")[0]))
     base += cfg.l_layers
     if name.startswith("bert.pooler."):
-        return base
+        return 0               # only used on the pooled-output tasks, where it is finished right after the head
     return base + 1             # visn_fc, embeddings, mask_feat: finished by the very last kernels
 
 
 class ParamStore:
     """Flat fp32 master parameters + gradients + Adam state + compute-dtype copy, on one device."""
 
-    def __init__(self, cfg, device, compute_dtype=torch.bfloat16, task="vis_mask"):
+    def __init__(self, cfg, device, compute_dtype=torch.bfloat16, task="vis_mask", num_answers=0):
         self.cfg, self.device, self.compute_dtype, self.task = cfg, torch.device(device), compute_dtype, task
-        units = build_units(cfg, task)
+        self.num_answers = num_answers
+        units = build_units(cfg, task, num_answers)
         # used tensors in the order backward FINISHES them (head, cross layers N..0, visual layers, language layers,
         # visual feature encoder, embeddings): completed gradients form a growing prefix of the flat buffer, so the
         # data-parallel exchange can start on contiguous buckets while backward is still running.

@@ -30,7 +30,8 @@ def init_reference_weights(store, seed):
             v = store.view(name)
             if name == "mask_feat" or name.endswith(".bias"):
                 v.zero_()
-            elif name.endswith("LayerNorm.weight") or name.endswith("layer_norm.weight"):
+            elif name.endswith("LayerNorm.weight") or name.endswith("layer_norm.weight") or \
+                    (len(m.shape) == 1 and name.endswith(".weight")):      # answer_head.logit_fc.2 is a LayerNorm too
                 v.fill_(1.0)
             else:
                 v.copy_((torch.randn(m.shape, generator=g) * std).to(v.device))
@@ -49,17 +50,20 @@ class PretrainStep:
     def __init__(self, cfg: XLxmertConfig, batch_size, text_len=20, n_grids=64, dtype=torch.bfloat16, device=None,
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=True, train_dropout=False, store=None,
-                 bucket_mb=128, ops=None):
-        """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps."""
+                 bucket_mb=128, ops=None, task="vis_mask", num_answers=0):
+        """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
+        task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py) or "vqa" (VQA/GQA fine-tune step
+        on real grid features with `num_answers` answers, ref tasks/vqa.py:166-198) -- same clip / AdamW / schedule."""
         self.cfg = cfg
+        self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
-        self.store = store if store is not None else ParamStore(cfg, self.device, dtype, task="vis_mask")
+        self.store = store if store is not None else ParamStore(cfg, self.device, dtype, task=task, num_answers=num_answers)
         self.ops = ops if ops is not None else HipOps(dtype)
         if store is None:
             init_reference_weights(self.store, seed)          # same seed on every rank == DDP's rank-0 broadcast
-        self.engine = Engine(cfg, self.store, self.ops, batch_size, text_len, n_grids, need_lang=False,
+        self.engine = Engine(cfg, self.store, self.ops, batch_size, text_len, n_grids, need_lang=(task == "vqa"),
                              train_dropout=train_dropout)
         self.engine.sync_compute_weights()
         self.store.ensure_adam_state()
@@ -113,7 +117,19 @@ class PretrainStep:
         ids = batch["input_ids"]
         am = batch.get("attention_mask")
         if am is None:
-            am = ids > 0                                       # ref lxmert_pretrain.py:206
+            am = ids > 0                                       # ref lxmert_pretrain.py:206 / tasks/vqa.py:178
+        if self.task == "vqa":
+            # batch: input_ids (word_ids), visual_feats [B,V,F] (vis_feats), visual_pos (boxes), targets [B,A] soft scores
+            eng.set_step_seed(self.t * self.world + self.rank)
+            eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], visual_feats=batch["visual_feats"])
+            if self.world > 1:
+                self._begin_exchange()
+                eng.grad_ready = self._on_grad_ready
+            loss = eng.vqa_forward_backward(batch["targets"])
+            if self.world > 1:
+                self._finish_exchange()
+            self.optimizer_step()
+            return loss
         labels = batch.get("obj_labels")
         if labels is None:
             labels = batch["cluster_ids"].clone()
