@@ -156,6 +156,15 @@ int xl_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, v
 int xl_bce_logits_fwd_bwd(const float* logits, const float* targets, void* dlogits, float* loss,
                           int M, int N, int ld_logits, int ld_targets, int ld_dlogits, int dtype, void* stream);
 
+/* Iterative (Mask-Predict) sampler, ref tasks/imggen_model.py:169-257, kept on the device between steps:
+ * xl_remask_lowest: vis_mask[b, v] (uint8) = 1 at the n_mask lowest-confidence positions of row b (prob fp32 [B,V], V <= 64;
+ *   ties -> lower index), 0 elsewhere  (ref :204-212  topk(largest=False) + scatter_).
+ * xl_sampler_update: code_ids[i] (int64) = pred_ids[i] (int32, from xl_ce_fwd_bwd's argmax) where vis_mask[i] != 0
+ *   (ref :238-243; the [B,V,2048] code tensor is represented by its codebook ids + mask, materialised by
+ *   xl_codebook_gather exactly as `where(mask, mask_feat, vis_emb(ids))`). */
+int xl_remask_lowest(const float* prob, void* vis_mask, int B, int V, int n_mask, void* stream);
+int xl_sampler_update(const int* pred_ids, const void* vis_mask, int64_t* code_ids, int n, void* stream);
+
 /* ---------------------------------------------------------------- attention core (HF:247-263)
  * per (b,h): O = softmax(Q K^T * scale, keys with key_mask==0 excluded) V ; nq,nk <= 64.
  * q/k/v/o are [B, n, H*dh]-shaped views with row strides ldq/ldk/ldv/ldo (elements); head h

@@ -231,6 +231,45 @@ def gen_vqa(name, cfg, num_answers, seed, B, L, grid):
     print(name, "loss", float(loss), "n_grads", len(grads))
 
 
+def gen_sampler(name, cfg, seed, B, L, grid, n_steps):
+    """Mask-Predict sampling loop of tasks/imggen_model.py:199-243 executed on the REFERENCE's modules
+    (`bert`, `obj_predict_head`, `vis_emb`, `mask_feat` of lxrt.modeling.XLxmertForPretraining).  The published
+    ImggenModel cannot run it itself: it builds HF's LxmertVisualObjHead, which has no `out_keys` / cluster output, and
+    downloads a tokenizer; the loop body below is its line-for-line sequence of calls."""
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    input_ids = inp["input_ids"]
+    V = grid * grid
+    visual_pos = torch.from_numpy(O.box_position(grid)).unsqueeze(0).expand(B, -1, -1)
+    masks, ids, probs = [], [], []
+    with torch.no_grad():
+        for i in range(n_steps):
+            ratio = (n_steps - i) / n_steps
+            n_mask = int(ratio * V)
+            if i == 0:
+                vis_mask = torch.ones(B, V).long()
+                code = torch.zeros(B, V, cfg.visual_feat_dim)
+            else:
+                lowest_prob, lowest_arg = pred_prob.topk(n_mask, dim=1, largest=False)
+                vis_mask = torch.zeros(B, V).long()
+                vis_mask.scatter_(1, lowest_arg, 1)
+            code = torch.where(vis_mask.view(B, V, 1).bool(), m.mask_feat.view(1, 1, -1).to(dtype=code.dtype), code)
+            out = m.bert(input_ids=input_ids, visual_feats=code, visual_pos=visual_pos, attention_mask=input_ids > 0,
+                         return_dict=True)
+            pred_code_logit = m.obj_predict_head(out[1], out_keys=["obj"])["obj"]
+            pred_code_prob = torch.softmax(pred_code_logit, dim=2)
+            pred_prob, pred_code_id = pred_code_prob.max(dim=2)
+            pred_code = m.vis_emb(pred_code_id)
+            code = torch.where(vis_mask.view(B, V, 1).bool(), pred_code, code)
+            masks.append(vis_mask.numpy().copy()); ids.append(pred_code_id.numpy().copy()); probs.append(pred_prob.numpy().copy())
+    d = dict(seed=np.array(seed), n_steps=np.array(n_steps), grid=np.array(grid), **cfg_fields(cfg), in_input_ids=input_ids.numpy())
+    d.update(code=code.numpy(), step_masks=np.stack(masks), step_pred_ids=np.stack(ids), step_pred_prob=np.stack(probs))
+    top2 = torch.softmax(pred_code_logit, dim=2).topk(2, dim=2).values
+    d["last_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "steps", n_steps, "final code norm", float(code.norm()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     tiny = dict(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
@@ -240,4 +279,5 @@ if __name__ == "__main__":
     gen_tiny("tiny_955", O.OracleConfig(l_layers=9, x_layers=5, r_layers=5, **tiny), seed=4321, B=2, L=8, grid=4,
              store_grads=False)
     gen_config1()
+    gen_sampler("sampler_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, B=3, L=8, grid=4, n_steps=4)
     gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)

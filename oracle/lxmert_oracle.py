@@ -212,6 +212,41 @@ def lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=No
     return lang, vis, pooled
 
 
+# --------------------------------------------------------------------------- iterative sampler
+def sample_codes_nar(sd, cfg, input_ids, n_steps, grid_size=8, return_trace=False):
+    """ref:x-lxmert/src/tasks/imggen_model.py:169-243 (sample_image_NAR, up to the hand-off to the frozen GAN generator).
+    Returns (code [B,V,F], code_ids [B,V], pred_prob [B,V]); the code tensor only ever holds mask_feat or centroid rows,
+    so it is tracked here both ways."""
+    B = input_ids.shape[0]
+    V = grid_size ** 2
+    dtype = sd["vis_emb.weight"].dtype
+    visual_pos = torch.from_numpy(box_position(grid_size)).unsqueeze(0).expand(B, -1, -1).to(dtype)
+    trace = []
+    with torch.no_grad():
+        for i in range(n_steps):
+            n_mask = int((n_steps - i) / n_steps * V)                                   # :201-202
+            if i == 0:
+                vis_mask = torch.ones(B, V, dtype=torch.long)                           # :204-206
+                code = torch.zeros(B, V, cfg.visual_feat_dim, dtype=dtype)
+                code_ids = torch.zeros(B, V, dtype=torch.long)
+            else:
+                _, lowest_arg = pred_prob.topk(n_mask, dim=1, largest=False)            # :208-212
+                vis_mask = torch.zeros(B, V, dtype=torch.long)
+                vis_mask.scatter_(1, lowest_arg, 1)
+            m3 = vis_mask.view(B, V, 1).bool()
+            code = torch.where(m3, sd["mask_feat"].view(1, 1, -1).to(dtype), code)      # :215-218
+            _, vis, _ = lxmert_model(sd, cfg, input_ids, code, visual_pos, input_ids > 0)   # :221-227
+            _, obj = visual_obj_head(sd, cfg, vis)                                      # :228-229
+            pred_prob, pred_code_id = torch.softmax(obj, dim=2).max(dim=2)              # :232-235
+            code = torch.where(m3, sd["vis_emb.weight"][pred_code_id], code)            # :238-243
+            code_ids = torch.where(vis_mask.bool(), pred_code_id, code_ids)
+            if return_trace:
+                trace.append((vis_mask.clone(), pred_code_id.clone(), pred_prob.clone()))
+    if return_trace:
+        return code, code_ids, pred_prob, trace
+    return code, code_ids, pred_prob
+
+
 # --------------------------------------------------------------------------- VQA / GQA fine-tune head (SURVEY 8f N1)
 def visual_answer_head(sd, cfg, pooled, prefix="answer_head.logit_fc"):
     """HF:602-614 LxmertVisualAnswerHead -- Linear(d, 2d) -> GeLU -> LayerNorm(2d, eps=1e-12) -> Linear(2d, num_answers)."""

@@ -191,6 +191,18 @@ class FakeOps:
             d.zero_()
             d[:, :N].copy_((torch.sigmoid(x) - t) / float(M * N))
 
+    def remask_lowest(self, prob, vis_mask, B, V, n_mask):
+        p = prob.reshape(B, V)
+        order = torch.argsort(p, dim=1, stable=True)           # ascending, ties -> lower index first
+        m = torch.zeros(B, V, dtype=torch.uint8)
+        if n_mask > 0:
+            m.scatter_(1, order[:, :n_mask], 1)
+        vis_mask.view(B, V).copy_(m)
+
+    def sampler_update(self, pred_ids, vis_mask, code_ids, n):
+        m = vis_mask.reshape(-1)[:n] != 0
+        code_ids.view(-1)[:n][m] = pred_ids.reshape(-1)[:n][m].to(code_ids.dtype)
+
     @staticmethod
     def _heads(t, B, n, H, dh, ld):
         return torch.as_strided(t, (B, H, n, dh), (n * ld, dh, ld, 1))

@@ -168,3 +168,35 @@ def test_vqa_step_vs_reference_fixture():
         assert maxdiff(got, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), k
     used = {m.name for u in eng.store.units if u.used for m in u.members}
     assert set(names) <= used and not any(n.startswith("obj_predict_head") or n == "mask_feat" for n in used)
+
+
+def make_sampler_engine(g, ops, device="cpu", dtype=torch.float32):
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    ids = torch.from_numpy(g["in_input_ids"])
+    B, L = ids.shape
+    grid = int(g["grid"])
+    V = grid * grid
+    store = ParamStore(cfg, device, dtype, task="vis_mask")
+    store.load_named(sd)
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=False)
+    eng.sync_compute_weights()
+    dev = torch.device(device)
+    pos = torch.from_numpy(O.box_position(grid)).unsqueeze(0).expand(B, -1, -1)
+    eng.set_inputs(ids.to(dev), (ids > 0).to(dev), None, pos.to(dev), cluster_ids=torch.zeros(B, V, dtype=torch.long, device=dev),
+                   vis_mask=torch.ones(B, V, dtype=torch.bool, device=dev))
+    return eng, sd
+
+
+def test_sampler_loop_vs_reference_fixture():
+    """the engine's on-device Mask-Predict loop reproduces the reference modules' codes exactly (fp32)."""
+    g = load_golden("sampler_tiny")
+    eng, sd = make_sampler_engine(g, FakeOps(torch.float32))
+    cid, code, prob = eng.sample_codes_nar(int(g["n_steps"]))
+    assert maxdiff(code.view(g["code"].shape), g["code"]) == 0.0
+    assert maxdiff(prob.view(g["step_pred_prob"][-1].shape), g["step_pred_prob"][-1]) < 1e-5
+    assert torch.equal(eng.vmask.long().cpu(), torch.from_numpy(g["step_masks"][-1]))

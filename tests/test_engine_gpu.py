@@ -295,3 +295,60 @@ def test_vqa_full_size_step_properties_bf16():
     assert torch.isfinite(gr).all()
     assert store.gview("bert.encoder.visn_fc.visn_fc.weight").abs().max().item() > 0
     assert store.gview("answer_head.logit_fc.3.weight").abs().max().item() > 0
+
+
+# ---------------------------------------------------------------- on-device iterative sampler
+def test_sampler_loop_fp32_matches_reference_fixture():
+    from test_engine_cpu import make_sampler_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("sampler_tiny")
+    eng, sd = make_sampler_engine(g, HipOps(torch.float32), device="cuda")
+    cid, code, prob = eng.sample_codes_nar(int(g["n_steps"]))
+    torch.cuda.synchronize()
+    assert maxdiff(code.cpu().view(g["code"].shape), g["code"]) == 0.0            # same codes chosen at every position
+    assert maxdiff(prob.cpu().view(g["step_pred_prob"][-1].shape), g["step_pred_prob"][-1]) < 1e-4
+    assert torch.equal(eng.vmask.long().cpu(), torch.from_numpy(g["step_masks"][-1]))
+
+
+def test_sampler_loop_bf16_agrees_where_the_reference_is_decisive():
+    """bf16 may flip an argmax between near-tied codes (and a flipped code changes later steps); stated tolerance:
+    >= 85 % of the positions carry the reference's code after 4 steps."""
+    from test_engine_cpu import make_sampler_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("sampler_tiny")
+    eng, sd = make_sampler_engine(g, HipOps(torch.bfloat16), device="cuda", dtype=torch.bfloat16)
+    cid, code, prob = eng.sample_codes_nar(int(g["n_steps"]))
+    torch.cuda.synchronize()
+    ref_ids = torch.from_numpy(g["step_pred_ids"][-1])
+    # the reference's final ids of positions last predicted at earlier steps are not in the fixture's last row: compare codes
+    same = (code.float().cpu().view(g["code"].shape) - torch.from_numpy(g["code"])).abs().amax(-1) < 2e-2
+    assert same.float().mean().item() >= 0.85, same.float().mean().item()
+
+
+def test_sampler_full_size_properties_bf16():
+    """BASELINE config 5 geometry (bs 64 here, 4 steps, 8x8 grid, 10k codebook): ids in range, every position predicted,
+    deterministic (two runs agree), no host synchronisation needed between steps."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import Engine
+    from xlxmert_amd.ops import HipOps
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import init_reference_weights
+    cfg = XLxmertConfig()
+    B, L, V = 64, 20, 64
+    store = ParamStore(cfg, "cuda", torch.bfloat16, task="vis_mask")
+    init_reference_weights(store, 11)
+    gen = torch.Generator().manual_seed(5)
+    store.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=gen).relu())
+    store.view("mask_feat").copy_(torch.randn(cfg.visual_feat_dim, generator=gen).cuda() * 0.1)
+    eng = Engine(cfg, store, HipOps(torch.bfloat16), B, L, V, need_lang=False)
+    eng.sync_compute_weights()
+    inp = O.make_inputs(O.OracleConfig(), 21, B, L, 8)
+    eng.set_inputs(inp["input_ids"].cuda(), inp["attention_mask"].cuda(), None, inp["visual_pos"].cuda(),
+                   cluster_ids=torch.zeros(B, V, dtype=torch.long, device="cuda"), vis_mask=torch.ones(B, V, dtype=torch.bool, device="cuda"))
+    cid1 = eng.sample_codes_nar(4)[0].clone()
+    code1 = eng.feats.clone()
+    cid2 = eng.sample_codes_nar(4)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(cid1, cid2) and cid1.min().item() >= 0 and cid1.max().item() < cfg.num_clusters
+    assert torch.equal(code1.view(B * V, -1), store.centroids_c[cid1.view(-1)])
+    assert eng.vmask.sum(1).eq(16).all()            # last step re-masks int(1/4 * 64) positions per image

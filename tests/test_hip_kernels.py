@@ -515,3 +515,18 @@ def test_tanh_bwd(dtype):
     dx = torch.zeros(n, dtype=dtype)
     cpu, gpu = run_both(dtype, "tanh_bwd", [dy, y, dx, n])
     close(gpu[2], cpu[2], dtype, "tanh_bwd")
+
+
+@pytest.mark.parametrize("V,n_mask", [(64, 16), (64, 64), (16, 0), (16, 5)])
+def test_remask_lowest_and_sampler_update(V, n_mask):
+    g = torch.Generator().manual_seed(V + n_mask)
+    B = 37
+    prob = torch.rand(B, V, generator=g)
+    prob[0, :4] = 0.25                     # ties -> lower index first
+    mask = torch.zeros(B, V, dtype=torch.uint8)
+    cpu, gpu = run_both(torch.float32, "remask_lowest", [prob, mask, B, V, n_mask])
+    assert torch.equal(gpu[1], cpu[1]) and int(gpu[1].sum()) == B * n_mask
+    pred = torch.randint(0, 10000, (B, V), generator=g, dtype=torch.int32)
+    ids = torch.randint(0, 10000, (B, V), generator=g)
+    cpu2, gpu2 = run_both(torch.float32, "sampler_update", [pred, cpu[1], ids, B * V])
+    assert torch.equal(gpu2[2], cpu2[2])

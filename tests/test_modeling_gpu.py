@@ -115,3 +115,23 @@ def test_vqa_model_dropin_matches_reference_fixture():
         ref = torch.from_numpy(g["grad:" + k])
         assert maxdiff(params[k].grad.cpu(), ref) <= 1e-4 * max(1.0, ref.abs().max().item()), k
     assert set(m.state_dict().keys()) >= {"answer_head.logit_fc.3.bias", "bert.pooler.dense.weight"}
+
+
+def test_sample_codes_dropin_matches_reference_fixture():
+    """SURVEY 8f N2 through the module surface: XLxmertForPretraining.sample_codes == the reference loop's final codes."""
+    import lxmert_oracle as O
+    from _util import golden_cfg, load_golden, maxdiff
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.modeling import XLxmertForPretraining
+    g = load_golden("sampler_tiny")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "l_layers", "x_layers",
+                                                      "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+    m = XLxmertForPretraining(cfg, dtype=torch.float32)
+    m.load_state_dict(O.make_state_dict(oc, int(g["seed"])))
+    grid = int(g["grid"])
+    code, ids = m.sample_codes(torch.from_numpy(g["in_input_ids"]).cuda(), n_steps=int(g["n_steps"]), grid_size=grid)
+    B = code.shape[0]
+    ref = torch.from_numpy(g["code"]).permute(0, 2, 1).reshape(B, -1, grid, grid)
+    assert maxdiff(code.cpu(), ref) == 0.0

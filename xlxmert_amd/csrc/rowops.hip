@@ -636,6 +636,29 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ iterative sampler pieces
+// Mask-Predict re-masking (ref tasks/imggen_model.py:204-212): vis_mask[b, :] = 1 at the n_mask positions with the lowest
+// confidence (ties: lower index first), 0 elsewhere.  One wave per row, V <= 64: rank by all-pairs comparison.
+__global__ __launch_bounds__(256) void remask_lowest_kernel(const float* __restrict__ prob, uint8_t* __restrict__ mask,
+                                                            int B, int V, int n_mask) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float mine = lane < V ? prob[(size_t)row * V + lane] : 3.0e38f;
+    int rank = 0;
+    for (int j = 0; j < V; ++j) {
+        const float other = __shfl(mine, j, 64);
+        rank += (other < mine || (other == mine && j < lane)) ? 1 : 0;
+    }
+    if (lane < V) mask[(size_t)row * V + lane] = rank < n_mask ? 1 : 0;
+}
+
+// code ids of the masked positions take the prediction (ref :238-243, with the code kept as an id into the codebook)
+__global__ __launch_bounds__(256) void sampler_update_kernel(const int* __restrict__ pred, const uint8_t* __restrict__ mask,
+                                                             int64_t* __restrict__ ids, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && mask[i]) ids[i] = pred[i];
+}
+
 }  // namespace xl
 
 using namespace xl;
@@ -901,6 +924,23 @@ extern "C" int xl_bce_logits_fwd_bwd(const float* logits, const float* targets, 
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((bce_logits_kernel<T>), dim3(M), dim3(256), 0, st, logits, targets, (T*)dlogits, loss, M, N,
                            ld_logits, ld_targets, dlogits ? ld_dlogits : N, scale););
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_remask_lowest(const float* prob, void* vis_mask, int B, int V, int n_mask, void* stream) {
+    XL_CHECK_ARG(prob && vis_mask && B > 0 && V > 0 && V <= 64 && n_mask >= 0 && n_mask <= V, XL_ERR_BAD_ARG,
+                 "xl_remask_lowest: B=%d V=%d (<= 64) n_mask=%d", B, V, n_mask);
+    hipLaunchKernelGGL(remask_lowest_kernel, dim3((B + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, prob,
+                       (uint8_t*)vis_mask, B, V, n_mask);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_sampler_update(const int* pred_ids, const void* vis_mask, int64_t* code_ids, int n, void* stream) {
+    XL_CHECK_ARG(pred_ids && vis_mask && code_ids && n > 0, XL_ERR_BAD_ARG, "xl_sampler_update: bad args");
+    hipLaunchKernelGGL(sampler_update_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred_ids,
+                       (const uint8_t*)vis_mask, code_ids, n);
     XL_CHECK_LAUNCH();
     return XL_OK;
 }

@@ -625,6 +625,29 @@ class Engine:
                             self.MV, self.K, self.K, self.Kp, 1.0)
         return self.row_maxprob, self.row_argmax
 
+    def sample_codes_nar(self, n_steps=4):
+        """Iterative Mask-Predict sampling (ref tasks/imggen_model.py:169-243) without a host round trip between steps:
+        re-mask the lowest-confidence positions -> encoder -> codebook head -> softmax-max / argmax -> keep the predictions
+        of the masked positions.  Text inputs come from set_inputs (cluster_ids / vis_mask there are placeholders).
+        Returns (code_ids [B,V] int64, code features [B*V, F] in the compute dtype, pred_prob [B*V] fp32); the caller
+        hands `code.view(B,V,F).permute(0,2,1).view(B,F,g,g)` to the frozen GAN generator (stock PyTorch, ref :254)."""
+        ops, B, V = self.ops, self.B, self.V
+        st = self.store
+        self.use_codebook, self.has_vmask = True, True
+        self.cid.zero_()
+        for i in range(n_steps):
+            n_mask = int((n_steps - i) / n_steps * V)                      # ref :201-202 (host arithmetic on the step index)
+            if i == 0:
+                self.vmask.fill_(1)                                        # ref :204-206
+            else:
+                ops.remask_lowest(self.row_maxprob, self.vmask, B, V, n_mask)
+            self.encoder_forward(want_pooled=False)                        # codebook_gather == where(mask, mask_feat, vis_emb(ids))
+            self.head_forward()
+            self.predict_codes()
+            ops.sampler_update(self.row_argmax, self.vmask, self.cid, B * V)
+        ops.codebook_gather(self.cid, None, st.centroids_c, st.view("mask_feat"), self.feats, self.MV, self.F)
+        return self.cid, self.feats, self.row_maxprob
+
     # ------------------------------------------------------------ backward
     def zero_accumulated_grads(self):
         st = self.store

@@ -300,6 +300,32 @@ class XLxmertForPretraining(nn.Module):
         total = obj_loss + feat_l
         return {"obj_loss": obj_loss.detach(), "feat_loss": feat_l.detach(), "vis_loss": total.detach(), "total_loss": total}
 
+    @torch.no_grad()
+    def sample_codes(self, input_ids, n_steps=4, grid_size=8):
+        """The device part of ImggenModel.sample_image_NAR (ref tasks/imggen_model.py:169-254): Mask-Predict sampling of
+        the grid codes, returned as the generator's input `[B, feat_dim, grid, grid]` (fp32) plus the chosen code ids.
+        Tokenisation (before) and the frozen GAN `G(code)` + denorm (after) stay with the caller, as in the reference."""
+        import numpy as np
+        if self.vis_emb is None:
+            raise RuntimeError("call set_visual_embedding(centroids) first")
+        was_training = self.training
+        self.eval()
+        B, L = input_ids.shape
+        V = grid_size * grid_size
+        eng = self._step_engine(B, L, V)
+        pos = np.zeros((V, 4), np.float32)                      # ref utils.box_position
+        for i in range(grid_size):
+            for j in range(grid_size):
+                pos[i * grid_size + j] = [j / grid_size, i / grid_size, (j + 1) / grid_size, (i + 1) / grid_size]
+        dev = input_ids.device
+        eng.set_inputs(input_ids, input_ids > 0, None, torch.from_numpy(pos).to(dev).unsqueeze(0).expand(B, -1, -1),
+                       cluster_ids=torch.zeros(B, V, dtype=torch.long, device=dev),
+                       vis_mask=torch.ones(B, V, dtype=torch.bool, device=dev))
+        cid, code, _ = eng.sample_codes_nar(n_steps)
+        out = code.view(B, V, -1).permute(0, 2, 1).reshape(B, -1, grid_size, grid_size).float()
+        self.train(was_training)
+        return out, cid.clone()
+
     def _step_engine(self, B, L, V):
         key = (B, L, V, self.training, "step")
         if self.bert._geom != key:

@@ -131,6 +131,12 @@ class HipOps:
         self.lib.call("xl_bce_logits_fwd_bwd", self._p(logits), self._p(targets), self._p(dlogits), self._p(loss), M, N,
                       ld_logits, ld_targets, ld_dlogits, self.dt, self._stream())
 
+    def remask_lowest(self, prob, vis_mask, B, V, n_mask):
+        self.lib.call("xl_remask_lowest", self._p(prob), self._p(vis_mask), B, V, int(n_mask), self._stream())
+
+    def sampler_update(self, pred_ids, vis_mask, code_ids, n):
+        self.lib.call("xl_sampler_update", self._p(pred_ids), self._p(vis_mask), self._p(code_ids), n, self._stream())
+
     # -- attention core
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
         self.lib.call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),
