@@ -231,6 +231,44 @@ def gen_vqa(name, cfg, num_answers, seed, B, L, grid):
     print(name, "loss", float(loss), "n_grads", len(grads))
 
 
+def gen_lang_tasks(name, cfg, seed, B, L, grid):
+    """the reference's `word_mask` and `matched` branches (lxrt/modeling.py:211-235) with the pretraining heads
+    of HF:589-657.  transformers 4.1.1 ties `cls.predictions.decoder.weight` to the word embeddings in the constructor
+    (`LxmertPreTrainingHeads(config, weight)`); the 5.15.0 class takes no weight, so the shim re-ties it by assignment."""
+    hf = LxmertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                      num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                      max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                      l_layers=cfg.l_layers, x_layers=cfg.x_layers, r_layers=cfg.r_layers,
+                      visual_feat_dim=cfg.visual_feat_dim, visual_pos_dim=cfg.visual_pos_dim,
+                      visual_attr_loss=False, task_qa=False, task_mask_lm=True, task_matched=True)
+    m = Shim(hf, num_clusters=cfg.num_clusters)
+    sd = O.make_cls_state_dict(cfg, seed)
+    m.set_visual_embedding(sd["vis_emb.weight"].clone())
+    m.config.n_centroids = cfg.num_clusters
+    res = m.load_state_dict({k: v for k, v in sd.items() if k not in ("vis_emb.weight", "obj_predict_head.out_cluster.weight",
+                                                                      "cls.predictions.decoder.weight")}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    m.cls.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight          # 4.1.1 constructor behaviour
+    m.eval()
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    word_labels, matched_labels = O.make_lang_task_labels(cfg, inp["input_ids"], seed + 2)
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp), in_word_labels=word_labels.numpy(),
+             in_matched_labels=matched_labels.numpy())
+    for task, key, labels in (("word_mask", "word_labels", word_labels), ("matched", "matched_labels", matched_labels)):
+        m.zero_grad(set_to_none=True)
+        out = m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+                cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], token_type_ids=inp["token_type_ids"],
+                return_dict=True, label_dict={key: labels}, task=task)
+        out["total_loss"].backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        d[task + ":loss"] = out["total_loss"].detach().numpy()
+        d[task + ":grad_names"] = np.array(sorted(grads.keys()))
+        for k, g in grads.items():
+            d[task + ":grad:" + k] = g.numpy()
+        print(name, task, "loss", float(out["total_loss"]), "n_grads", len(grads))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+
+
 def gen_sampler(name, cfg, seed, B, L, grid, n_steps):
     """Mask-Predict sampling loop of tasks/imggen_model.py:199-243 executed on the REFERENCE's modules
     (`bert`, `obj_predict_head`, `vis_emb`, `mask_feat` of lxrt.modeling.XLxmertForPretraining).  The published
@@ -279,5 +317,6 @@ if __name__ == "__main__":
     gen_tiny("tiny_955", O.OracleConfig(l_layers=9, x_layers=5, r_layers=5, **tiny), seed=4321, B=2, L=8, grid=4,
              store_grads=False)
     gen_config1()
+    gen_lang_tasks("lang_tasks_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=8642, B=3, L=8, grid=4)
     gen_sampler("sampler_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, B=3, L=8, grid=4, n_steps=4)
     gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)

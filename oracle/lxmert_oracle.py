@@ -212,6 +212,72 @@ def lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=No
     return lang, vis, pooled
 
 
+# --------------------------------------------------------------------------- language pretraining heads
+def lm_prediction_head(sd, cfg, lang, prefix="cls.predictions"):
+    """HF:589-599 LxmertLMPredictionHead -- decoder(LN(gelu(dense(x)))) + bias, decoder weight TIED to the word embeddings
+    (transformers 4.1.1 ctor: `self.decoder.weight = lxmert_model_embedding_weights`; ref lxrt/modeling.py:86)."""
+    h = _layer_norm(sd, prefix + ".transform.LayerNorm", F.gelu(_linear(sd, prefix + ".transform.dense", lang)), 1e-12)
+    return F.linear(h, sd["bert.embeddings.word_embeddings.weight"]) + sd[prefix + ".bias"]
+
+
+def xlxmert_word_mask_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, word_labels, token_type_ids=None):
+    """ref:x-lxmert/src/lxrt/modeling.py:154-225, task == 'word_mask': un-masked centroid features in, MLM CE (ignore -100)."""
+    feats = codebook_features(sd, cluster_ids, None)
+    lang, vis, pooled = lxmert_model(sd, cfg, input_ids, feats, visual_pos, attention_mask, token_type_ids)
+    scores = lm_prediction_head(sd, cfg, lang)
+    lm_loss = F.cross_entropy(scores.view(-1, cfg.vocab_size), word_labels.view(-1))
+    return {"lm_loss": lm_loss, "total_loss": lm_loss, "scores": scores}
+
+
+def xlxmert_matched_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, matched_labels, token_type_ids=None):
+    """ref:x-lxmert/src/lxrt/modeling.py:154-235, task == 'matched': seq_relationship(pooled_output), 2-way CE (HF:648-657)."""
+    feats = codebook_features(sd, cluster_ids, None)
+    lang, vis, pooled = lxmert_model(sd, cfg, input_ids, feats, visual_pos, attention_mask, token_type_ids)
+    score = _linear(sd, "cls.seq_relationship", pooled)
+    loss = F.cross_entropy(score.view(-1, 2), matched_labels.view(-1))
+    return {"matched_loss": loss, "total_loss": loss, "score": score}
+
+
+def cls_head_shapes(cfg):
+    d = cfg.hidden_size
+    return [("cls.predictions.transform.dense.weight", (d, d)), ("cls.predictions.transform.dense.bias", (d,)),
+            ("cls.predictions.transform.LayerNorm.weight", (d,)), ("cls.predictions.transform.LayerNorm.bias", (d,)),
+            ("cls.predictions.bias", (cfg.vocab_size,)),
+            ("cls.seq_relationship.weight", (2, d)), ("cls.seq_relationship.bias", (2,))]
+
+
+def make_cls_state_dict(cfg, seed, perturb=True):
+    """make_state_dict(cfg, seed) + deterministic `cls.*` heads (seed + 13); `cls.predictions.decoder.weight` is the word
+    embedding matrix (tied)."""
+    sd = make_state_dict(cfg, seed, perturb)
+    rng = np.random.default_rng(seed + 13)
+    for name, shape in cls_head_shapes(cfg):
+        if name.endswith("LayerNorm.weight"):
+            w = np.ones(shape, np.float32) + (0.1 * rng.standard_normal(shape, dtype=np.float32) if perturb else 0.0)
+        elif len(shape) == 1:
+            w = 0.05 * rng.standard_normal(shape, dtype=np.float32) if perturb else np.zeros(shape, np.float32)
+        else:
+            w = 0.02 * rng.standard_normal(shape, dtype=np.float32)
+        sd[name] = torch.from_numpy(np.asarray(w, np.float32))
+    sd["cls.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    return sd
+
+
+def make_lang_task_labels(cfg, input_ids, seed):
+    """word_labels: the token id at ~25 % of the real, non-special positions, -100 elsewhere (the loss ignores -100; the
+    reference's data code writes -1, which its own CrossEntropyLoss would reject); matched_labels: 0/1 per example."""
+    rng = np.random.default_rng(seed)
+    ids = input_ids.numpy()
+    lab = np.full(ids.shape, -100, np.int64)
+    for b in range(ids.shape[0]):
+        real = np.flatnonzero(ids[b] > 0)[1:-1]
+        pick = real[rng.random(len(real)) < 0.25]
+        if len(pick) == 0 and len(real):
+            pick = real[:1]
+        lab[b, pick] = ids[b, pick]
+    return torch.from_numpy(lab), torch.from_numpy(rng.integers(0, 2, size=ids.shape[0], dtype=np.int64))
+
+
 # --------------------------------------------------------------------------- iterative sampler (SURVEY 8f N2)
 def sample_codes_nar(sd, cfg, input_ids, n_steps, grid_size=8, return_trace=False):
     """ref:x-lxmert/src/tasks/imggen_model.py:169-243 (sample_image_NAR, up to the hand-off to the frozen GAN generator).

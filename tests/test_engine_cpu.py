@@ -200,3 +200,45 @@ def test_sampler_loop_vs_reference_fixture():
     assert maxdiff(code.view(g["code"].shape), g["code"]) == 0.0
     assert maxdiff(prob.view(g["step_pred_prob"][-1].shape), g["step_pred_prob"][-1]) < 1e-5
     assert torch.equal(eng.vmask.long().cpu(), torch.from_numpy(g["step_masks"][-1]))
+
+
+def make_lang_task_engine(g, task, ops, device="cpu", dtype=torch.float32):
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    sd = O.make_cls_state_dict(oc, int(g["seed"]))
+    inp = golden_inputs(g)
+    B, L = inp["input_ids"].shape
+    V = inp["cluster_ids"].shape[1]
+    store = ParamStore(cfg, device, dtype, task=task)
+    store.load_named(sd)
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=True)
+    eng.sync_compute_weights()
+    dev = torch.device(device)
+    eng.set_inputs(inp["input_ids"].to(dev), inp["attention_mask"].to(dev), inp["token_type_ids"].to(dev),
+                   inp["visual_pos"].to(dev), cluster_ids=inp["cluster_ids"].to(dev))
+    return eng, inp
+
+
+def check_lang_task(g, task, eng, inp, loss_tol, grad_tol, dev="cpu"):
+    labels = inp["word_labels" if task == "word_mask" else "matched_labels"].to(dev)
+    loss = eng.word_mask_forward_backward(labels) if task == "word_mask" else eng.matched_forward_backward(labels)
+    assert abs(loss.item() - float(g[task + ":loss"])) < loss_tol
+    names = [str(n) for n in g[task + ":grad_names"]]
+    used = {m.name for u in eng.store.units if u.used for m in u.members}
+    assert set(names) == used, (sorted(set(names) ^ used))[:6]      # optimizer range == the reference's grad-carrying set
+    for k in names:
+        ref = torch.from_numpy(g[task + ":grad:" + k])
+        got = eng.store.gview(k).cpu()
+        assert maxdiff(got, ref) <= grad_tol * max(1.0, ref.abs().max().item()), k
+
+
+@pytest.mark.parametrize("task", ["word_mask", "matched"])
+def test_language_pretraining_steps_vs_reference_fixture(task):
+    """MLM (tied decoder: d(word embeddings) = embedding scatter + decoder weight gradient) and matched head
+    steps against the fixture generated by the reference's own branches."""
+    g = load_golden("lang_tasks_tiny")
+    eng, inp = make_lang_task_engine(g, task, FakeOps(torch.float32))
+    check_lang_task(g, task, eng, inp, 5e-6, 1e-4)

@@ -352,3 +352,59 @@ def test_sampler_full_size_properties_bf16():
     assert torch.equal(cid1, cid2) and cid1.min().item() >= 0 and cid1.max().item() < cfg.num_clusters
     assert torch.equal(code1.view(B * V, -1), store.centroids_c[cid1.view(-1)])
     assert eng.vmask.sum(1).eq(16).all()            # last step re-masks int(1/4 * 64) positions per image
+
+
+# ---------------------------------------------------------------- language pretraining branches
+@pytest.mark.parametrize("task", ["word_mask", "matched"])
+def test_language_pretraining_steps_fp32_match_reference_fixture(task):
+    from test_engine_cpu import check_lang_task, make_lang_task_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("lang_tasks_tiny")
+    eng, inp = make_lang_task_engine(g, task, HipOps(torch.float32), device="cuda")
+    check_lang_task(g, task, eng, inp, 2e-5, 1e-4, dev="cuda")
+
+
+@pytest.mark.parametrize("task", ["word_mask", "matched"])
+def test_language_pretraining_steps_bf16_stated_tolerance(task):
+    """bf16: loss within 2e-2, every gradient tensor within 6 % relative L2 of the fp32 reference gradient."""
+    from test_engine_cpu import make_lang_task_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("lang_tasks_tiny")
+    eng, inp = make_lang_task_engine(g, task, HipOps(torch.bfloat16), device="cuda", dtype=torch.bfloat16)
+    labels = inp["word_labels" if task == "word_mask" else "matched_labels"].cuda()
+    loss = eng.word_mask_forward_backward(labels) if task == "word_mask" else eng.matched_forward_backward(labels)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g[task + ":loss"])) < 2e-2
+    for k in [str(n) for n in g[task + ":grad_names"]]:
+        ref = torch.from_numpy(g[task + ":grad:" + k]).double()
+        got = eng.store.gview(k).cpu().double()
+        rel = (got - ref).norm().item() / max(ref.norm().item(), 1e-4)
+        assert rel < 6e-2, (k, rel)
+
+
+def test_word_mask_full_size_step_properties_bf16():
+    """full encoder, 30522-way tied decoder at bs 64: loss ~ ln(30522) at init, finite gradients, the word-embedding
+    gradient has a non-zero row 0 (decoder side; the embedding scatter skips padding_idx 0)."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import Engine
+    from xlxmert_amd.ops import HipOps
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import init_reference_weights
+    cfg = XLxmertConfig()
+    B, L, V = 64, 20, 64
+    store = ParamStore(cfg, "cuda", torch.bfloat16, task="word_mask")
+    init_reference_weights(store, 3)
+    gen = torch.Generator().manual_seed(5)
+    store.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=gen).relu())
+    eng = Engine(cfg, store, HipOps(torch.bfloat16), B, L, V, need_lang=True)
+    eng.sync_compute_weights()
+    oc = O.OracleConfig()
+    inp = O.make_inputs(oc, 31, B, L, 8)
+    wl, _ = O.make_lang_task_labels(oc, inp["input_ids"], 32)
+    eng.set_inputs(inp["input_ids"].cuda(), inp["attention_mask"].cuda(), None, inp["visual_pos"].cuda(),
+                   cluster_ids=inp["cluster_ids"].cuda())
+    loss = eng.word_mask_forward_backward(wl.cuda())
+    torch.cuda.synchronize()
+    assert 9.5 < loss.item() < 11.5, loss.item()                # ln(30522) = 10.33
+    assert torch.isfinite(store.grad[:store.n_used]).all()
+    assert store.gview("bert.embeddings.word_embeddings.weight")[0].abs().max().item() > 0

@@ -260,18 +260,114 @@ class AnswerHead:
         ops.colsum(self.dpre, self.gb0, B, 2 * d, 2 * d, ws=e.ws)
         e.wgrad_defer(self.dpre, pooled, self.gw0, 2 * d, d, B, 2 * d, d, d)
         ops.gemm(self.dpre, self.w0, self.dpooled, None, None, None, B, d, 2 * d, 2 * d, d, d, a_kmajor=1, b_kmajor=0)
-        # LxmertPooler backward (HF:566-572): pooled = tanh(W_p cls + b_p)
-        ops.tanh_bwd(self.dpooled, pooled, self.dz, B * d)
-        ops.colsum(self.dz, st.gview("bert.pooler.dense.bias"), B, d, d, ws=e.ws)
-        e.wgrad_defer(self.dz, cls_rows, st.gview("bert.pooler.dense.weight"), d, d, B, d, L * d, d)
-        e.wgrad_flush()
-        ops.gemm(self.dz, st.cview("bert.pooler.dense.weight"), d_cls, None, None, None, B, d, d, d, d, L * d,
-                 a_kmajor=1, b_kmajor=0)
+        e.pooler_backward(self.dpooled, self.dz, cls_rows, d_cls)
 
     def gb3_pad(self):
         """bias-gradient view padded to the 8-column granule of dlogit (the bias unit is padded in the flat buffer)."""
         m = self.e.store.index["answer_head.logit_fc.3.bias"]
         return self.e.store.grad[m.offset:m.offset + self.Ap]
+
+
+class LangHeads:
+    """LxmertPreTrainingHeads (HF:589-657) for the `word_mask` and `matched` pretraining branches (ref lxrt/modeling.py:
+    211-235): MLM = decoder(LN(gelu(dense(lang)))) + bias with the decoder TIED to the word-embedding matrix, vocab-way CE
+    over the masked tokens; matched = seq_relationship(pooled_output), 2-way CE."""
+
+    def __init__(self, eng):
+        self.e = eng
+        st, d, ML, B = eng.store, eng.d, eng.ML, eng.B
+        self.has_mlm = "cls.predictions.bias" in st.index and eng.task in ("word_mask", "all")
+        self.has_rel = "cls.seq_relationship.weight" in st.index and eng.task in ("matched", "all")
+        self.loss = eng.f32(2)                  # [lm_loss, matched_loss]
+        self.counts, self.dummy = eng.f32(4), eng.f32(B)
+        if self.has_mlm:
+            t = "cls.predictions.transform"
+            self.wt, self.gwt = st.cview(t + ".dense.weight"), st.gview(t + ".dense.weight")
+            self.bt, self.gbt = st.view(t + ".dense.bias"), st.gview(t + ".dense.bias")
+            self.g, self.gg = st.view(t + ".LayerNorm.weight"), st.gview(t + ".LayerNorm.weight")
+            self.b, self.gb = st.view(t + ".LayerNorm.bias"), st.gview(t + ".LayerNorm.bias")
+            self.vb = st.view("cls.predictions.bias")
+            self.Vn = eng.cfg.vocab_size
+            self.Vp = (self.Vn + 7) // 8 * 8
+            self.pre, self.h, self.hn = eng.act(ML, d), eng.act(ML, d), eng.act(ML, d)
+            self.mean, self.rstd = eng.f32(ML), eng.f32(ML)
+            self.scores = torch.zeros(ML, self.Vp, dtype=torch.float32, device=eng.dev)       # row stride padded to 8
+            self.dscores = eng.act(ML, self.Vp)
+            self.word_labels = torch.full((B, eng.L), -100, dtype=torch.int64, device=eng.dev)
+        if self.has_rel:
+            self.wr, self.gwr = st.cview("cls.seq_relationship.weight"), st.gview("cls.seq_relationship.weight")
+            self.br, self.gbr = st.view("cls.seq_relationship.bias"), st.gview("cls.seq_relationship.bias")
+            self.rel = torch.zeros(B, 8, dtype=torch.float32, device=eng.dev)                # 2 columns used
+            self.drel = eng.act(B, 8)
+            self.matched_labels = torch.zeros(B, dtype=torch.int64, device=eng.dev)
+            self.dpooled, self.dz = eng.act(B, d), eng.act(B, d)
+
+    def _gvb_pad(self):
+        m = self.e.store.index["cls.predictions.bias"]
+        return self.e.store.grad[m.offset:m.offset + self.Vp]
+
+    # ---- word_mask
+    def mlm_fwd(self, lang):
+        e, d, ML = self.e, self.e.d, self.e.ML
+        ops, st = e.ops, e.store
+        ops.gemm(lang, self.wt, self.h, self.bt, None, self.pre, ML, d, d, d, d, d, ldx=d, epilogue=EPI_GELU)
+        ops.layernorm_fwd(self.h, self.g, self.b, self.hn, self.mean, self.rstd, ML, d, 1e-12)
+        ops.gemm(self.hn, st.cview("bert.embeddings.word_embeddings.weight"), self.scores, self.vb, None, None,
+                 ML, self.Vn, d, d, d, self.Vp, out_f32=True)
+        return self.scores
+
+    def mlm_loss_bwd(self, d_lang):
+        """CE over the masked tokens (labels -100 ignored) + backward down to d(language_output) (written to d_lang)."""
+        e, d, ML, Vn, Vp = self.e, self.e.d, self.e.ML, self.Vn, self.Vp
+        ops, st = e.ops, e.store
+        self.loss.zero_()
+        ops.mask_counts(self.word_labels, e.kmask, self.counts, self.dummy, e.B, e.L)
+        ops.ce_fwd_bwd(self.scores, self.word_labels, self.counts, self.dscores, self.loss[0:], None, None, None,
+                       ML, Vn, Vp, Vp, 1.0)
+        emb = "bert.embeddings.word_embeddings.weight"
+        ops.colsum(self.dscores, self._gvb_pad(), ML, Vp, Vp, ws=e.ws)
+        e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, ML, Vp, d, d)             # tied decoder: d(word embeddings)
+        dhn = e.tmp("dctx", ML, d)
+        ops.gemm(self.dscores, st.cview(emb), dhn, None, None, None, ML, d, Vn, Vp, d, d, a_kmajor=1, b_kmajor=0)
+        dh = e.tmp("dz", ML, d)
+        ops.layernorm_bwd(dhn, self.h, self.g, self.mean, self.rstd, dh, self.gg, self.gb, None, ML, d, ws=e.ws)
+        dpre = e.tmp("dzm", ML, d)
+        ops.gelu_bwd(dh, self.pre, dpre, ML * d)
+        ops.colsum(dpre, self.gbt, ML, d, d, ws=e.ws)
+        e.wgrad_defer(dpre, e.lang_final, self.gwt, d, d, ML, d, d, d)
+        e.wgrad_flush()
+        ops.gemm(dpre, self.wt, d_lang, None, None, None, ML, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        return self.loss
+
+    # ---- matched
+    def rel_fwd(self, pooled):
+        e, d, B = self.e, self.e.d, self.e.B
+        e.ops.gemm(pooled, self.wr, self.rel, self.br, None, None, B, 2, d, d, d, 8, out_f32=True)
+        return self.rel
+
+    def rel_loss_bwd(self, pooled, cls_rows, d_cls):
+        e, d, B = self.e, self.e.d, self.e.B
+        ops = e.ops
+        self.loss.zero_()
+        self.counts.fill_(float(B))                                     # every example carries a matched label
+        ops.ce_fwd_bwd(self.rel, self.matched_labels, self.counts, self.drel, self.loss[1:], None, None, None, B, 2, 8, 8, 1.0)
+        # the two output rows of seq_relationship: tiny contractions, done on the 8-column padded gradient
+        g8 = torch.zeros(8, d, dtype=torch.float32, device=e.dev) if not hasattr(self, "_g8") else self._g8
+        self._g8 = g8
+        g8.zero_()
+        ops.gemm(self.drel, pooled, g8, None, None, None, 8, d, B, 8, d, d, a_kmajor=0, b_kmajor=0, out_f32=True)
+        self.gwr.add_(g8[:2])
+        gb8 = torch.zeros(8, dtype=torch.float32, device=e.dev) if not hasattr(self, "_gb8") else self._gb8
+        self._gb8 = gb8
+        gb8.zero_()
+        ops.colsum(self.drel, gb8, B, 8, 8, ws=e.ws)
+        self.gbr.add_(gb8[:2])
+        w8 = torch.zeros(8, d, dtype=e.cdtype, device=e.dev) if not hasattr(self, "_w8") else self._w8
+        self._w8 = w8
+        w8[:2].copy_(self.wr)
+        ops.gemm(self.drel, w8, self.dpooled, None, None, None, B, d, 8, 8, d, d, a_kmajor=1, b_kmajor=0)
+        e.pooler_backward(self.dpooled, self.dz, cls_rows, d_cls)
+        return self.loss
 
 
 class Engine:
@@ -344,8 +440,9 @@ class Engine:
         self.labels = torch.full((B, V), -100, dtype=torch.int64, device=self.dev)
         self.task = getattr(store, "task", "vis_mask")
         self.answer = AnswerHead(self, store.num_answers) if self.task == "vqa" else None
-        if self.task == "vqa":
-            assert need_lang, "the VQA head reads pooled_output: build the engine with need_lang=True"
+        self.lang_heads = LangHeads(self) if self.task in ("word_mask", "matched") else None
+        if self.task in ("vqa", "word_mask", "matched"):
+            assert need_lang, "this task reads the language / pooled output: build the engine with need_lang=True"
         # ---- head (ref lxrt/modeling.py:38-53) + losses
         h = "obj_predict_head"
         self.hd = {k: (st.cview(n) if c else st.view(n), st.gview(n)) for k, n, c in (
@@ -357,7 +454,7 @@ class Engine:
         self.t_pre, self.t_h, self.t_y = self.act(self.MV, d), self.act(self.MV, d), self.act(self.MV, d)
         self.t_mean, self.t_rstd = self.f32(self.MV), self.f32(self.MV)
         self.feat = self.act(self.MV, self.F)
-        n_head_rows = self.MV if self.task != "vqa" else 8          # the codebook head is not part of the VQA model
+        n_head_rows = self.MV if self.task in ("vis_mask", "all") else 8     # the codebook head is only read by vis_mask steps
         self.logits = torch.zeros(n_head_rows, self.K, dtype=torch.float32, device=self.dev)
         self.dlogits = self.act(n_head_rows, self.Kp)
         self.dfeat = self.act(self.MV, self.F)
@@ -597,6 +694,47 @@ class Engine:
             ops.featloss_fwd_bwd(self.feat, self.store.centroids_c, self.cid, self.vmask, self.nmask,
                                  self.dfeat if want_grad else None, self.losses[1:], self.B, self.V, F, 1.0)
         return self.losses
+
+    def pooler_backward(self, dpooled, dz, cls_rows, d_cls):
+        """LxmertPooler backward (HF:566-572): pooled = tanh(W_p cls + b_p).  cls_rows / d_cls are [B, d] views of the
+        language output / its gradient with row stride L*d (the [CLS] rows)."""
+        ops, st, d, B, L = self.ops, self.store, self.d, self.B, self.L
+        ops.tanh_bwd(dpooled, self.pooled, dz, B * d)
+        ops.colsum(dz, st.gview("bert.pooler.dense.bias"), B, d, d, ws=self.ws)
+        self.wgrad_defer(dz, cls_rows, st.gview("bert.pooler.dense.weight"), d, d, B, d, L * d, d)
+        self.wgrad_flush()
+        ops.gemm(dz, st.cview("bert.pooler.dense.weight"), d_cls, None, None, None, B, d, d, d, d, L * d,
+                 a_kmajor=1, b_kmajor=0)
+
+    def word_mask_forward_backward(self, word_labels):
+        """XLxmertForPretraining.forward(task='word_mask') + backward (ref lxrt/modeling.py:211-219): un-masked codebook
+        features in (set_inputs(cluster_ids=..., vis_mask=None)), MLM loss over `word_labels` (negative = ignored)."""
+        lh = self.lang_heads
+        wl = word_labels.clone()
+        wl[wl < 0] = -100               # the reference's data code writes -1, its loss ignores -100: any negative = not masked
+        lh.word_labels.copy_(wl, non_blocking=True)
+        self.encoder_forward(want_pooled=False)
+        lh.mlm_fwd(self.lang_final)
+        self.zero_accumulated_grads()
+        self.GA.zero_()
+        loss = lh.mlm_loss_bwd(self.GA[:self.ML])
+        self._ready("cls.")
+        self.encoder_backward(True)
+        return loss[0:1]
+
+    def matched_forward_backward(self, matched_labels):
+        """XLxmertForPretraining.forward(task='matched') + backward (ref lxrt/modeling.py:221-229)."""
+        lh = self.lang_heads
+        lh.matched_labels.copy_(matched_labels, non_blocking=True)
+        self.encoder_forward(want_pooled=True)
+        lh.rel_fwd(self.pooled)
+        self.zero_accumulated_grads()
+        self.GA.zero_()
+        cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
+        loss = lh.rel_loss_bwd(self.pooled, cls_rows, self.GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
+        self._ready("cls.")
+        self.encoder_backward(True)
+        return loss[1:2]
 
     def vqa_forward(self):
         """VQAModel.forward (ref tasks/vqa_model.py:22-72): real grid features -> encoder -> pooled_output -> answer head."""

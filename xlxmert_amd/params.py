@@ -55,7 +55,10 @@ def build_units(cfg, task="vis_mask", num_answers=0):
     -> LxmertVisualAnswerHead, ref tasks/vqa_model.py:7-72; the codebook head and mask_feat are not part of that model)."""
     d, dff, F, P = cfg.hidden_size, cfg.intermediate_size, cfg.visual_feat_dim, cfg.visual_pos_dim
     units = []
-    pretrain = task != "vqa"
+    # which heads a step of this task reads (everything else gets no gradient in the reference and must stay untouched):
+    #   "word_mask" / "matched": the language pretraining branches (ref lxrt/modeling.py:211-235) -- language output or
+    #   pooled_output only; un-masked codebook features in.  "all": every head of the pretraining model is live.
+    pretrain = task in ("vis_mask", "all")
 
     def U(region, used, *members):
         units.append(Unit([Member(n, tuple(s)) for n, s in members], region, used))
@@ -103,13 +106,13 @@ def build_units(cfg, task="vis_mask", num_answers=0):
         lang_used = not (task == "vis_mask" and i == cfg.x_layers - 1)
         # ... and the VQA step never reads the VISUAL output of the last cross layer (only pooled_output): its visual
         # self-attention / FFN get no gradient in the reference, so the optimizer must not touch them
-        vis_used = not (task == "vqa" and i == cfg.x_layers - 1)
+        vis_used = not (task in ("vqa", "word_mask", "matched") and i == cfg.x_layers - 1)
         att(p + ".visual_attention", "att")
         att(p + ".lang_self_att", "self", lang_used)
         att(p + ".visn_self_att", "self", vis_used)
         ffn(p + ".lang_inter", p + ".lang_output", lang_used)
         ffn(p + ".visn_inter", p + ".visn_output", vis_used)
-    pooled_used = task != "vis_mask"
+    pooled_used = task in ("vqa", "matched", "all")
     U("mat", pooled_used, ("bert.pooler.dense.weight", (d, d)))
     U("vec", pooled_used, ("bert.pooler.dense.bias", (d,)))
     h = "obj_predict_head"
@@ -120,6 +123,17 @@ def build_units(cfg, task="vis_mask", num_answers=0):
     U("mat", pretrain, (f"{h}.linear_feat.weight", (F, d)))
     U("vec", pretrain, (f"{h}.linear_feat.bias", (F,)))
     U("vec", pretrain, (f"{h}.out_cluster.bias", (cfg.num_clusters,)))
+    if task in ("word_mask", "matched", "all"):
+        c = "cls"                                        # LxmertPreTrainingHeads (HF:589-657); decoder.weight is tied to
+        mlm = task in ("word_mask", "all")               # the word embeddings and therefore not a unit of its own
+        U("mat", mlm, (f"{c}.predictions.transform.dense.weight", (d, d)))
+        U("vec", mlm, (f"{c}.predictions.transform.dense.bias", (d,)))
+        U("vec", mlm, (f"{c}.predictions.transform.LayerNorm.weight", (d,)))
+        U("vec", mlm, (f"{c}.predictions.transform.LayerNorm.bias", (d,)))
+        U("vec", mlm, (f"{c}.predictions.bias", (cfg.vocab_size,)))
+        rel = task in ("matched", "all")
+        U("vec", rel, (f"{c}.seq_relationship.weight", (2, d)))
+        U("vec", rel, (f"{c}.seq_relationship.bias", (2,)))
     if task == "vqa":
         a = "answer_head.logit_fc"                       # nn.Sequential indices of HF:606-611
         U("mat", True, (f"{a}.0.weight", (2 * d, d)))
@@ -133,7 +147,7 @@ def build_units(cfg, task="vis_mask", num_answers=0):
 
 def _backward_rank(cfg, name):
     """position of a tensor's block in the backward pass (stable sort keeps the order inside a block)."""
-    if name.startswith("obj_predict_head.") or name.startswith("answer_head."):
+    if name.startswith("obj_predict_head.") or name.startswith("answer_head.") or name.startswith("cls."):
         return 0
     if ".x_layers." in name:
         return 1 + (cfg.x_layers - 1 - int(name.split(".x_layers.")[1].split(".")[0]))
@@ -253,6 +267,8 @@ class ParamStore:
 
     def named_state(self):
         out = {n: self.view(n) for n in self.index}
+        if "cls.predictions.bias" in self.index:
+            out["cls.predictions.decoder.weight"] = self.view("bert.embeddings.word_embeddings.weight")      # tied
         if self.centroids is not None:
             out["vis_emb.weight"] = self.centroids
             out["obj_predict_head.out_cluster.weight"] = self.centroids

@@ -52,8 +52,10 @@ class PretrainStep:
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=True, train_dropout=False, store=None,
                  bucket_mb=128, ops=None, task="vis_mask", num_answers=0):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
-        task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py) or "vqa" (VQA/GQA fine-tune step
-        on real grid features with `num_answers` answers, ref tasks/vqa.py:166-198) -- same clip / AdamW / schedule."""
+        task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
+        language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
+        ref tasks/vqa.py:166-198) -- same clip / AdamW / schedule.  One task per step object: the reference's round-robin
+        over tasks on ONE parameter set (a different optimizer range every step) is not built."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -63,7 +65,7 @@ class PretrainStep:
         self.ops = ops if ops is not None else HipOps(dtype)
         if store is None:
             init_reference_weights(self.store, seed)          # same seed on every rank == DDP's rank-0 broadcast
-        self.engine = Engine(cfg, self.store, self.ops, batch_size, text_len, n_grids, need_lang=(task == "vqa"),
+        self.engine = Engine(cfg, self.store, self.ops, batch_size, text_len, n_grids, need_lang=(task != "vis_mask"),
                              train_dropout=train_dropout)
         self.engine.sync_compute_weights()
         self.store.ensure_adam_state()
@@ -118,6 +120,20 @@ class PretrainStep:
         am = batch.get("attention_mask")
         if am is None:
             am = ids > 0                                       # ref lxmert_pretrain.py:206 / tasks/vqa.py:178
+        if self.task in ("word_mask", "matched"):
+            # language pretraining branches (ref lxmert_pretrain.py:159-160,180-182,192-195): un-masked codebook features;
+            # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels | matched_labels
+            eng.set_step_seed(self.t * self.world + self.rank)
+            eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"])
+            if self.world > 1:
+                self._begin_exchange()
+                eng.grad_ready = self._on_grad_ready
+            loss = (eng.word_mask_forward_backward(batch["word_labels"]) if self.task == "word_mask"
+                    else eng.matched_forward_backward(batch["matched_labels"]))
+            if self.world > 1:
+                self._finish_exchange()
+            self.optimizer_step()
+            return loss
         if self.task == "vqa":
             # batch: input_ids (word_ids), visual_feats [B,V,F] (vis_feats), visual_pos (boxes), targets [B,A] soft scores
             eng.set_step_seed(self.t * self.world + self.rank)
