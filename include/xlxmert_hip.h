@@ -195,7 +195,14 @@ int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const float* count
  * loss_out[0] += mean_b( sum_v mask*mean_F sl1 / max(nmask_b,1) ); dpred written for every row. */
 int xl_featloss_fwd_bwd(const void* pred, const void* centroids, const int64_t* cluster_ids,
                         const uint8_t* vis_mask, const float* nmask, void* dpred, float* loss_out,
-                        int B, int V, int F, float grad_scale, int dtype, void* stream);
+                        int B, int V, int F, float grad_scale, const int* rows, int n_rows, int dtype, void* stream);
+/* Both head losses only read the masked positions (labels are -100 / the SmoothL1 term is multiplied by vis_mask elsewhere:
+ * ref lxrt/modeling.py:253-256, 273-287), so the training step runs the head on the masked rows only:
+ * xl_gather_rows: dst[r,:] = src[rows[r],:]; xl_scatter_rows: dst[rows[r],:] = src[r,:]  (rows: int32 [n_rows], ascending row
+ * ids b*V+v of the masked positions; N, ld multiples of the 16-byte vector).  xl_featloss_fwd_bwd with rows != NULL takes
+ * pred / dpred with one row per entry of `rows`. */
+int xl_gather_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype, void* stream);
+int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- optimizer side (ref lxmert_pretrain.py:343-364)
  * sumsq[0] += sum g^2 over n fp32 elements */

@@ -268,17 +268,27 @@ class FakeOps:
             g = g * valid[:, None] * (grad_scale / cnt)
             v2(dlogits, M, K, lddl).copy_(g)
 
-    def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F, grad_scale=1.0):
-        M = B * V
+    def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F, grad_scale=1.0,
+                         rows=None, n_rows=0):
+        g = torch.arange(B * V) if rows is None else rows.view(-1)[:n_rows].long()
+        M = g.numel()
         p = v2(pred, M, F, F).float()
-        t = centroids[cluster_ids.view(-1)].float()
+        t = centroids[cluster_ids.view(-1)[g]].float()
         d = p - t
         sl1 = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5).mean(1)
-        w = (vis_mask.view(-1) != 0).float() / (nmask.clamp(min=1).repeat_interleave(V) * B)
+        w = ((vis_mask.view(-1) != 0).float() / (nmask.clamp(min=1).repeat_interleave(V) * B))[g]
         if loss_out is not None:
             loss_out[0] += (w * sl1).sum()
         if dpred is not None:
             v2(dpred, M, F, F).copy_(grad_scale * w[:, None] / F * d.clamp(-1, 1))
+
+    def gather_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
+        g = rows.view(-1)[:n_rows].long()
+        v2(dst, n_rows, N, ld_dst).copy_(torch.as_strided(src, (int(g.max()) + 1, N), (ld_src, 1))[g])
+
+    def scatter_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
+        g = rows.view(-1)[:n_rows].long()
+        torch.as_strided(dst, (int(g.max()) + 1, N), (ld_dst, 1))[g] = v2(src, n_rows, N, ld_src)
 
     def sumsq(self, g, out, n):
         out[0] += (g[:n].double() ** 2).sum().float()

@@ -565,14 +565,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pred, const T* __restrict__ cent,
                                                        const int64_t* __restrict__ cid, const uint8_t* __restrict__ mask,
                                                        const float* __restrict__ nmask, T* __restrict__ dpred,
-                                                       float* loss_out, int B, int V, int F, float grad_scale) {
+                                                       float* loss_out, int B, int V, int F, float grad_scale,
+                                                       const int* __restrict__ rows, int n_rows) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (row >= B * V) return;
-    const int b = row / V;
-    const float w = mask[row] ? 1.0f / (fmaxf(nmask[b], 1.0f) * (float)B) : 0.f;
-    const T* tgt = cent + (size_t)cid[row] * F;
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);      // row of pred / dpred
+    if (row >= n_rows) return;
+    const int gr = rows ? rows[row] : row;                       // (example, grid position) it belongs to
+    const int b = gr / V;
+    const float w = mask[gr] ? 1.0f / (fmaxf(nmask[b], 1.0f) * (float)B) : 0.f;
+    const T* tgt = cent + (size_t)cid[gr] * F;
     float s = 0.f;
     for (int col = lane * VEC; col < F; col += 64 * VEC) {
         float p[VEC], t[VEC], g[VEC];
@@ -657,6 +659,21 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(const int* __restri
                                                              int64_t* __restrict__ ids, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n && mask[i]) ids[i] = pred[i];
+}
+
+// ------------------------------------------------------------------ row compaction of the masked-token head
+// dst[r, :] = src[rows[r], :] (gather) / dst[rows[r], :] = src[r, :] (scatter); N a multiple of the 16-byte vector.
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(const T* __restrict__ src, const int* __restrict__ rows, T* __restrict__ dst,
+                                                        int n_rows, int N, int lds, int ldd) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int g = rows[r];
+    const T* s = src + (size_t)(SCATTER ? r : g) * lds;
+    T* d = dst + (size_t)(SCATTER ? g : r) * ldd;
+    for (int col = lane * VEC; col < N; col += 64 * VEC) *reinterpret_cast<uint4*>(d + col) = *reinterpret_cast<const uint4*>(s + col);
 }
 
 }  // namespace xl
@@ -863,13 +880,15 @@ extern "C" int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const f
 
 extern "C" int xl_featloss_fwd_bwd(const void* pred, const void* centroids, const int64_t* cluster_ids,
                                    const uint8_t* vis_mask, const float* nmask, void* dpred, float* loss_out,
-                                   int B, int V, int F, float grad_scale, int dtype, void* stream) {
+                                   int B, int V, int F, float grad_scale, const int* rows, int n_rows, int dtype, void* stream) {
     CHECK_ROW(F, dtype);
     hipStream_t st = (hipStream_t)stream;
-    const int M = B * V;
+    const int M = rows ? n_rows : B * V;
+    XL_CHECK_ARG(M > 0 && M <= B * V, XL_ERR_BAD_ARG, "xl_featloss_fwd_bwd: n_rows=%d", n_rows);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((featloss_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
-                           (const T*)pred, (const T*)centroids, cluster_ids, vis_mask, nmask, (T*)dpred, loss_out, B, V, F, grad_scale););
+                           (const T*)pred, (const T*)centroids, cluster_ids, vis_mask, nmask, (T*)dpred, loss_out, B, V, F, grad_scale,
+                           rows, M););
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
@@ -943,4 +962,31 @@ extern "C" int xl_sampler_update(const int* pred_ids, const void* vis_mask, int6
                        (const uint8_t*)vis_mask, code_ids, n);
     XL_CHECK_LAUNCH();
     return XL_OK;
+}
+
+static int move_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype, void* stream,
+                     bool scatter) {
+    XL_CHECK_ARG(src && rows && dst && n_rows > 0 && N > 0 && N % vec_of(dtype) == 0 && ld_src % vec_of(dtype) == 0 &&
+                 ld_dst % vec_of(dtype) == 0, XL_ERR_BAD_SHAPE, "xl_gather_rows / xl_scatter_rows: N=%d n_rows=%d", N, n_rows);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((n_rows + WPB - 1) / WPB);
+    if (scatter) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((move_rows_kernel<T, true>), grid, dim3(256), 0, st, (const T*)src, rows, (T*)dst,
+                                             n_rows, N, ld_src, ld_dst););
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((move_rows_kernel<T, false>), grid, dim3(256), 0, st, (const T*)src, rows, (T*)dst,
+                                             n_rows, N, ld_src, ld_dst););
+    }
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_gather_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype,
+                              void* stream) {
+    return move_rows(src, rows, dst, n_rows, N, ld_src, ld_dst, dtype, stream, false);
+}
+
+extern "C" int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype,
+                               void* stream) {
+    return move_rows(src, rows, dst, n_rows, N, ld_src, ld_dst, dtype, stream, true);
 }

@@ -438,6 +438,9 @@ class Engine:
         self.cid = torch.zeros(B, V, dtype=torch.int64, device=self.dev)
         self.vmask = torch.zeros(B, V, dtype=torch.uint8, device=self.dev)
         self.labels = torch.full((B, V), -100, dtype=torch.int64, device=self.dev)
+        self._hrows, self._hvis = None, None
+        import os
+        self.compact_head = os.environ.get("XL_COMPACT_HEAD", "1") != "0"   # training step: codebook head on the masked rows only
         self.task = getattr(store, "task", "vis_mask")
         self.answer = AnswerHead(self, store.num_answers) if self.task == "vqa" else None
         self.lang_heads = LangHeads(self) if self.task in ("word_mask", "matched") else None
@@ -462,6 +465,10 @@ class Engine:
         self.losses = self.f32(4)             # [obj_loss, feat_loss, -, -]
         self.row_lse, self.row_maxprob = self.f32(self.MV), self.f32(self.MV)
         self.row_argmax = torch.zeros(self.MV, dtype=torch.int32, device=self.dev)
+        self.mrows = torch.zeros(self.MV, dtype=torch.int32, device=self.dev)         # ids b*V+v of the masked positions
+        self._hrows_long = torch.zeros(self.MV, dtype=torch.int64, device=self.dev)
+        self.labels_c = torch.zeros(self.MV, dtype=torch.int64, device=self.dev)
+        self.n_mrows = 0
         self.mf_tmp = self.f32(d)
         self.mf_tmp_c = self.act(1, d)
         # ---- activation-gradient ping-pong
@@ -586,7 +593,9 @@ class Engine:
 
     # ------------------------------------------------------------ inputs
     def set_inputs(self, input_ids, attention_mask=None, token_type_ids=None, visual_pos=None, cluster_ids=None,
-                   vis_mask=None, obj_labels=None, visual_feats=None):
+                   vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None):
+        """masked_rows (optional): ascending ids b*V+v of the masked positions, i.e. vis_mask.flatten().nonzero(), as the data
+        loader can compute them on the CPU next to vis_mask itself; given, the step needs no host <-> device round trip."""
         B, L, V = self.B, self.L, self.V
         assert tuple(input_ids.shape) == (B, L), (input_ids.shape, (B, L))
         self.ids.copy_(input_ids, non_blocking=True)
@@ -605,6 +614,13 @@ class Engine:
             self.has_vmask = vis_mask is not None
             if vis_mask is not None:
                 self.vmask.copy_(vis_mask.reshape(B, V) != 0, non_blocking=True)
+                if self.compact_head and self.task in ("vis_mask", "all"):
+                    # the only host <-> device round trip of a step: how many positions are masked (sizes the head's launches)
+                    idx = masked_rows.reshape(-1) if masked_rows is not None else (vis_mask.reshape(-1) != 0).nonzero().reshape(-1)
+                    self.n_mrows = int(idx.numel())
+                    if self.n_mrows:
+                        self._hrows_long[:self.n_mrows].copy_(idx, non_blocking=True)
+                        self.mrows[:self.n_mrows].copy_(idx, non_blocking=True)
         else:
             self.feats.copy_(visual_feats.reshape(self.MV, self.F), non_blocking=True)
         if obj_labels is not None:
@@ -670,29 +686,50 @@ class Engine:
                      None, None, self.B, d, d, self.L * d, d, d, epilogue=EPI_TANH)
         return self.lang_final, self.vis_final, self.pooled
 
+    # The head runs either on all B*V visual rows (inference, sampler, the nn.Module API) or, inside the training step, on the
+    # masked rows only: both losses read nothing else (ref lxrt/modeling.py:253-256: labels -100 elsewhere; :273-287: the
+    # SmoothL1 term is multiplied by vis_mask), so with `--vis_mask_predict` masks (n ~ U{1..64}) half of the head's rows --
+    # and of its 10k-codebook contractions -- are never needed.  `_hrows` = None (all rows) or (rows int32, n).
+    def _head_rows(self):
+        return self._hrows[1] if self._hrows is not None else self.MV
+
     def head_forward(self, want_logits=True):
         """LxmertVisualObjHead.forward (ref lxrt/modeling.py:38-53): returns (feat, logits)."""
-        ops, d, MV, F, K = self.ops, self.d, self.MV, self.F, self.K
+        ops, d, F, K = self.ops, self.d, self.F, self.K
+        M = self._head_rows()
         hd = self.hd
-        ops.gemm(self.vis_final, hd["wt"][0], self.t_h, hd["bt"][0], None, self.t_pre, MV, d, d, d, d, d, ldx=d, epilogue=EPI_GELU)
-        ops.layernorm_fwd(self.t_h, hd["gt"][0], hd["bbt"][0], self.t_y, self.t_mean, self.t_rstd, MV, d, self.eps)
-        ops.gemm(self.t_y, hd["wf"][0], self.feat, hd["bf"][0], None, None, MV, F, d, d, d, F)
+        vis = self.vis_final
+        if self._hrows is not None:
+            vis = self.tmp("vis_c", self.MV, d)[:M]
+            ops.gather_rows(self.vis_final, self._hrows[0], vis, M, d, d, d)
+        self._hvis = vis
+        ops.gemm(vis, hd["wt"][0], self.t_h, hd["bt"][0], None, self.t_pre, M, d, d, d, d, d, ldx=d, epilogue=EPI_GELU)
+        ops.layernorm_fwd(self.t_h, hd["gt"][0], hd["bbt"][0], self.t_y, self.t_mean, self.t_rstd, M, d, self.eps)
+        ops.gemm(self.t_y, hd["wf"][0], self.feat, hd["bf"][0], None, None, M, F, d, d, d, F)
         if want_logits:
-            ops.gemm(self.feat, self.store.centroids_c, self.logits, hd["bc"][0], None, None, MV, K, F, F, F, K, out_f32=True)
+            ops.gemm(self.feat, self.store.centroids_c, self.logits, hd["bc"][0], None, None, M, K, F, F, F, K, out_f32=True)
         return self.feat, self.logits
 
     def losses_forward_backward(self, want_grad=True, feat_loss=True):
         """ref lxrt/modeling.py:237-290.  Leaves d(logits) / d(feat) for head_backward; returns the loss buffer
         [obj_loss, feat_loss] (device, fp32)."""
-        ops, MV, F, K = self.ops, self.MV, self.F, self.K
+        ops, F, K = self.ops, self.F, self.K
+        M = self._head_rows()
         self.losses.zero_()
         ops.mask_counts(self.labels, self.vmask, self.counts, self.nmask, self.B, self.V)
-        ops.ce_fwd_bwd(self.logits, self.labels, self.counts, self.dlogits if want_grad else None, self.losses[0:],
-                       None, None, None, MV, K, K, self.Kp, 1.0)
+        labels = self.labels
+        rows = None
+        if self._hrows is not None:
+            rows = self._hrows[0]
+            labels = self.labels_c[:M]
+            torch.index_select(self.labels.view(-1), 0, self._hrows_long[:M], out=labels)
+        ops.ce_fwd_bwd(self.logits, labels, self.counts, self.dlogits if want_grad else None, self.losses[0:],
+                       None, None, None, M, K, K, self.Kp, 1.0)
         self.with_feat_loss = feat_loss
         if feat_loss:
             ops.featloss_fwd_bwd(self.feat, self.store.centroids_c, self.cid, self.vmask, self.nmask,
-                                 self.dfeat if want_grad else None, self.losses[1:], self.B, self.V, F, 1.0)
+                                 self.dfeat if want_grad else None, self.losses[1:], self.B, self.V, F, 1.0,
+                                 rows=rows, n_rows=M if rows is not None else 0)
         return self.losses
 
     def pooler_backward(self, dpooled, dz, cls_rows, d_cls):
@@ -794,26 +831,40 @@ class Engine:
     def head_backward(self, d_vis):
         """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis."""
         ops, d, MV, F, K = self.ops, self.d, self.MV, self.F, self.K
+        M = self._head_rows()
         hd = self.hd
-        ops.colsum(self.dlogits, hd["bc"][1], MV, self.Kp, self.Kp, ws=self.ws)      # pad columns are zero; the bias unit is padded
+        ops.colsum(self.dlogits, hd["bc"][1], M, self.Kp, self.Kp, ws=self.ws)      # pad columns are zero; the bias unit is padded
         dfeat = self.tmp("dfeat", MV, F)
         if self.with_feat_loss:
-            ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, self.dfeat, None, MV, F, K, self.Kp, F, F, ldr=F,
+            ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, self.dfeat, None, M, F, K, self.Kp, F, F, ldr=F,
                      a_kmajor=1, b_kmajor=0, epilogue=EPI_RESIDUAL)
         else:
-            ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, None, None, MV, F, K, self.Kp, F, F, a_kmajor=1, b_kmajor=0)
-        ops.colsum(dfeat, hd["bf"][1], MV, F, F, ws=self.ws)
-        self.wgrad_defer(dfeat, self.t_y, hd["wf"][1], F, d, MV, F, d, d)
+            ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, None, None, M, F, K, self.Kp, F, F, a_kmajor=1, b_kmajor=0)
+        ops.colsum(dfeat, hd["bf"][1], M, F, F, ws=self.ws)
+        # weight gradients contract over the rows: round a compacted row count up to the K tile with zero gradient rows
+        Mk = min(MV, (M + 63) // 64 * 64)
+        if Mk > M:
+            dfeat[M:Mk].zero_()
+        self.wgrad_defer(dfeat, self.t_y, hd["wf"][1], F, d, Mk, F, d, d)
         dty = self.tmp("dz", MV, d)
-        ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, MV, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
+        ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, M, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
         dth = self.tmp("dctx", MV, d)
-        ops.layernorm_bwd(dty, self.t_h, hd["gt"][0], self.t_mean, self.t_rstd, dth, hd["gt"][1], hd["bbt"][1], None, MV, d, ws=self.ws)
+        ops.layernorm_bwd(dty, self.t_h, hd["gt"][0], self.t_mean, self.t_rstd, dth, hd["gt"][1], hd["bbt"][1], None, M, d, ws=self.ws)
         dtp = self.tmp("dzm", MV, d)
-        ops.gelu_bwd(dth, self.t_pre, dtp, MV * d)
-        ops.colsum(dtp, hd["bt"][1], MV, d, d, ws=self.ws)
-        self.wgrad_defer(dtp, self.vis_final, hd["wt"][1], d, d, MV, d, d, d)
+        ops.gelu_bwd(dth, self.t_pre, dtp, M * d)
+        ops.colsum(dtp, hd["bt"][1], M, d, d, ws=self.ws)
+        if Mk > M:
+            dtp[M:Mk].zero_()
+        hv = self._hvis if self._hrows is None else self.tmp("vis_c", MV, d)
+        self.wgrad_defer(dtp, hv, hd["wt"][1], d, d, Mk, d, d, d)
         self.wgrad_flush()
-        ops.gemm(dtp, hd["wt"][0], d_vis, None, None, None, MV, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        if self._hrows is None:
+            ops.gemm(dtp, hd["wt"][0], d_vis, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        else:                       # gradient of the masked rows, scattered into an otherwise zero d(vision_output)
+            dvc = self.tmp("dvis_c", MV, d)
+            ops.gemm(dtp, hd["wt"][0], dvc, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+            d_vis.zero_()
+            ops.scatter_rows(dvc, self._hrows[0], d_vis, M, d, d, d)
         self._ready("obj_predict_head.")
 
     def encoder_backward(self, have_lang_grad=False):
@@ -891,9 +942,14 @@ class Engine:
         """XLxmertForPretraining.forward(task='vis_mask') + loss.backward() (ref lxrt/modeling.py:154-308,
         lxmert_pretrain.py:338).  Gradients land in store.grad; returns the device loss buffer."""
         self.encoder_forward(want_pooled=False)
-        self.head_forward()
-        self.zero_accumulated_grads()
-        losses = self.losses_forward_backward(True, feat_loss)
-        self.head_backward(self.GA[self.ML:])
+        use_rows = self.compact_head and self.has_vmask and 0 < self.n_mrows < self.MV
+        self._hrows = (self.mrows, self.n_mrows) if use_rows else None
+        try:
+            self.head_forward()
+            self.zero_accumulated_grads()
+            losses = self.losses_forward_backward(True, feat_loss)
+            self.head_backward(self.GA[self.ML:])
+        finally:
+            self._hrows = None
         self.encoder_backward(False)
         return losses

@@ -161,12 +161,17 @@ class HipOps:
                       float(grad_scale), self.dt, self._stream())
 
     def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F,
-                         grad_scale=1.0):
+                         grad_scale=1.0, rows=None, n_rows=0):
         self.lib.call("xl_featloss_fwd_bwd", self._p(pred), self._p(centroids), self._p(cluster_ids),
                       self._p(vis_mask), self._p(nmask), self._p(dpred), self._p(loss_out), B, V, F, float(grad_scale),
-                      self.dt, self._stream())
+                      self._p(rows), int(n_rows), self.dt, self._stream())
 
-    # -- optimizer side
+    def gather_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
+        self.lib.call("xl_gather_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
+
+    def scatter_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
+        self.lib.call("xl_scatter_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
+
     def sumsq(self, g, out, n):
         self.lib.call("xl_sumsq", self._p(g), self._p(out), n, self._stream())
 

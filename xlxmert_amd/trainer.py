@@ -152,7 +152,7 @@ class PretrainStep:
             labels[~batch["vis_mask"].bool()] = -100           # ref lxmert_pretrain.py:163-166
         eng.set_step_seed(self.t * self.world + self.rank)
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
-                       vis_mask=batch["vis_mask"], obj_labels=labels)
+                       vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"))
         if self.world > 1:
             self._begin_exchange()
             eng.grad_ready = self._on_grad_ready
@@ -206,5 +206,6 @@ def synthetic_batch(cfg, B, L=20, grid=8, seed=9595, device="cpu", ragged=True):
         for j in range(grid):
             pos[i * grid + j] = torch.tensor([j / grid, i / grid, (j + 1) / grid, (i + 1) / grid])
     batch = {"input_ids": ids, "attention_mask": ids > 0, "token_type_ids": torch.zeros_like(ids),
-             "cluster_ids": cid, "vis_mask": vm, "obj_labels": lab, "visual_pos": pos[None].expand(B, -1, -1).contiguous()}
+             "cluster_ids": cid, "vis_mask": vm, "obj_labels": lab, "visual_pos": pos[None].expand(B, -1, -1).contiguous(),
+             "masked_rows": vm.reshape(-1).nonzero().reshape(-1)}      # computed where the mask is drawn: on the host
     return {k: v.to(device) for k, v in batch.items()}
