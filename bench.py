@@ -202,9 +202,14 @@ def main():
                                    "masked-visual-token step fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world,
                        "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}",
                        "dropout": "off (eval-parity mode)" if args.no_dropout else "0.1 hidden + 0.1 attention (training mode, 94 sites)",
-                       "loss": round(loss_val, 4)},
+                       "loss": round(loss_val, 4),
+                       "vis_mask": "--vis_mask_predict masks, n ~ U{1..64} per image (ref lxmert_data.py:414-419)",
+                       "head_rows": "codebook head + both losses on the masked rows only (exact: the reference's losses read "
+                                    "nothing else); all rows with XL_COMPACT_HEAD=0"},
             "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
-            "step_mfma_frac": round(value / world * GFLOP_PER_EXAMPLE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            # whole-step MFMA utilisation from the dense-contraction FLOPs actually EXECUTED in a step (the head runs on the
+            # masked rows only, so this is below the contract figure 50.782 GFLOP/example x batch)
+            "step_mfma_frac": round(gt.flops / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel + gemm_bf16_mfma_kernel (all dense contractions of one step, grouped weight gradients included)",
                          "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
