@@ -530,3 +530,39 @@ def test_remask_lowest_and_sampler_update(V, n_mask):
     ids = torch.randint(0, 10000, (B, V), generator=g)
     cpu2, gpu2 = run_both(torch.float32, "sampler_update", [pred, cpu[1], ids, B * V])
     assert torch.equal(gpu2[2], cpu2[2])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gather_scatter_rows_and_row_mapped_featloss(dtype):
+    g = torch.Generator().manual_seed(17)
+    B, V, F = 5, 16, 64
+    M = B * V
+    src = rnd(g, M, F, dtype=dtype)
+    mask = (torch.rand(B, V, generator=g) < 0.4)
+    mask[0, 0] = True
+    rows = mask.reshape(-1).nonzero().reshape(-1).int()
+    n = rows.numel()
+    dst = torch.zeros(M, F, dtype=dtype)
+    cpu, gpu = run_both(dtype, "gather_rows", [src, rows, dst, n, F, F, F])
+    assert torch.equal(gpu[2][:n], src[rows.long()]) and torch.equal(gpu[2], cpu[2])
+    back = torch.zeros(M, F, dtype=dtype)
+    cpu, gpu = run_both(dtype, "scatter_rows", [dst.clone().copy_(gpu[2]), rows, back, n, F, F, F])
+    ref = torch.zeros(M, F, dtype=dtype)
+    ref[rows.long()] = src[rows.long()]
+    assert torch.equal(gpu[2], ref)
+    # feature loss on the compacted rows == feature loss on all rows (un-masked rows carry zero weight)
+    cent = rnd(g, 30, F, dtype=dtype).relu()
+    cid = torch.randint(0, 30, (B, V), generator=g)
+    nmask = mask.sum(1).float()
+    pred_all = rnd(g, M, F, dtype=dtype)
+    ops = hip(dtype)
+    loss_a, loss_c = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    d_all = torch.zeros(M, F, dtype=dtype, device="cuda")
+    d_c = torch.zeros(n, F, dtype=dtype, device="cuda")
+    m8 = mask.to(torch.uint8).cuda()
+    ops.featloss_fwd_bwd(pred_all.cuda(), cent.cuda(), cid.cuda(), m8, nmask.cuda(), d_all, loss_a, B, V, F)
+    ops.featloss_fwd_bwd(pred_all[rows.long()].contiguous().cuda(), cent.cuda(), cid.cuda(), m8, nmask.cuda(), d_c, loss_c, B, V, F,
+                         rows=rows.cuda(), n_rows=n)
+    torch.cuda.synchronize()
+    assert abs(loss_a.item() - loss_c.item()) <= 1e-5 * max(1.0, abs(loss_a.item()))
+    assert torch.equal(d_all[rows.long().cuda()], d_c)
