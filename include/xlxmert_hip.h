@@ -63,7 +63,8 @@ int  xl_gemm_trace(void* buffer);
  *   backward dW = dy^T x  (fp32 out, accumulate!=0 adds into C; split-K uses fp32 atomics)  : a_kmajor=0,b_kmajor=0
  *   in_dtype: element type of A,B,residual,aux.  out_dtype: element type of C (XL_F32 allowed with bf16 inputs).
  *   bias: fp32 [N] or NULL.  residual/aux: [M,N] with ldr/ldx or NULL.
- *   dropout (XL_EPI_RESIDUAL only): keep-prob (1-p_drop), mask = hash(seed, m*N+n); p_drop=0 disables.
+ *   dropout (XL_EPI_RESIDUAL only): keep-prob (1-p_drop), mask = hash(seed, row m, column pair n>>1) -> one 16-bit draw per
+ *     column (csrc/common.h dropout_draw16); p_drop=0 disables.
  *   colsum_out: NULL, or fp32 [N]: colsum_out[n] += sum_m C[m,n] over the values as stored in C (the bias gradient of the
  *     Linear layer whose output gradient C is, e.g. d(pre-activation) -> d(intermediate.dense.bias), HF:325-331); needs
  *     colsum_ws with xl_workspace_floats(N) floats.  Computed in the epilogue when every output tile is interior and
@@ -138,7 +139,7 @@ int xl_masked_colsum(const void* x, const uint8_t* mask, float* out, int M, int 
 /* out[n] += sum_m x[m,n]   (bias gradients) */
 int xl_colsum(const void* x, float* out, int M, int N, int ldx, float* workspace, int dtype, void* stream);
 
-/* y[i] = x[i] * (keep(seed, i) ? 1/(1-p) : 0), i in [0, M*N) with i = m*N + n (rows of ldx / ldy elements): the
+/* y[m,n] = x[m,n] * (keep(seed, m, n) ? 1/(1-p) : 0) (rows of ldx / ldy elements): the
  * counter-based mask used by every dropout site of the path (HF:213,258,278,340,475); calling it again with the same
  * (seed, p) on a gradient applies the identical mask (backward).  In-place (y == x) allowed. */
 int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy, float p_drop, uint64_t seed, int dtype, void* stream);
@@ -170,7 +171,7 @@ int xl_sampler_update(const int* pred_ids, const void* vis_mask, int64_t* code_i
  * q/k/v/o are [B, n, H*dh]-shaped views with row strides ldq/ldk/ldv/ldo (elements); head h
  * occupies columns [h*dh, (h+1)*dh).  key_mask: uint8 [B,nk] or NULL.  lse: fp32 [B,H,nq]
  * (log-sum-exp of the scaled scores) saved for backward.  Probability dropout (HF:258):
- * p_drop with mask hash(seed, ((b*H+h)*nq+q)*nk+key). */
+ * p_drop with mask hash(seed, row = (b*H+h)*nq+q, column = key). */
 int xl_sdpa_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
                 void* o, float* lse, int B, int H, int nq, int nk, int dh,
                 int ldq, int ldk, int ldv, int ldo, float scale,

@@ -22,23 +22,25 @@ def gelu_grad(x):
     return cdf + x * pdf
 
 
-def keep_scale(seed, idx, p_drop):
-    """Host restatement of csrc/common.h hash_u32()/dropout_scale(): 32-bit multiply-xorshift mixer of the index folded
-    with both halves of the seed; keep iff the draw >= p*2^32.  idx: int64 tensor.  Returns float32 0 or 1/(1-p)."""
+def keep_scale(seed, row, col, p_drop):
+    """Host restatement of csrc/common.h dropout_draw16()/dropout_scale(): one 32-bit multiply-xorshift mix of
+    (row, col >> 1, seed) gives two 16-bit draws (even / odd column); keep iff draw >= p * 2^16.
+    row, col: broadcastable int64 tensors.  Returns float32 0 or 1/(1-p)."""
     import numpy as np
     u32 = np.uint32
-    i64 = idx.numpy().astype(np.uint64)
-    lo, hi = (i64 & np.uint64(0xFFFFFFFF)).astype(u32), (i64 >> np.uint64(32)).astype(u32)
+    row, col = torch.broadcast_tensors(torch.as_tensor(row), torch.as_tensor(col))
+    r = (row.numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)).astype(u32)
+    c = (col.numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)).astype(u32)
     s_lo, s_hi = u32(seed & 0xFFFFFFFF), u32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        h = lo * u32(0x9E3779B1) ^ hi * u32(0x85EBCA77) ^ s_lo
+        mix = s_lo ^ (s_hi * u32(0xC2B2AE3D))
+        h = r * u32(0x9E3779B1) ^ (c >> u32(1)) * u32(0x85EBCA77) ^ mix
         h ^= h >> u32(16); h = h * u32(0x7FEB352D)
         h ^= h >> u32(15); h = h * u32(0x846CA68B)
-        h ^= h >> u32(16); h ^= s_hi * u32(0xC2B2AE3D)
-        h ^= h >> u32(15); h = h * u32(0x2C1B3C6D)
-        h ^= h >> u32(13)
-    thr = np.uint64(int(np.float32(p_drop) * np.float32(4294967296.0)))
-    keep = (h.astype(np.uint64) >= thr).astype(np.float32) * np.float32(1.0 / (1.0 - p_drop))
+        h ^= h >> u32(16)
+    draw = np.where((c & u32(1)) != 0, h >> u32(16), h & u32(0xFFFF))
+    thr = u32(int(np.float32(p_drop) * np.float32(65536.0)))
+    keep = (draw >= thr).astype(np.float32) * np.float32(1.0 / (1.0 - p_drop))
     return torch.from_numpy(keep)
 
 
@@ -63,8 +65,7 @@ class FakeOps:
             acc = torch.nn.functional.gelu(acc)
         elif epilogue == EPI_RESIDUAL:
             if p_drop > 0:
-                idx = torch.arange(M)[:, None] * N + torch.arange(N)[None, :]
-                acc = acc * keep_scale(seed, idx, p_drop)
+                acc = acc * keep_scale(seed, torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop)
             acc = acc + v2(residual, M, N, ldr).float()
         elif epilogue == EPI_DGELU:
             acc = acc * gelu_grad(v2(aux, M, N, ldx).float())
@@ -116,8 +117,7 @@ class FakeOps:
         dgamma.add_(dg)
         dbeta.add_(db)
         if dx_dropped is not None and p_drop > 0:
-            idx = torch.arange(M)[:, None] * N + torch.arange(N)[None, :]
-            d = d * keep_scale(seed, idx, p_drop)                           # the kernel masks the fp32 value, then rounds
+            d = d * keep_scale(seed, torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop)                         # the kernel masks the fp32 value, then rounds
             v2(dx_dropped, M, N, N).copy_(d)
         if dbias_prev is not None:
             dbias_prev.add_(d.sum(0))
@@ -173,8 +173,7 @@ class FakeOps:
         torch.as_strided(out, (N,), (1,)).add_(v2(x, M, N, ldx).float().sum(0))
 
     def dropout(self, x, y, M, N, ldx, ldy, p_drop, seed):
-        idx = torch.arange(M)[:, None] * N + torch.arange(N)[None, :]
-        v2(y, M, N, ldy).copy_(v2(x, M, N, ldx).float() * keep_scale(seed, idx, p_drop))
+        v2(y, M, N, ldy).copy_(v2(x, M, N, ldx).float() * keep_scale(seed, torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop))
 
     def gelu_bwd(self, dy, pre, dx, n):
         dx.view(-1)[:n].copy_(dy.reshape(-1)[:n].float() * gelu_grad(pre.reshape(-1)[:n].float()))
@@ -211,8 +210,8 @@ class FakeOps:
     def _pmask(B, H, nq, nk, p_drop, seed):
         if p_drop == 0:
             return 1.0
-        idx = torch.arange(B * H * nq * nk).view(B, H, nq, nk)          # ((b*H+h)*nq+q)*nk+key
-        return keep_scale(seed, idx, p_drop)
+        row = torch.arange(B * H * nq).view(B, H, nq, 1)                # (b*H+h)*nq+q
+        return keep_scale(seed, row, torch.arange(nk).view(1, 1, 1, nk), p_drop)
 
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
         Q, K_, V_ = (self._heads(t, B, n, H, dh, ld).float() for t, n, ld in ((q, nq, ldq), (k, nk, ldk), (v, nk, ldv)))

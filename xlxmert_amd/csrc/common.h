@@ -131,22 +131,23 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 }
 
 // ------------------------------------------------------------------ counter-based dropout
-// keep-mask draw for element `idx` under (seed): a 32-bit multiply-xorshift mixer (two rounds, "lowbias32" constants)
-// over the index folded with both halves of the seed -- ~10 integer instructions per element.
-__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-    uint32_t h = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
+// keep-mask draw for element (row, col) under (seed): one 32-bit multiply-xorshift mix ("lowbias32" constants) of
+// (row, col >> 1, seed) yields TWO 16-bit draws, for the even and the odd column of the pair; keep iff draw >= p * 2^16.
+// Integer multiplies are quarter rate on CDNA, and the mask is evaluated up to three times per element of a step (GEMM
+// epilogue / LayerNorm backward / attention forward + two backward passes): an 8-column row segment now costs 1 + 4 x 3
+// multiplies instead of 8 x 5 (one hash per element over a 64-bit linear index with three rounds).
+__device__ __forceinline__ uint32_t dropout_seed_mix(uint64_t seed) { return (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0xC2B2AE3Du; }
+__device__ __forceinline__ uint32_t dropout_draw16(uint32_t seedmix, uint32_t row, uint32_t col) {
+    uint32_t h = row * 0x9E3779B1u ^ (col >> 1) * 0x85EBCA77u ^ seedmix;
     h ^= h >> 16; h *= 0x7FEB352Du;
     h ^= h >> 15; h *= 0x846CA68Bu;
-    h ^= h >> 16; h ^= (uint32_t)(seed >> 32) * 0xC2B2AE3Du;
-    h ^= h >> 15; h *= 0x2C1B3C6Du;
-    h ^= h >> 13;
-    return h;
+    h ^= h >> 16;
+    return (col & 1u) ? (h >> 16) : (h & 0xffffu);
 }
 // returns 1/(1-p) if kept, 0 if dropped
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
-    const uint32_t r = hash_u32(seed, idx);
-    const uint32_t thr = (uint32_t)(p_drop * 4294967296.0f);
-    return r >= thr ? inv_keep : 0.0f;
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t row, uint32_t col, float p_drop, float inv_keep) {
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f);
+    return dropout_draw16(dropout_seed_mix(seed), row, col) >= thr ? inv_keep : 0.0f;
 }
 
 extern int g_use_tr_read;   // set by xl_set_lds_transpose_read

@@ -32,7 +32,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
             break;
         }
         case XL_EPI_RESIDUAL: {
-            if (p.p_drop > 0.0f) v *= dropout_scale(p.seed, (uint64_t)m * (uint64_t)p.N + n, p.p_drop, p.inv_keep);
+            if (p.p_drop > 0.0f) v *= dropout_scale(p.seed, (uint32_t)m, (uint32_t)n, p.p_drop, p.inv_keep);
             const TIn* res = reinterpret_cast<const TIn*>(p.residual);
             v += Elem<TIn>::ld(res + (size_t)m * p.ldr + n);
             break;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, float* wbuf, 
                 if (p.p_drop > 0.0f) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        v[e] *= dropout_scale(p.seed, (uint64_t)m * (uint64_t)p.N + n + e, p.p_drop, p.inv_keep);
+                        v[e] *= dropout_scale(p.seed, (uint32_t)m, (uint32_t)(n + e), p.p_drop, p.inv_keep);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
@@ -334,7 +334,7 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
             unpack8(op.row[ps], rv);
             if (drop) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(p.seed, (uint64_t)m * (uint64_t)p.N + n + e, p.p_drop, p.inv_keep);
+                for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(p.seed, (uint32_t)m, (uint32_t)(n + e), p.p_drop, p.inv_keep);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 if (dx_drop != nullptr) {          // gradient through the dropout of the dense layer feeding this LN
 #pragma unroll
                     for (int i = 0; i < VEC; ++i)
-                        o[i] *= dropout_scale(seed, (uint64_t)row * (uint64_t)N + col + i, p_drop, inv_keep);
+                        o[i] *= dropout_scale(seed, (uint32_t)row, (uint32_t)(col + i), p_drop, inv_keep);
                     stvec(dx_drop + (size_t)row * N + col, o);
                 }
 #pragma unroll
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
         float v[VEC];
         ldvec(x + (size_t)m * ldx + c, v);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] *= dropout_scale(seed, (uint64_t)m * (uint64_t)N + c + j, p_drop, inv_keep);
+        for (int j = 0; j < VEC; ++j) v[j] *= dropout_scale(seed, (uint32_t)m, (uint32_t)(c + j), p_drop, inv_keep);
         stvec(y + (size_t)m * ldy + c, v);
     }
 }

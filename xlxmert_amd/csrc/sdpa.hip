@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void sdpa_fwd_generic(const T* __restrict__ q, 
     const float inv = 1.0f / sum;
     for (int j = 0; j < nk; ++j) {
         float p = s[j] * inv;
-        if (p_drop > 0.f) p *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + j, p_drop, inv_keep);
+        if (p_drop > 0.f) p *= dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)j, p_drop, inv_keep);
         const T* vr = v + (size_t)(b * nk + j) * ldv + h * dh;
         for (int d = 0; d < dh; ++d) acc[d] = fmaf(p, Elem<T>::ld(vr + d), acc[d]);
     }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
             float pj = expf(s0 * scale - l);
             if (key_mask && !key_mask[b * nk + j]) pj = 0.f;
             float msk = 1.f;
-            if (p_drop > 0.f) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + j, p_drop, inv_keep);
+            if (p_drop > 0.f) msk = dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)j, p_drop, inv_keep);
             p[j] = pj;
             dp[j] = g * msk;                 // d(p) through the dropout mask
             delta += pj * dp[j];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float pv = st[i][r] * inv;
-            if (DROP) pv *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + (i * 32 + acc_row(r, hi)), p_drop, inv_keep);
+            if (DROP) pv *= dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)(i * 32 + acc_row(r, hi)), p_drop, inv_keep);
             st[i][r] = pv;
         }
     __syncthreads();                      // V tile staged by all waves
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
                 const float e = __expf(st[i][r] * scale - l);
                 const float pv = ok ? e : 0.f;
                 float dp = dpt[i][r];
-                if (DROP) dp *= dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
+                if (DROP) dp *= dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)key, p_drop, inv_keep);
                 st[i][r] = pv;
                 dpt[i][r] = dp;
                 delta += pv * dp;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
                 const float e = __expf(s2[j][r] * scale - s_lse[qi]);
                 const float pv = (kok && qi < nq) ? e : 0.f;
                 float msk = 1.f;
-                if (DROP) msk = dropout_scale(seed, ((uint64_t)bh * nq + qi) * nk + key, p_drop, inv_keep);
+                if (DROP) msk = dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)key, p_drop, inv_keep);
                 const float dp = dp2[j][r] * msk;
                 dp2[j][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
                 s2[j][r] = pv * msk;                              // P~[q][key]
