@@ -210,11 +210,15 @@ int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int
 int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream);
 /* transformers==4.1.1 AdamW on flat fp32 buffers with fused gradient clipping:
  * clip = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) (max_norm<=0 disables), g' = g*clip*grad_scale;
- * decay_flags: uint8 per 256-element chunk (1 = apply weight decay).  lr_and_steps (device, fp32[4]):
- * {lr, bias_corr1 = 1-beta1^t, bias_corr2 = 1-beta2^t, unused}.  Writes the compute copy
+ * decay_flags: uint8 per 256-element chunk: bit 0 = apply weight decay, bit 1 = SKIP the chunk (a tensor that got no
+ * gradient this step: the reference resets .grad to None every step and AdamW skips such tensors -- the task round-robin
+ * of lxmert_pretrain.py:296-298 changes the set every step).  lr_and_steps (device, fp32[4]):
+ * {lr, bias_corr1 = 1-beta1^t, bias_corr2 = 1-beta2^t, unused}; chunk_steps (device int32 per chunk, may be NULL): the
+ * per-tensor update count state["step"] of transformers' AdamW -- when given, the bias corrections are computed from it
+ * instead of lr_and_steps[1..2] (the caller increments it for the chunks it does not skip).  Writes the compute copy
  * (`dtype`) of every updated parameter to p_compute (may be NULL). */
 int xl_adamw(float* p, const float* g, float* m, float* v, void* p_compute,
-             const uint8_t* decay_flags, const float* sumsq, const float* lr_and_steps,
+             const uint8_t* decay_flags, const int* chunk_steps, const float* sumsq, const float* lr_and_steps,
              int64_t n, float beta1, float beta2, float eps, float weight_decay, float max_norm,
              float grad_scale, int dtype, void* stream);
 /* dst (`dtype`) = src (fp32), n elements */

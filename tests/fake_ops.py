@@ -293,20 +293,29 @@ class FakeOps:
         out[0] += (g[:n].double() ** 2).sum().float()
 
     def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
-              max_norm, grad_scale=1.0):
+              max_norm, grad_scale=1.0, chunk_steps=None):
         lr, bc1, bc2 = (float(x) for x in lr_and_steps[:3])
         clip = grad_scale
         if max_norm > 0 and sumsq is not None:
             norm = math.sqrt(float(sumsq[0])) * grad_scale
             clip *= min(1.0, max_norm / (norm + 1e-6))
+        fl = decay_flags.repeat_interleave(256)[:n] if decay_flags is not None else torch.zeros(n, dtype=torch.uint8)
+        act = (fl & 2) == 0                                    # bit 1: tensor without a gradient this step -> untouched
         gg = g[:n] * clip
-        m[:n].mul_(beta1).add_(gg, alpha=1 - beta1)
-        v[:n].mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
-        step = lr * math.sqrt(bc2) / bc1
-        p[:n].addcdiv_(m[:n], v[:n].sqrt() + eps, value=-step)
-        if weight_decay > 0 and decay_flags is not None:
-            dec = decay_flags.repeat_interleave(256)[:n] != 0
-            p[:n][dec] -= lr * weight_decay * p[:n][dec]
+        m_new = m[:n] * beta1 + gg * (1 - beta1)
+        v_new = v[:n] * beta2 + gg * gg * (1 - beta2)
+        if chunk_steps is not None:
+            t = chunk_steps.repeat_interleave(256)[:n].double().clamp(min=1)
+            step = (lr * torch.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)).float()
+        else:
+            step = torch.full((n,), lr * math.sqrt(bc2) / bc1)
+        p_new = p[:n] - step * (m_new / (v_new.sqrt() + eps))
+        if weight_decay > 0:
+            dec = (fl & 1) != 0
+            p_new = torch.where(dec, p_new - lr * weight_decay * p_new, p_new)
+        m[:n].copy_(torch.where(act, m_new, m[:n]))
+        v[:n].copy_(torch.where(act, v_new, v[:n]))
+        p[:n].copy_(torch.where(act, p_new, p[:n]))
         if p_compute is not None and p_compute.data_ptr() != p.data_ptr():
             p_compute[:n].copy_(p[:n])
 

@@ -412,3 +412,32 @@ def test_word_mask_full_size_step_properties_bf16():
     assert 9.5 < loss.item() < 11.5, loss.item()                # ln(30522) = 10.33
     assert torch.isfinite(store.grad[:store.n_used]).all()
     assert store.gview("bert.embeddings.word_embeddings.weight")[0].abs().max().item() > 0
+
+
+def test_task_round_robin_full_size_bf16():
+    """one multi-task parameter set, full size: vis_mask / word_mask / matched steps in turn; tensors outside a step's branch
+    are bit-identical after it, everything stays finite."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig()
+    B = 64
+    tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=2, task="all", train_dropout=True, warmup_ratio=0.0,
+                      total_steps=100)
+    g = torch.Generator().manual_seed(0)
+    tr.store.view("mask_feat").copy_(torch.randn(cfg.visual_feat_dim, generator=g).relu())
+    tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
+    oc = O.OracleConfig()
+    for t, task in enumerate(["vis_mask", "word_mask", "matched"]):
+        batch = synthetic_batch(cfg, B, 20, 8, seed=40 + t)
+        wl, ml = O.make_lang_task_labels(oc, batch["input_ids"], 50 + t)
+        batch["word_labels"], batch["matched_labels"] = wl, ml
+        before = {k: tr.store.view(k).clone() for k in ("obj_predict_head.linear_feat.weight", "cls.seq_relationship.weight",
+                                                        "cls.predictions.transform.dense.weight", "bert.encoder.layer.0.output.dense.weight")}
+        loss = tr.step({k: v.cuda() for k, v in batch.items()}, task=task)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).all() and torch.isfinite(tr.store.master).all()
+        same = {k: torch.equal(before[k], tr.store.view(k)) for k in before}
+        assert same["obj_predict_head.linear_feat.weight"] == (task != "vis_mask")
+        assert same["cls.seq_relationship.weight"] == (task != "matched")
+        assert same["cls.predictions.transform.dense.weight"] == (task != "word_mask")
+        assert not same["bert.encoder.layer.0.output.dense.weight"]

@@ -408,6 +408,15 @@ def test_sumsq_adamw_cast(dtype):
         close(gpu2[i], cpu2[i], torch.float32, "adamw " + nm, f32_tol=2e-6)
     if dtype == torch.bfloat16:
         close(gpu2[4], cpu2[0], dtype, "adamw compute copy", bf16_tol=4e-3)
+    # task round-robin: skipped chunks (flag bit 1) stay bit-identical, the others use their own update count
+    flags2 = flags | ((torch.rand(n // 256, generator=g) < 0.4).to(torch.uint8) * 2)
+    steps = torch.randint(1, 9, (n // 256,), generator=g, dtype=torch.int32)
+    args = [p, gr, m, v, pc, flags2, cpu[1], lrs, n, 0.9, 0.999, 1e-6, 0.01, 1.0]
+    cpu4, gpu4 = run_both(dtype, "adamw", args, dict(grad_scale=0.5, chunk_steps=steps))
+    skip = (flags2 & 2).bool().repeat_interleave(256)
+    for i, nm in ((0, "p"), (2, "m"), (3, "v")):
+        close(gpu4[i], cpu4[i], torch.float32, "adamw(round-robin) " + nm, f32_tol=5e-6)
+        assert torch.equal(gpu4[i][skip], args[i][skip]), nm
     src = rnd(g, 1000)
     dst = torch.zeros(1000, dtype=dtype)
     cpu3, gpu3 = run_both(dtype, "cast_from_f32", [src, dst, 1000])

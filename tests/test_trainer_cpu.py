@@ -109,6 +109,60 @@ def test_vqa_two_steps_match_closed_form():
     assert torch.equal(tr.store.view(dead), sd[dead])
 
 
+def test_task_round_robin_on_one_parameter_set():
+    """vis_mask -> word_mask -> matched -> vis_mask on ONE parameter set (ref lxmert_pretrain.py:296-298).
+    The reference sets .grad = None after every step, so AdamW touches only the tensors of the step's branch and each
+    tensor keeps its own update count (bias correction); checked against the oracle with that per-tensor state."""
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    B, L, grid = 3, 8, 4
+    store = ParamStore(cfg, "cpu", torch.float32, task="all")
+    sd = O.make_cls_state_dict(oc, 11)
+    store.load_named(sd)
+    tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
+                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="all")
+    ref = {k: v.clone() for k, v in sd.items() if k != "cls.predictions.decoder.weight"}
+    ref["obj_predict_head.out_cluster.weight"] = ref["vis_emb.weight"]
+    m = {k: torch.zeros_like(v) for k, v in ref.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in ref.items()}
+    nstep = {k: 0 for k in ref}
+    for t, task in enumerate(["vis_mask", "word_mask", "matched", "vis_mask"], start=1):
+        batch = synthetic_batch(cfg, B, L, grid, seed=300 + t)
+        wl, ml = O.make_lang_task_labels(oc, batch["input_ids"], 400 + t)
+        batch["word_labels"], batch["matched_labels"] = wl, ml
+        loss = tr.step(batch, task=task)
+        leaf = {k: v.clone().requires_grad_(v.is_floating_point() and k not in ("vis_emb.weight", "obj_predict_head.out_cluster.weight"))
+                for k, v in ref.items()}
+        leaf["obj_predict_head.out_cluster.weight"] = leaf["vis_emb.weight"]
+        if task == "vis_mask":
+            out = O.xlxmert_vis_mask_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                             batch["cluster_ids"], batch["vis_mask"], batch["obj_labels"])
+            assert abs(loss[0].item() - out["obj_loss"].item()) < 3e-5
+        elif task == "word_mask":
+            out = O.xlxmert_word_mask_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                              batch["cluster_ids"], wl)
+            assert abs(loss.item() - out["total_loss"].item()) < 3e-5
+        else:
+            out = O.xlxmert_matched_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                            batch["cluster_ids"], ml)
+            assert abs(loss.item() - out["total_loss"].item()) < 3e-5
+        out["total_loss"].backward()
+        names = sorted(k for k, v in leaf.items() if v.grad is not None)
+        norm, clipped = O.clip_grad_norm([leaf[k].grad for k in names], 1.0)
+        assert abs(tr.grad_norm() - norm.item()) < 1e-4 * max(1.0, norm.item())
+        lr = 1e-2 * linear_schedule(t - 1, 2, 10)
+        for k, g in zip(names, clipped):
+            nstep[k] += 1
+            wd = 0.0 if ("bias" in k or "LayerNorm.weight" in k) else 0.01
+            ref[k], m[k], v2[k] = O.adamw_update(ref[k], g, m[k], v2[k], nstep[k], lr, weight_decay=wd)
+            ref[k] = ref[k].detach()
+        for k in ref:
+            if k in store.index:
+                d = (tr.store.view(k) - ref[k]).abs().max().item()
+                assert d < 3e-5, (t, task, k, d)
+    assert nstep["obj_predict_head.linear_feat.weight"] == 2 and nstep["cls.seq_relationship.weight"] == 1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

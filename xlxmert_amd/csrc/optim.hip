@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, T* __restrict__ pc, const uint8_t* __restrict__ decay,
+                                                    const int* __restrict__ chunk_steps,
                                                     const float* __restrict__ sumsq, const float* __restrict__ lrs, int64_t n4,
                                                     float beta1, float beta2, float eps, float wd, float max_norm, float gscale) {
     const float lr = lrs[0], bc1 = lrs[1], bc2 = lrs[2];
@@ -43,13 +44,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float norm = sqrtf(sumsq[0]) * gscale;
         clip *= fminf(1.0f, max_norm / (norm + 1e-6f));
     }
-    const float step = lr * sqrtf(bc2) / bc1;
+    const float step0 = lr * sqrtf(bc2) / bc1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uint8_t fl = decay != nullptr ? decay[i >> 6] : 0;                  // 256-element chunks: bit 0 decay, bit 1 skip
+        if (fl & 2) continue;              // tensor without a gradient this step: the reference's AdamW does not touch it
+        float step = step0;
+        if (chunk_steps != nullptr) {      // per-tensor update count (transformers AdamW keeps state["step"] per parameter)
+            const float t = (float)chunk_steps[i >> 6];
+            step = lr * sqrtf(1.0f - exp2f(t * log2f(beta2))) / (1.0f - exp2f(t * log2f(beta1)));
+        }
         float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
         float4 mv = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
-        const bool dec = wd > 0.f && decay != nullptr && decay[i >> 6] != 0;       // 256-element chunks
+        const bool dec = wd > 0.f && (fl & 1);
         float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
         float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -102,7 +110,7 @@ extern "C" int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream) {
 }
 
 extern "C" int xl_adamw(float* p, const float* g, float* m, float* v, void* p_compute,
-                        const uint8_t* decay_flags, const float* sumsq, const float* lr_and_steps,
+                        const uint8_t* decay_flags, const int* chunk_steps, const float* sumsq, const float* lr_and_steps,
                         int64_t n, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                         float grad_scale, int dtype, void* stream) {
     XL_CHECK_ARG(p && g && m && v && lr_and_steps, XL_ERR_BAD_ARG, "xl_adamw: null pointer");
@@ -112,10 +120,10 @@ extern "C" int xl_adamw(float* p, const float* g, float* m, float* v, void* p_co
     const int64_t n4 = n >> 2;
     if (dtype == XL_BF16)
         hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_compute,
-                           decay_flags, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
+                           decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
     else if (dtype == XL_F32)
         hipLaunchKernelGGL((adamw_kernel<float>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (float*)p_compute,
-                           decay_flags, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
+                           decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
     else { set_error("xl_adamw: bad dtype %d", dtype); return XL_ERR_BAD_DTYPE; }
     XL_CHECK_LAUNCH();
     return XL_OK;

@@ -443,8 +443,8 @@ class Engine:
         self.compact_head = os.environ.get("XL_COMPACT_HEAD", "1") != "0"   # training step: codebook head on the masked rows only
         self.task = getattr(store, "task", "vis_mask")
         self.answer = AnswerHead(self, store.num_answers) if self.task == "vqa" else None
-        self.lang_heads = LangHeads(self) if self.task in ("word_mask", "matched") else None
-        if self.task in ("vqa", "word_mask", "matched"):
+        self.lang_heads = LangHeads(self) if self.task in ("word_mask", "matched", "all") else None
+        if self.task in ("vqa", "word_mask", "matched", "all"):
             assert need_lang, "this task reads the language / pooled output: build the engine with need_lang=True"
         # ---- head (ref lxrt/modeling.py:38-53) + losses
         h = "obj_predict_head"
@@ -951,5 +951,7 @@ class Engine:
             self.head_backward(self.GA[self.ML:])
         finally:
             self._hrows = None
-        self.encoder_backward(False)
+        if self.need_lang:              # multi-task engine: the language side of the last cross layer exists, with zero gradient
+            self.GA[:self.ML].zero_()
+        self.encoder_backward(self.need_lang)
         return losses

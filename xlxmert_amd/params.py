@@ -204,9 +204,22 @@ class ParamStore:
             if u.decay:
                 flags[u.offset // CHUNK:(u.offset + u.padded) // CHUNK] = 1
         self.decay_flags = flags.to(dev)
+        self._task_flags = {}
         # frozen centroid codebook (vis_emb.weight == obj_predict_head.out_cluster.weight, ref modeling.py:140-151)
         self.centroids = None          # fp32 [K, F]
         self.centroids_c = None        # compute dtype
+
+    def task_flags(self, task):
+        """per-chunk optimizer flags for one step of `task` on a multi-task ("all") store: bit 0 = weight decay, bit 1 = skip
+        (tensors that get no gradient in that branch of the reference: .grad stays None and AdamW leaves them alone)."""
+        if task not in self._task_flags:
+            active = {m.name for u in build_units(self.cfg, task, self.num_answers) if u.used for m in u.members}
+            fl = self.decay_flags.clone()
+            for u in self.units:
+                if not all(m.name in active for m in u.members):
+                    fl[u.offset // CHUNK:(u.offset + u.padded) // CHUNK] |= 2
+            self._task_flags[task] = fl
+        return self._task_flags[task]
 
     # ---- views
     def view(self, name, buf=None):

@@ -54,8 +54,9 @@ class PretrainStep:
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
-        ref tasks/vqa.py:166-198) -- same clip / AdamW / schedule.  One task per step object: the reference's round-robin
-        over tasks on ONE parameter set (a different optimizer range every step) is not built."""
+        ref tasks/vqa.py:166-198) -- same clip / AdamW / schedule.  task="all": the three pretraining branches on ONE
+        parameter set, `step(batch, task=...)` per call (the reference's round-robin, lxmert_pretrain.py:296-298): tensors
+        without a gradient in the step's branch are skipped by the optimizer and keep their own update count."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -74,6 +75,10 @@ class PretrainStep:
         self.total_steps, self.warmup_steps = total_steps, int(total_steps * warmup_ratio)
         self.feat_loss = feat_loss
         self.t = 0
+        # task round-robin on one parameter set (ref lxmert_pretrain.py:296-298): per-tensor update counts, as transformers'
+        # AdamW keeps them (a tensor skipped in a step does not advance its bias correction)
+        self.chunk_steps = (torch.zeros(self.store.n_total // 256, dtype=torch.int32, device=self.device)
+                            if task == "all" else None)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.lrs = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._lrs_host = torch.zeros(4, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.zeros(4)
@@ -112,15 +117,18 @@ class PretrainStep:
         for w in self._works:
             w.wait()
 
-    def step(self, batch):
+    def step(self, batch, task=None):
         """batch: dict with input_ids, attention_mask (optional), token_type_ids (optional), visual_pos,
         cluster_ids, vis_mask, obj_labels (optional: derived from cluster_ids/vis_mask as the reference does)."""
         eng, st, ops = self.engine, self.store, self.ops
+        run = self.task if self.task != "all" else task           # a multi-task step object is told which branch to run
+        assert run in ("vis_mask", "word_mask", "matched", "vqa"), "PretrainStep(task='all').step(batch, task=...)"
+        self._step_task = run
         ids = batch["input_ids"]
         am = batch.get("attention_mask")
         if am is None:
             am = ids > 0                                       # ref lxmert_pretrain.py:206 / tasks/vqa.py:178
-        if self.task in ("word_mask", "matched"):
+        if run in ("word_mask", "matched"):
             # language pretraining branches (ref lxmert_pretrain.py:159-160,180-182,192-195): un-masked codebook features;
             # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels | matched_labels
             eng.set_step_seed(self.t * self.world + self.rank)
@@ -128,13 +136,13 @@ class PretrainStep:
             if self.world > 1:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
-            loss = (eng.word_mask_forward_backward(batch["word_labels"]) if self.task == "word_mask"
+            loss = (eng.word_mask_forward_backward(batch["word_labels"]) if run == "word_mask"
                     else eng.matched_forward_backward(batch["matched_labels"]))
             if self.world > 1:
                 self._finish_exchange()
             self.optimizer_step()
             return loss
-        if self.task == "vqa":
+        if run == "vqa":
             # batch: input_ids (word_ids), visual_feats [B,V,F] (vis_feats), visual_pos (boxes), targets [B,A] soft scores
             eng.set_step_seed(self.t * self.world + self.rank)
             eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], visual_feats=batch["visual_feats"])
@@ -175,10 +183,14 @@ class PretrainStep:
         if self.clip > 0:
             self.sumsq.zero_()
             ops.sumsq(st.grad, self.sumsq, n)
+        flags = st.decay_flags
+        if self.chunk_steps is not None:
+            flags = st.task_flags(self._step_task)
+            self.chunk_steps.add_(((flags & 2) == 0).to(torch.int32))
         ops.adamw(st.master, st.grad, st.exp_avg, st.exp_avg_sq,
-                  st.compute if st.compute_dtype != torch.float32 else None, st.decay_flags,
+                  st.compute if st.compute_dtype != torch.float32 else None, flags,
                   self.sumsq if self.clip > 0 else None, self.lrs, n, b1, b2, self.eps, self.wd, self.clip,
-                  grad_scale=1.0 / self.world)
+                  grad_scale=1.0 / self.world, chunk_steps=self.chunk_steps)
 
     def grad_norm(self):
         return math.sqrt(float(self.sumsq.item())) / self.world
