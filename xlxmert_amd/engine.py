@@ -135,8 +135,13 @@ class CrossAttBlock:
     """LxmertXLayer.cross_att (HF:377-398): ONE LxmertCrossAttentionLayer applied in both directions on the
     pre-update inputs.  Rows = [language (B*L) ; visual (B*V)]."""
 
-    def __init__(self, eng, prefix, need_lang, tag):
-        self.e, self.need_lang, self.tag = eng, need_lang, tag
+    def __init__(self, eng, prefix, need_lang, tag, need_vis=True):
+        """need_lang / need_vis: whether the language / visual rows of the OUTPUT are consumed.  The last cross layer of a
+        masked-visual-token step needs only the visual side, the one of the pooled-output / language tasks (VQA, word_mask,
+        matched) only the language side: the other direction of the attention, its output projection and LayerNorm are
+        skipped (their parameters get no gradient in the reference either)."""
+        assert need_lang or need_vis
+        self.e, self.need_lang, self.need_vis, self.tag = eng, need_lang, need_vis, tag
         self.p = _Att(eng, prefix, "att")
         d = eng.d
         self.qkv = eng.act(eng.MX, 3 * d)
@@ -151,6 +156,16 @@ class CrossAttBlock:
         e, p, d = self.e, self.p, self.e.d
         ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
         qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
+        if not self.need_vis:
+            ops.gemm(X[:ML], p.wqkv, qkv_l, p.bqkv, None, None, ML, d, d, d, d, 3 * d)                    # Q of language rows
+            ops.gemm(X[ML:], p.wqkv[d:], qkv_v[:, d:], p.bqkv[d:], None, None, MV, 2 * d, d, d, d, 3 * d)  # K,V of visual rows
+            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
+                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
+            ops.gemm(self.ctx[:ML], p.wo, self.z[:ML], p.bo, X[:ML], None, ML, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
+                     p_drop=e.p_hid, seed=e.seed(self.site + 2))
+            ops.layernorm_fwd(self.z[:ML], p.g, p.b, Y[:ML], self.mean[:ML], self.rstd[:ML], ML, d, e.eps)
+            self.X = X
+            return
         if self.need_lang:
             ops.gemm(X, p.wqkv, self.qkv, p.bqkv, None, None, MX, 3 * d, d, d, d, 3 * d)
             # language queries over visual keys/values (no mask: visual_attention_mask is None in every caller)
@@ -172,6 +187,8 @@ class CrossAttBlock:
         e, p, d = self.e, self.p, self.e.d
         ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
         e.wgrad_sync()
+        if not self.need_vis:
+            return self._bwd_lang_only(dY, dX)
         r0, M = (0, MX) if self.need_lang else (ML, MV)
         dz_full = e.tmp("dz", MX, d)
         dz = dz_full[r0:]
@@ -206,6 +223,29 @@ class CrossAttBlock:
             ops.gemm(dqkv_v, p.wqkv, dX[ML:], None, dz, None, MV, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
             ops.gemm(dqkv_l[:, d:], p.wqkv[d:], dX[:ML], None, None, None, ML, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
+
+
+    def _bwd_lang_only(self, dY, dX):
+        e, p, d = self.e, self.p, self.e.d
+        ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
+        X = self.X
+        dz = e.tmp("dz", MX, d)[:ML]
+        dzm = e.ln_bwd_dense(dY[:ML], self.z[:ML], p.g, self.mean[:ML], self.rstd[:ML], dz, p.gg, p.gb, p.gbo, ML, d, self.site + 2)
+        e.wgrad_defer(dzm, self.ctx[:ML], p.gwo, d, d, ML, d, d, d)
+        dctx = e.tmp("dctx", MX, d)[:ML]
+        ops.gemm(dzm, p.wo, dctx, None, None, None, ML, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        dqkv = e.tmp("dqkv", MX, 3 * d)
+        dqkv_l, dqkv_v = dqkv[:ML], dqkv[ML:]
+        qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
+        ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, dctx, self.lse_l, dqkv_l, dqkv_v[:, d:], dqkv_v[:, 2 * d:],
+                     e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale, e.p_attn, e.seed(self.site))
+        ops.colsum(dqkv_l, p.gbqkv, ML, d, 3 * d, ws=e.ws)
+        ops.colsum(dqkv_v[:, d:], p.gbqkv[d:], MV, 2 * d, 3 * d, ws=e.ws)
+        e.wgrad_defer(dqkv_l, X[:ML], p.gwqkv, d, d, ML, 3 * d, d, d)
+        e.wgrad_defer(dqkv_v[:, d:], X[ML:], p.gwqkv[d:], 2 * d, d, MV, 3 * d, d, d)
+        e.wgrad_flush()
+        ops.gemm(dqkv_l, p.wqkv, dX[:ML], None, dz, None, ML, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0, epilogue=EPI_RESIDUAL)
+        ops.gemm(dqkv_v[:, d:], p.wqkv[d:], dX[ML:], None, None, None, MV, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
 
 
 class AnswerHead:
@@ -406,12 +446,17 @@ class Engine:
                             FFNBlock(self, f"{e_}.r_layers.{i}.intermediate", f"{e_}.r_layers.{i}.output", self.MV, f"r{i}"))
                            for i in range(cfg.r_layers)]
         self.x_layers = []
+        task0 = getattr(store, "task", "vis_mask")
         for i in range(cfg.x_layers):
             p = f"{e_}.x_layers.{i}"
             lang_on = need_lang or i < cfg.x_layers - 1
-            blk = {"cross": CrossAttBlock(self, p + ".visual_attention", lang_on, f"x{i}"), "lang_on": lang_on,
-                   "sa_v": SelfAttBlock(self, p + ".visn_self_att", V, False, f"x{i}v"),
-                   "ffn_v": FFNBlock(self, p + ".visn_inter", p + ".visn_output", self.MV, f"x{i}v")}
+            # VQA / word_mask / matched read only the language (pooled) output: the visual side of the last cross layer is dead
+            vis_on = not (task0 in ("vqa", "word_mask", "matched") and i == cfg.x_layers - 1)
+            blk = {"cross": CrossAttBlock(self, p + ".visual_attention", lang_on, f"x{i}", need_vis=vis_on), "lang_on": lang_on,
+                   "vis_on": vis_on}
+            if vis_on:
+                blk["sa_v"] = SelfAttBlock(self, p + ".visn_self_att", V, False, f"x{i}v")
+                blk["ffn_v"] = FFNBlock(self, p + ".visn_inter", p + ".visn_output", self.MV, f"x{i}v")
             if lang_on:
                 blk["sa_l"] = SelfAttBlock(self, p + ".lang_self_att", L, True, f"x{i}l")
                 blk["ffn_l"] = FFNBlock(self, p + ".lang_inter", p + ".lang_output", self.ML, f"x{i}l")
@@ -674,8 +719,9 @@ class Engine:
                 with self.lang_stream():
                     blk["sa_l"].fwd(Y[:ML], S[:ML])
                     blk["ffn_l"].fwd(S[:ML], Xo[:ML])
-            blk["sa_v"].fwd(Y[ML:], S[ML:])
-            blk["ffn_v"].fwd(S[ML:], Xo[ML:])
+            if blk["vis_on"]:
+                blk["sa_v"].fwd(Y[ML:], S[ML:])
+                blk["ffn_v"].fwd(S[ML:], Xo[ML:])
             if blk["lang_on"]:
                 self.join()
         Xl = self.X[-1]
@@ -883,8 +929,9 @@ class Engine:
                     blk["ffn_l"].bwd(GA[:ML], GB[:ML])
                     blk["sa_l"].bwd(GB[:ML], GA[:ML])
                     self.wgrad_sync()
-            blk["ffn_v"].bwd(GA[ML:], GB[ML:])
-            blk["sa_v"].bwd(GB[ML:], GA[ML:])
+            if blk["vis_on"]:
+                blk["ffn_v"].bwd(GA[ML:], GB[ML:])
+                blk["sa_v"].bwd(GB[ML:], GA[ML:])
             if blk["lang_on"]:
                 self.join()
             blk["cross"].bwd(GA, GB)
