@@ -165,6 +165,12 @@ int xl_bce_logits_fwd_bwd(const float* logits, const float* targets, void* dlogi
  *   xl_codebook_gather exactly as `where(mask, mask_feat, vis_emb(ids))`). */
 int xl_remask_lowest(const float* prob, void* vis_mask, int B, int V, int n_mask, void* stream);
 int xl_sampler_update(const int* pred_ids, const void* vis_mask, int64_t* code_ids, int n, void* stream);
+/* Autoregressive variant (ref tasks/imggen_model.py:49-167): per step ONE position per image takes its prediction and is
+ * un-masked: fixed_pos >= 0 -> that position for every image (position_TLBR / position_random order drawn on the host),
+ * fixed_pos < 0 -> each image's most confident position among the not yet visited ones (position_confidence, ref :140-149;
+ * `visited` uint8 [B,V] is updated). */
+int xl_sampler_ar_update(const float* prob, const int* pred_ids, void* visited, void* vis_mask, int64_t* code_ids,
+                         int B, int V, int fixed_pos, void* stream);
 
 /* ---------------------------------------------------------------- attention core (HF:247-263)
  * per (b,h): O = softmax(Q K^T * scale, keys with key_mask==0 excluded) V ; nq,nk <= 64.

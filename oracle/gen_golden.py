@@ -269,6 +269,59 @@ def gen_lang_tasks(name, cfg, seed, B, L, grid):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
 
 
+def gen_sampler_ar(name, cfg, seed, B, L, grid):
+    """SURVEY 8f N2 (AR variant): the loop body of tasks/imggen_model.py:96-153 on the reference's own modules, for the
+    three position policies; `random` uses random.Random(7).shuffle as the reference does with seed=7."""
+    import random
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    input_ids = inp["input_ids"]
+    V = grid * grid
+    visual_pos = torch.from_numpy(O.box_position(grid)).unsqueeze(0).expand(B, -1, -1)
+    d = dict(seed=np.array(seed), grid=np.array(grid), **cfg_fields(cfg), in_input_ids=input_ids.numpy())
+    for mode in ("confidence", "tlbr", "random"):
+        n_steps = V
+        positions = list(range(V))
+        random.Random(7).shuffle(positions)
+        d["random_positions"] = np.array(positions)
+        visited = torch.zeros(B, V)
+        masks = []
+        with torch.no_grad():
+            for i in range(n_steps):
+                if i == 0:
+                    vis_mask = torch.ones(B, V).long()
+                    code = torch.zeros(B, V, cfg.visual_feat_dim)
+                if mode == "random":
+                    current_pos_i = positions.pop() % V
+                    vis_mask[:, current_pos_i] = 1
+                elif mode == "tlbr":
+                    current_pos_i = i
+                code = torch.where(vis_mask.view(B, V, 1).bool(), m.mask_feat.view(1, 1, -1).to(dtype=code.dtype), code)
+                out = m.bert(input_ids=input_ids, visual_feats=code, visual_pos=visual_pos, attention_mask=input_ids > 0,
+                             return_dict=True)
+                pred_code_logit = m.obj_predict_head(out[1], out_keys=["obj"])["obj"]
+                pred_prob, pred_code_id = torch.softmax(pred_code_logit, dim=2).max(dim=2)
+                pred_code = m.vis_emb(pred_code_id)
+                if mode in ("tlbr", "random"):
+                    update_mask = torch.zeros(B, V).bool()
+                    update_mask[:, current_pos_i] = 1
+                    vis_mask[:, current_pos_i] = 0
+                else:
+                    _pred_prob = pred_prob.masked_fill(visited.bool(), -10000)
+                    top_prob, top_arg = _pred_prob.topk(1, dim=1, largest=True)
+                    update_mask = torch.zeros(B, V).long()
+                    update_mask.scatter_(1, top_arg, 1)
+                    vis_mask.scatter_(1, top_arg, 0)
+                    visited.scatter_(1, top_arg, 1)
+                code = torch.where(update_mask.view(B, V, 1).bool(), pred_code, code)
+                masks.append(vis_mask.numpy().astype(np.uint8).copy())
+        d["code_" + mode] = code.numpy()
+        d["step_masks_" + mode] = np.stack(masks)
+        d["final_ids_" + mode] = pred_code_id.numpy()
+        print(name, mode, "final code norm", float(code.norm()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+
+
 def gen_sampler(name, cfg, seed, B, L, grid, n_steps):
     """Mask-Predict sampling loop of tasks/imggen_model.py:199-243 executed on the REFERENCE's modules
     (`bert`, `obj_predict_head`, `vis_emb`, `mask_feat` of lxrt.modeling.XLxmertForPretraining).  The published
@@ -318,5 +371,6 @@ if __name__ == "__main__":
              store_grads=False)
     gen_config1()
     gen_lang_tasks("lang_tasks_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=8642, B=3, L=8, grid=4)
+    gen_sampler_ar("sampler_ar_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=9753, B=3, L=8, grid=4)
     gen_sampler("sampler_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, B=3, L=8, grid=4, n_steps=4)
     gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)

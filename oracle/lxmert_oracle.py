@@ -313,6 +313,47 @@ def sample_codes_nar(sd, cfg, input_ids, n_steps, grid_size=8, return_trace=Fals
     return code, code_ids, pred_prob
 
 
+def sample_codes_ar(sd, cfg, input_ids, n_steps=None, grid_size=8, mode="confidence", positions=None):
+    """ref:x-lxmert/src/tasks/imggen_model.py:49-153 (sample_image_AR up to the GAN hand-off).  mode: "confidence"
+    (position_confidence, the default), "tlbr" (position_TLBR) or "random" (position_random; `positions` = the order
+    popped from the END of the host-shuffled list, ref :78-91, 104-108)."""
+    B = input_ids.shape[0]
+    V = grid_size ** 2
+    n_steps = V if n_steps is None else n_steps
+    dtype = sd["vis_emb.weight"].dtype
+    visual_pos = torch.from_numpy(box_position(grid_size)).unsqueeze(0).expand(B, -1, -1).to(dtype)
+    visited = torch.zeros(B, V)
+    positions = list(positions) if positions is not None else None
+    with torch.no_grad():
+        for i in range(n_steps):
+            if i == 0:
+                vis_mask = torch.ones(B, V, dtype=torch.long)
+                code = torch.zeros(B, V, cfg.visual_feat_dim, dtype=dtype)
+            if mode == "random":
+                cur = positions.pop() % V
+                vis_mask[:, cur] = 1
+            elif mode == "tlbr":
+                cur = i
+            code = torch.where(vis_mask.view(B, V, 1).bool(), sd["mask_feat"].view(1, 1, -1).to(dtype), code)
+            _, vis, _ = lxmert_model(sd, cfg, input_ids, code, visual_pos, input_ids > 0)
+            _, obj = visual_obj_head(sd, cfg, vis)
+            pred_prob, pred_code_id = torch.softmax(obj, dim=2).max(dim=2)
+            pred_code = sd["vis_emb.weight"][pred_code_id]
+            if mode in ("tlbr", "random"):
+                update = torch.zeros(B, V, dtype=torch.bool)
+                update[:, cur] = True
+                vis_mask[:, cur] = 0
+            else:
+                _p = pred_prob.masked_fill(visited.bool(), -10000)
+                _, top_arg = _p.topk(1, dim=1, largest=True)
+                update = torch.zeros(B, V, dtype=torch.long)
+                update.scatter_(1, top_arg, 1)
+                vis_mask.scatter_(1, top_arg, 0)
+                visited.scatter_(1, top_arg, 1)
+            code = torch.where(update.view(B, V, 1).bool(), pred_code, code)
+    return code, vis_mask
+
+
 # --------------------------------------------------------------------------- VQA / GQA fine-tune head (SURVEY 8f N1)
 def visual_answer_head(sd, cfg, pooled, prefix="answer_head.logit_fc"):
     """HF:602-614 LxmertVisualAnswerHead -- Linear(d, 2d) -> GeLU -> LayerNorm(2d, eps=1e-12) -> Linear(2d, num_answers)."""

@@ -202,6 +202,18 @@ class FakeOps:
         m = vis_mask.reshape(-1)[:n] != 0
         code_ids.view(-1)[:n][m] = pred_ids.reshape(-1)[:n][m].to(code_ids.dtype)
 
+    def sampler_ar_update(self, prob, pred_ids, visited, vis_mask, code_ids, B, V, fixed_pos=-1):
+        p, pr = prob.reshape(B, V), pred_ids.reshape(B, V)
+        if fixed_pos >= 0:
+            pos = torch.full((B,), fixed_pos, dtype=torch.long)
+        else:
+            q = p.masked_fill(visited.view(B, V) != 0, -10000.0)
+            pos = (q == q.max(1, keepdim=True).values).float().argmax(1)          # first index of the maximum
+            visited.view(B, V)[torch.arange(B), pos] = 1
+        r = torch.arange(B)
+        code_ids.view(B, V)[r, pos] = pr[r, pos].to(code_ids.dtype)
+        vis_mask.view(B, V)[r, pos] = 0
+
     @staticmethod
     def _heads(t, B, n, H, dh, ld):
         return torch.as_strided(t, (B, H, n, dh), (n * ld, dh, ld, 1))

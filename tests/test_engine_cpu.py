@@ -242,3 +242,20 @@ def test_language_pretraining_steps_vs_reference_fixture(task):
     g = load_golden("lang_tasks_tiny")
     eng, inp = make_lang_task_engine(g, task, FakeOps(torch.float32))
     check_lang_task(g, task, eng, inp, 5e-6, 1e-4)
+
+
+def check_ar_sampler(g, eng, mode):
+    trace = []
+    cid, code, prob = eng.sample_codes_ar(None, mode, positions=g["random_positions"].tolist(), trace=trace)
+    assert maxdiff(code.float().cpu().view(g["code_" + mode].shape), g["code_" + mode]) == 0.0
+    ref = torch.from_numpy(g["step_masks_" + mode])
+    for i, m in enumerate(trace):
+        assert torch.equal(m.cpu(), ref[i]), (mode, i)
+
+
+@pytest.mark.parametrize("mode", ["confidence", "tlbr", "random"])
+def test_ar_sampler_vs_reference_fixture(mode):
+    """SURVEY 8f N2, autoregressive variant: same codes and the same fill order (mask after every step) as the reference loop."""
+    g = load_golden("sampler_ar_tiny")
+    eng, sd = make_sampler_engine(g, FakeOps(torch.float32))
+    check_ar_sampler(g, eng, mode)

@@ -441,3 +441,12 @@ def test_task_round_robin_full_size_bf16():
         assert same["cls.seq_relationship.weight"] == (task != "matched")
         assert same["cls.predictions.transform.dense.weight"] == (task != "word_mask")
         assert not same["bert.encoder.layer.0.output.dense.weight"]
+
+
+@pytest.mark.parametrize("mode", ["confidence", "tlbr", "random"])
+def test_ar_sampler_fp32_matches_reference_fixture(mode):
+    from test_engine_cpu import check_ar_sampler, make_sampler_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("sampler_ar_tiny")
+    eng, sd = make_sampler_engine(g, HipOps(torch.float32), device="cuda")
+    check_ar_sampler(g, eng, mode)

@@ -676,6 +676,34 @@ __global__ __launch_bounds__(256) void move_rows_kernel(const T* __restrict__ sr
     for (int col = lane * VEC; col < N; col += 64 * VEC) *reinterpret_cast<uint4*>(d + col) = *reinterpret_cast<const uint4*>(s + col);
 }
 
+// Autoregressive sampler step (ref tasks/imggen_model.py:140-153): one position per image takes its prediction and is
+// un-masked -- position `fixed_pos` for every image (top-left to bottom-right / host-drawn random order), or, with
+// fixed_pos < 0, each image's most confident position among those not visited yet (ties: lower index; ref topk(1)).
+__global__ __launch_bounds__(256) void sampler_ar_update_kernel(const float* __restrict__ prob, const int* __restrict__ pred,
+                                                                uint8_t* __restrict__ visited, uint8_t* __restrict__ mask,
+                                                                int64_t* __restrict__ ids, int B, int V, int fixed_pos) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= B) return;
+    int pos = fixed_pos;
+    if (fixed_pos < 0) {
+        float best = (lane < V && !visited[(size_t)row * V + lane]) ? prob[(size_t)row * V + lane] : -10000.0f;   // ref masked_fill
+        int arg = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oa = __shfl_xor(arg, o, 64);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        pos = arg;
+    }
+    if (lane == 0) {
+        const size_t i = (size_t)row * V + pos;
+        ids[i] = pred[i];
+        mask[i] = 0;
+        if (fixed_pos < 0) visited[i] = 1;
+    }
+}
+
 }  // namespace xl
 
 using namespace xl;
@@ -989,4 +1017,14 @@ extern "C" int xl_gather_rows(const void* src, const int* rows, void* dst, int n
 extern "C" int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype,
                                void* stream) {
     return move_rows(src, rows, dst, n_rows, N, ld_src, ld_dst, dtype, stream, true);
+}
+
+extern "C" int xl_sampler_ar_update(const float* prob, const int* pred_ids, void* visited, void* vis_mask, int64_t* code_ids,
+                                    int B, int V, int fixed_pos, void* stream) {
+    XL_CHECK_ARG(prob && pred_ids && vis_mask && code_ids && B > 0 && V > 0 && V <= 64 && fixed_pos < V &&
+                 (fixed_pos >= 0 || visited != nullptr), XL_ERR_BAD_ARG, "xl_sampler_ar_update: B=%d V=%d fixed_pos=%d", B, V, fixed_pos);
+    hipLaunchKernelGGL(sampler_ar_update_kernel, dim3((B + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, prob, pred_ids,
+                       (uint8_t*)visited, (uint8_t*)vis_mask, code_ids, B, V, fixed_pos);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
 }

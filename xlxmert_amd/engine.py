@@ -869,6 +869,37 @@ class Engine:
         ops.codebook_gather(self.cid, None, st.centroids_c, st.view("mask_feat"), self.feats, self.MV, self.F)
         return self.cid, self.feats, self.row_maxprob
 
+    def sample_codes_ar(self, n_steps=None, mode="confidence", positions=None, trace=None):
+        """Autoregressive sampling (ref tasks/imggen_model.py:49-153): one grid position per image is filled per step --
+        the most confident not-yet-visited one ("confidence", the reference's default), position i ("tlbr"), or the host's
+        shuffled order popped from the end ("random", positions = that list).  Same device-resident state as
+        sample_codes_nar; `trace` (a list) receives a copy of vis_mask after every step."""
+        ops, B, V = self.ops, self.B, self.V
+        st = self.store
+        n_steps = V if n_steps is None else n_steps
+        self.use_codebook, self.has_vmask = True, True
+        self.cid.zero_()
+        self.vmask.fill_(1)
+        if not hasattr(self, "visited"):
+            self.visited = torch.zeros(B, V, dtype=torch.uint8, device=self.dev)
+        self.visited.zero_()
+        positions = list(positions) if positions is not None else None
+        for i in range(n_steps):
+            cur = -1
+            if mode == "random":
+                cur = positions.pop() % V
+                self.vmask[:, cur] = 1                                     # ref :104-108 (re-visits beyond V steps)
+            elif mode == "tlbr":
+                cur = i
+            self.encoder_forward(want_pooled=False)
+            self.head_forward()
+            self.predict_codes()
+            ops.sampler_ar_update(self.row_maxprob, self.row_argmax, self.visited, self.vmask, self.cid, B, V, cur)
+            if trace is not None:
+                trace.append(self.vmask.clone())
+        ops.codebook_gather(self.cid, self.vmask, st.centroids_c, st.view("mask_feat"), self.feats, self.MV, self.F)
+        return self.cid, self.feats, self.row_maxprob
+
     # ------------------------------------------------------------ backward
     def zero_accumulated_grads(self):
         st = self.store

@@ -137,6 +137,10 @@ class HipOps:
     def sampler_update(self, pred_ids, vis_mask, code_ids, n):
         self.lib.call("xl_sampler_update", self._p(pred_ids), self._p(vis_mask), self._p(code_ids), n, self._stream())
 
+    def sampler_ar_update(self, prob, pred_ids, visited, vis_mask, code_ids, B, V, fixed_pos=-1):
+        self.lib.call("xl_sampler_ar_update", self._p(prob), self._p(pred_ids), self._p(visited), self._p(vis_mask),
+                      self._p(code_ids), B, V, int(fixed_pos), self._stream())
+
     # -- attention core
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
         self.lib.call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),
