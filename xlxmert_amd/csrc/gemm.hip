@@ -285,12 +285,14 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // kernel choice.  Ping-pong 256x256 kernel (one workgroup per CU): XL_GEMM_PP = 0 never, 1 by shape, 2 whenever eligible
     if (g_gemm_pp < 0) g_gemm_pp = env_int("XL_GEMM_PP", 1);
     const int pp_mode = g_gemm_pp;
-    static const int pp_min_tiles = env_int("XL_GEMM_PP_MIN_TILES", 128);
+    static const int pp_min_tiles = env_int("XL_GEMM_PP_MIN_TILES", 48);
     const long t256n = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool pp_ok = mfma_ok && g_use_tr_read && K % 8 == 0 && (double)(a_kmajor ? M : K) * lda < 2e9 &&
                        (double)(b_kmajor ? N : K) * ldb < 2e9;
-    // by shape: the ping-pong kernel needs enough 256x256 tiles (x K splits for weight gradients) to occupy the chip at one
-    // workgroup per CU; below that the 128x128 kernel (two workgroups per CU, 4x the tiles) wins (tools/gemm_bench.py)
+    // by shape: >= 48 tiles of 256x256 (x K splits for weight gradients).  In isolation the 128x128 kernel (two workgroups
+    // per CU, 4x the tiles) is faster below ~128 tiles (tools/gemm_bench.py), but the language stream's 60-tile contractions
+    // run NEXT TO the visual stream's 192-tile ones (N = 768: 3 column tiles x 64 row tiles on 256 CUs): as 60 whole-CU
+    // workgroups they drop into the 64 idle CUs instead of competing for all of them (-0.5 ms per step)
     long pp_blocks = t256n;
     if (may_split && t256n < 256 && K >= 1024) pp_blocks = t256n * std::max<long>(1, std::min<long>(256 / t256n, K / 512));
     const bool use_pp = pp_ok && (pp_mode == 2 || (pp_mode == 1 && pp_blocks >= pp_min_tiles));
