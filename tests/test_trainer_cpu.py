@@ -204,3 +204,19 @@ def test_data_parallel_world2_gloo(tmp_path):
     for k, g in zip(names, clipped):
         p, _, _ = O.adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr)
         assert (r0[k] - p).abs().max().item() < 2e-5, k
+
+
+def test_random_word_batch_statistics():
+    from xlxmert_amd.trainer import random_word_batch
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(1000, 30000, (400, 20), generator=g)
+    masked, labels = random_word_batch(ids, generator=g)
+    chosen = labels != -100
+    assert not chosen[:, 0].any() and not chosen[:, -1].any()
+    assert torch.equal(labels[chosen], ids[chosen]) and torch.equal(masked[~chosen], ids[~chosen])
+    frac = chosen[:, 1:-1].float().mean().item()
+    assert 0.13 < frac < 0.17
+    is_mask = (masked == 103) & chosen
+    assert 0.75 < is_mask.sum().item() / chosen.sum().item() < 0.85
+    kept = (masked == ids) & chosen
+    assert 0.06 < kept.sum().item() / chosen.sum().item() < 0.14

@@ -221,3 +221,27 @@ def synthetic_batch(cfg, B, L=20, grid=8, seed=9595, device="cpu", ragged=True):
              "cluster_ids": cid, "vis_mask": vm, "obj_labels": lab, "visual_pos": pos[None].expand(B, -1, -1).contiguous(),
              "masked_rows": vm.reshape(-1).nonzero().reshape(-1)}      # computed where the mask is drawn: on the host
     return {k: v.to(device) for k, v in batch.items()}
+
+
+def random_word_batch(input_ids, mask_token_id=103, vocab_size=30522, mlm_probability=0.15, generator=None):
+    """Host-side BERT masking of the `word_mask` task (ref pretrain/lxmert_data.py:697-724): each non-special position is chosen
+    with probability `mlm_probability`; of the chosen ones 80 % become [MASK], 10 % a random token, 10 % stay.  Returns
+    (masked_input_ids, labels) with labels = the original id at chosen positions and -100 elsewhere (the reference writes -1
+    there, which its own CrossEntropyLoss(ignore_index=-100) would reject)."""
+    labels = input_ids.clone()
+    masked = input_ids.clone()
+    shape = labels.shape
+
+    def bern(p):
+        return torch.rand(shape, generator=generator) < p
+
+    chosen = bern(mlm_probability)
+    chosen[:, 0] = False                    # "do not mask special tokens": first and last position (ref :706-707)
+    chosen[:, -1] = False
+    labels[~chosen] = -100
+    replaced = bern(0.8) & chosen
+    masked[replaced] = mask_token_id
+    rnd = bern(0.5) & chosen & ~replaced
+    words = torch.randint(vocab_size, shape, generator=generator, dtype=torch.long)
+    masked[rnd] = words[rnd]
+    return masked, labels
