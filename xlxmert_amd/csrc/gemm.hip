@@ -287,8 +287,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     const int pp_mode = g_gemm_pp;
     static const int pp_min_tiles = env_int("XL_GEMM_PP_MIN_TILES", 48);
     const long t256n = (long)((M + 255) / 256) * ((N + 255) / 256);
-    const bool pp_ok = mfma_ok && g_use_tr_read && K % 8 == 0 && (double)(a_kmajor ? M : K) * lda < 2e9 &&
-                       (double)(b_kmajor ? N : K) * ldb < 2e9;
+    const bool pp_ok = mfma_ok && g_use_tr_read && K % 8 == 0 && (double)(a_kmajor ? M : K) * lda < 1e9 &&
+                       (double)(b_kmajor ? N : K) * ldb < 1e9;      // 32-bit byte offsets below 2^31 inside the kernel
     // by shape: >= 48 tiles of 256x256 (x K splits for weight gradients).  In isolation the 128x128 kernel (two workgroups
     // per CU, 4x the tiles) is faster below ~128 tiles (tools/gemm_bench.py), but the language stream's 60-tile contractions
     // run NEXT TO the visual stream's 192-tile ones (N = 768: 3 column tiles x 64 row tiles on 256 CUs): as 60 whole-CU
@@ -369,7 +369,7 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
         XL_CHECK_ARG(A[i] && B[i] && C[i] && M[i] > 0 && N[i] > 0 && K[i] > 0 && lda[i] >= M[i] && ldb[i] >= N[i] && ldc[i] >= N[i],
                      XL_ERR_BAD_SHAPE, "xl_gemm_wgrad_group: problem %d: bad operands / shape", i);
         grouped = grouped && lda[i] % 8 == 0 && ldb[i] % 8 == 0 && aligned16(A[i]) && aligned16(B[i]) && K[i] % 8 == 0 &&
-                  (double)K[i] * lda[i] < 2e9 && (double)K[i] * ldb[i] < 2e9;
+                  (double)K[i] * lda[i] < 1e9 && (double)K[i] * ldb[i] < 1e9;
         total += (long)((M[i] + 255) / 256) * ((N[i] + 255) / 256);
         max_split = std::min(max_split, std::max(1, K[i] / 512));
     }

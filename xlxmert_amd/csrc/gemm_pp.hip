@@ -12,8 +12,6 @@ namespace xl {
 // issues loads.  vmcnt is never 0 in the steady state: four half-tiles (8 DMA instructions per wave) stay in flight
 // across the barriers.  (A four-phase variant with 8 MFMAs per section measured 1.9 us per K tile against this one's
 // figure in DESIGN.md: the barrier round trip, ~200 cycles, is the overhead to amortise.)
-__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void hard_barrier() {
@@ -72,19 +70,31 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
                                  : (uint32_t)rs * (uint32_t)p.ldb + min(gn, p.ldb - 8);
         }
     }
+    // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane part of the address is a constant
+    // 32-bit byte offset, the K position goes into the scalar offset, and a lane past the end of K is pointed beyond the
+    // descriptor's range, where the hardware returns zeros -- two VALU instructions per DMA instead of a 64-bit address
+    // computation and a two-register select against a zero page.
+    const auto rsrc_of = [](const void* ptr, uint32_t bytes) {
+        const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(A, (uint32_t)(((size_t)((AK ? p.M : p.K) - 1) * p.lda + (AK ? p.K : p.M)) * 2));
+    const __amdgpu_buffer_rsrc_t rb = rsrc_of(B, (uint32_t)(((size_t)((BKM ? p.N : p.K) - 1) * p.ldb + (BKM ? p.K : p.N)) * 2));
     auto stage = [&](auto SUB, int kt) {
         constexpr int sub = decltype(SUB)::value;
         constexpr bool isA = (sub == 0 || sub == 3);
         const int k0 = kbeg + kt * BK;
         const int krem = kend - k0;
         uint8_t* dst = smem + (kt & 1) * BUF + sub * HT + wave * 2048;
-        const bf16_t* base = isA ? A + (AK ? (size_t)k0 : (size_t)k0 * p.lda) : B + (BKM ? (size_t)k0 : (size_t)k0 * p.ldb);
+        const uint32_t soff = isA ? (uint32_t)(AK ? k0 : k0 * p.lda) * 2u : (uint32_t)(BKM ? k0 : k0 * p.ldb) * 2u;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const bf16_t* g = base + src[sub][pt];
-            if (kk[isA ? 0 : 1][pt] >= krem) g = reinterpret_cast<const bf16_t*>(g_zero16);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16, 0, 0);
+            uint32_t voff = src[sub][pt] * 2u;
+            if (kk[isA ? 0 : 1][pt] >= krem) voff = 0x7FFFFFF0u;             // out of range -> zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
+                                                     (int)voff, (int)soff, 0, 0);
         }
     };
     bf16x8_t fa[2][4], fb[2][4];          // A: 2 row fragments x 4 k-steps of the current A half; B: both halves
