@@ -43,7 +43,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // per-lane sources of this wave's two 1 KiB pieces of each half-tile (element offsets, k0 excluded), and the k
+    // per-lane sources of this wave's two 1 KiB pieces of each half-tile (BYTE offsets, k0 excluded), and the k
     // coordinate of the lane's 16 bytes inside the K tile (ragged last tile: lanes past kend read zeros instead)
     uint32_t src[4][2];
     int kk[2][2];
@@ -57,8 +57,8 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         for (int h = 0; h < 2; ++h) {
             const int lr = AK ? rs : c * 8;                                   // local row (first of 8 when M-major)
             const int gr = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
-            src[h == 0 ? 0 : 3][pt] = AK ? (uint32_t)min(gr, p.M - 1) * (uint32_t)p.lda + c * 8
-                                         : (uint32_t)rs * (uint32_t)p.lda + min(gr, p.lda - 8);
+            src[h == 0 ? 0 : 3][pt] = 2u * (AK ? (uint32_t)min(gr, p.M - 1) * (uint32_t)p.lda + c * 8
+                                              : (uint32_t)rs * (uint32_t)p.lda + min(gr, p.lda - 8));
         }
         TB::decode(o, rs, c);
         kk[1][pt] = BKM ? c * 8 : rs;
@@ -66,8 +66,8 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         for (int h = 0; h < 2; ++h) {
             const int lr = BKM ? rs : c * 8;
             const int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
-            src[1 + h][pt] = BKM ? (uint32_t)min(gn, p.N - 1) * (uint32_t)p.ldb + c * 8
-                                 : (uint32_t)rs * (uint32_t)p.ldb + min(gn, p.ldb - 8);
+            src[1 + h][pt] = 2u * (BKM ? (uint32_t)min(gn, p.N - 1) * (uint32_t)p.ldb + c * 8
+                                       : (uint32_t)rs * (uint32_t)p.ldb + min(gn, p.ldb - 8));
         }
     }
     // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane part of the address is a constant
@@ -89,12 +89,19 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         const int krem = kend - k0;
         uint8_t* dst = smem + (kt & 1) * BUF + sub * HT + wave * 2048;
         const uint32_t soff = isA ? (uint32_t)(AK ? k0 : k0 * p.lda) * 2u : (uint32_t)(BKM ? k0 : k0 * p.ldb) * 2u;
+        if (krem >= BK) {                                 // whole K tile in range (wave-uniform): no per-lane work at all
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            uint32_t voff = src[sub][pt] * 2u;
-            if (kk[isA ? 0 : 1][pt] >= krem) voff = 0x7FFFFFF0u;             // out of range -> zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
-                                                     (int)voff, (int)soff, 0, 0);
+            for (int pt = 0; pt < 2; ++pt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
+                                                         (int)src[sub][pt], (int)soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                uint32_t voff = src[sub][pt];
+                if (kk[isA ? 0 : 1][pt] >= krem) voff = 0x7FFFFFF0u;         // out of range -> zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
+                                                         (int)voff, (int)soff, 0, 0);
+            }
         }
     };
     bf16x8_t fa[2][4], fb[2][4];          // A: 2 row fragments x 4 k-steps of the current A half; B: both halves
@@ -145,7 +152,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         } else {
             read_a(buf, ic<1>{});
         }
-        if (decltype(ISSUE)::value != 0 && !(p.ablate & 2)) {
+        if constexpr (decltype(ISSUE)::value != 0) {
             if constexpr (x == 0) {
                 stage(ic<3>{}, kt + 1);
             } else {
@@ -156,15 +163,8 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         wait_vmcnt<decltype(WAIT)::value>();
         hard_barrier();
         __builtin_amdgcn_s_setprio(1);
-        if (!(p.ablate & 8)) {
-            if constexpr (x == 0) mma2(ic<0>{});
-            else mma2(ic<1>{});
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) asm volatile("" ::"v"(fa[i][s2]), "v"(fb[0][s2]), "v"(fb[1][s2]));
-        }
+        if constexpr (x == 0) mma2(ic<0>{});
+        else mma2(ic<1>{});
         __builtin_amdgcn_s_setprio(0);
         hard_barrier();
     };
@@ -179,8 +179,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     if (nkt >= 2) { stage(ic<0>{}, 1); stage(ic<1>{}, 1); stage(ic<2>{}, 1); wait_vmcnt<8>(); } else { wait_vmcnt<2>(); }
     hard_barrier();
     stamp(1);
-    const bool stagger = !(p.ablate & 16);
-    if (stagger && wr == 1) hard_barrier();
+    if (wr == 1) hard_barrier();                  // waves 4-7 run one barrier behind waves 0-3
     for (int kt = 0; kt < nkt - 2; ++kt) {
         phase(ic<0>{}, ic<8>{}, ic<1>{}, kt);
         phase(ic<1>{}, ic<8>{}, ic<1>{}, kt);
@@ -191,7 +190,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     }
     phase(ic<0>{}, ic<0>{}, ic<0>{}, nkt - 1);
     phase(ic<1>{}, ic<0>{}, ic<0>{}, nkt - 1);
-    if (stagger && wr == 0) hard_barrier();
+    if (wr == 0) hard_barrier();
     stamp(2);
     if (p.ablate & 4) return;
     // ---- epilogue (all fragment reads of the staging LDS are behind the last barrier)
