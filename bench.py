@@ -218,7 +218,7 @@ def main():
                          "algorithmic_gflop_per_step": round(gt.flops / 1e9, 1),
                          "contract_gflop_per_step": round(GFLOP_PER_EXAMPLE * B, 1)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch)
         print(json.dumps(out))
     if world > 1:
