@@ -118,6 +118,13 @@ int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, const float
                    float* dwbox, float* dbbox, float* dbias_visn,
                    int M, int N, int P, float* workspace, int dtype, void* stream);
 
+/* The second stage of the two-stage column reductions (LayerNorm affine / bias gradients: xl_layernorm_bwd, xl_visn_ln_bwd,
+ * xl_colsum, xl_masked_colsum, xl_gemm's colsum_out) can be deferred: with xl_set_deferred_reduce(1) those calls only write
+ * their partial slabs and remember what is left to do, and xl_flush_reductions(stream) combines everything pending on that
+ * stream in one launch.  While deferred, every such call needs a workspace region of its own. */
+int xl_set_deferred_reduce(int on);
+int xl_flush_reductions(void* stream);
+
 /* ---------------------------------------------------------------- embeddings (HF:191-214)
  * y[b,l] = LN(word[ids[b,l]] + pos[l] + type[tt[b,l]]); tables in `dtype`; saves pre-LN sum + stats. */
 int xl_embed_ln_fwd(const int64_t* ids, const int64_t* tt, const void* word, const void* pos,

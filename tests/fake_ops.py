@@ -81,6 +81,12 @@ class FakeOps:
         if colsum is not None:
             torch.as_strided(colsum, (N,), (1,)).add_(c.float().sum(0))
 
+    def set_deferred_reduce(self, on):
+        pass                                   # the host restatement always reduces at once
+
+    def flush_reductions(self):
+        pass
+
     def gemm_wgrad_group(self, problems):
         for (A, B, C, M, N, K, lda, ldb, ldc) in problems:
             self.gemm(A, B, C, None, None, None, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)

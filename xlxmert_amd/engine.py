@@ -401,6 +401,7 @@ class LangHeads:
         self._gb8 = gb8
         gb8.zero_()
         ops.colsum(self.drel, gb8, B, 8, 8, ws=e.ws)
+        e.flush_reductions()                     # consumed right away
         self.gbr.add_(gb8[:2])
         w8 = torch.zeros(8, d, dtype=e.cdtype, device=e.dev) if not hasattr(self, "_w8") else self._w8
         self._w8 = w8
@@ -519,8 +520,13 @@ class Engine:
         # ---- activation-gradient ping-pong
         self.GA, self.GB = self.act(self.MX, d), self.act(self.MX, d)
         # two-stage column reductions: one workspace per stream (language / visual work runs concurrently)
-        self._ws = {"v": self.f32(ops.workspace_floats(max(3 * d, self.dff, self.F, self.Kp))),
-                    "l": self.f32(ops.workspace_floats(max(3 * d, self.dff)))}
+        # (the second stages are deferred and combined per layer -- flush_reductions -- so every producer between two flushes
+        # gets a workspace region of its own: _WS_REGIONS per stream)
+        self._ws_len = {"v": ops.workspace_floats(max(3 * d, self.dff, self.F, self.Kp)),
+                        "l": ops.workspace_floats(max(3 * d, self.dff))}
+        self._ws = {t: self.f32(self._WS_REGIONS * n) for t, n in self._ws_len.items()}
+        self._ws_i = {"v": 0, "l": 0}
+        self._deferred = False
         # The language stream (B*20 rows) fills less than half the chip per kernel; its layers are independent of the
         # visual stream inside the L/R stacks and between two cross-attention blocks, so they run on a second HIP stream.
         self._tag = "v"
@@ -539,9 +545,34 @@ class Engine:
     def f32(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
+    _WS_REGIONS = 10
+
     @property
     def ws(self):
-        return self._ws[self._tag]
+        """workspace of the next two-stage column reduction on the current stream (a fresh region while deferred)."""
+        t = self._tag
+        if not self._deferred:
+            return self._ws[t][:self._ws_len[t]]
+        i = self._ws_i[t]
+        assert i < self._WS_REGIONS, "too many column reductions between two flush_reductions()"
+        self._ws_i[t] = i + 1
+        return self._ws[t][i * self._ws_len[t]:(i + 1) * self._ws_len[t]]
+
+    def defer_reductions(self, on):
+        """backward of a training step: second stages of the column reductions are combined per layer (one launch)."""
+        import os
+        if on and os.environ.get("XL_DEFER_REDUCE", "1") == "0":
+            return
+        if on != self._deferred:
+            if not on:
+                self.flush_reductions()
+            self._deferred = on
+            self.ops.set_deferred_reduce(1 if on else 0)
+
+    def flush_reductions(self):
+        if self._deferred:
+            self.ops.flush_reductions()
+            self._ws_i[self._tag] = 0
 
     class _LangStream:
         def __init__(self, eng):
@@ -626,6 +657,7 @@ class Engine:
 
     def _ready(self, prefix):
         assert not self._pending["v"] and not self._pending["l"], "weight gradients registered but never flushed"
+        self.flush_reductions()
         self.wgrad_sync()
         if self.grad_ready is not None:
             self.grad_ready(self.store.range_of(prefix)[1])
@@ -902,8 +934,10 @@ class Engine:
 
     # ------------------------------------------------------------ backward
     def zero_accumulated_grads(self):
+        """start of a training step's backward: clear the gradient buffer, defer the column reductions' second stages."""
         st = self.store
         st.grad[st.n_mat:st.n_used].zero_()
+        self.defer_reductions(True)
 
     def head_backward(self, d_vis):
         """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis."""
@@ -959,6 +993,7 @@ class Engine:
                 with self.lang_stream():
                     blk["ffn_l"].bwd(GA[:ML], GB[:ML])
                     blk["sa_l"].bwd(GB[:ML], GA[:ML])
+                    self.flush_reductions()
                     self.wgrad_sync()
             if blk["vis_on"]:
                 blk["ffn_v"].bwd(GA[ML:], GB[ML:])
@@ -974,6 +1009,7 @@ class Engine:
                 sa, ffn = self.lang_layers[i]
                 ffn.bwd(GA[:ML], GB[:ML])
                 sa.bwd(GB[:ML], GA[:ML])
+                self.flush_reductions()
             e = "bert.embeddings"
             if self.p_hid > 0:
                 ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
@@ -983,6 +1019,7 @@ class Engine:
             ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
                           st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
                           self.B, self.L, d)
+            self.flush_reductions()
             self.wgrad_sync()
         # ---- relational (visual) stack
         for i in reversed(range(cfg.r_layers)):
@@ -1007,11 +1044,14 @@ class Engine:
             # d(mask_feat) = (sum over masked rows of d(xv)) W_visn   (ref lxrt/modeling.py:190-193: mask_feat is a Parameter)
             self.mf_tmp.zero_()
             ops.masked_colsum(dxv, self.vmask, self.mf_tmp, MV, d, d, ws=self.ws)
+            self.flush_reductions()              # consumed right away
             ops.cast_from_f32(self.mf_tmp, self.mf_tmp_c, d)
             ops.gemm(self.mf_tmp_c, st.cview(v + ".visn_fc.weight"), st.gview("mask_feat"), None, None, None, 1, self.F, d,
                      d, self.F, self.F, a_kmajor=1, b_kmajor=0, out_f32=True, accumulate=1)
+        self.flush_reductions()
         self.wgrad_sync()
         self.join()                          # language-stack gradients are final from here on
+        self.defer_reductions(False)
         if self.grad_ready is not None:
             self.grad_ready(st.n_used)
 

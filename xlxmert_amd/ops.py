@@ -51,6 +51,12 @@ class HipOps:
         """0: 128x128 GEMM kernel only; 1: by shape (default); 2: 256x256 ping-pong kernel whenever eligible."""
         self.lib.call("xl_set_gemm_pingpong", int(mode))
 
+    def set_deferred_reduce(self, on):
+        self.lib.call("xl_set_deferred_reduce", int(on))
+
+    def flush_reductions(self):
+        self.lib.call("xl_flush_reductions", self._stream())
+
     # -- dense contractions
     def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
              out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0, colsum=None, ws=None):
