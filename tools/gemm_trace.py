@@ -18,7 +18,7 @@ bias = torch.randn(N, device=dev) if ak else None
 res = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi == 2 else None
 aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi in (1, 3) else None
 lda, ldb = (K if ak else M), (K if bk else N)
-trace = torch.zeros(4 * 8192, dtype=torch.int64, device=dev)
+trace = torch.zeros(4 * 8192 + 12 * 8192, dtype=torch.int64, device=dev)
 def run():
     ops.gemm(A, B, C, bias, res, aux, M, N, K, lda, ldb, N, ldr=N, ldx=N, a_kmajor=ak, b_kmajor=bk, out_f32=of32, epilogue=epi)
 for _ in range(3):
@@ -28,7 +28,8 @@ ops.lib.call("xl_gemm_trace", trace.data_ptr())
 run()
 torch.cuda.synchronize()
 ops.lib.call("xl_gemm_trace", 0)
-t = trace.view(-1, 4).cpu()
+sec = trace[4 * 8192:].view(-1, 2, 6).cpu()
+t = trace[:4 * 8192].view(-1, 4).cpu()
 t = t[t[:, 0] > 0].double() / 100.0          # us
 t0 = t[:, 0].min()
 print(f"{len(t)} workgroups; kernel span {t[:, 3].max() - t0:.1f} us")
@@ -42,3 +43,11 @@ for lo in range(0, n, 256):
     seg = t[lo:lo + 256]
     print(f"  blocks {lo:4d}..{lo + len(seg) - 1:4d}: start {seg[:, 0].min() - t0:6.1f}..{seg[:, 0].max() - t0:6.1f}  "
           f"end {seg[:, 3].min() - t0:6.1f}..{seg[:, 3].max() - t0:6.1f} us")
+
+if sec.sum() > 0:          # library built with -DXL_PP_PROFILE: per-section cycles of wave 0 (group 0) and wave 4 (group 1)
+    nb = len(t)
+    nph = 2 * ((K + 63) // 64)
+    for gi, name in ((0, "waves 0-3"), (1, "waves 4-7")):
+        c = sec[:nb, gi].double().mean(0)
+        print(f"  {name}: per phase pair (cycles): L(P0) {c[0] * 2 / nph:6.0f}  L(P1) {c[1] * 2 / nph:6.0f}  vmcnt wait {c[5] / nph:6.0f}  "
+              f"barrier-1 wait {c[2] / nph:6.0f}  M {c[3] / nph:6.0f}  barrier-2 wait {c[4] / nph:6.0f}")

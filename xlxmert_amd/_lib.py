@@ -9,7 +9,7 @@ import torch  # noqa: F401  -- must come first: loads the HIP runtime this proce
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "xlxmert_hip.h")
-LIB_PATH = os.path.join(HERE, "libxlxmert_hip.so")
+LIB_PATH = os.environ.get("XL_LIB", os.path.join(HERE, "libxlxmert_hip.so"))      # XL_LIB: debug builds (e.g. -DXL_PP_PROFILE)
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64}
 

@@ -143,9 +143,16 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     // Every half-tile is issued two phases before the phase that waits for it (vmcnt) and three before its first read;
     // a slot is rewritten one phase after its last read, which is safe because the fragment reads are retired
     // (lgkmcnt(0)) BEFORE the barrier that ends the reading section.
+#ifdef XL_PP_PROFILE      // debug build: cycles of the sections of wave 0 / wave 4 of every workgroup (tools/gemm_trace.py --sections)
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};       // L(P0), L(P1), barrier-1 wait, M, barrier-2 wait, phases
+#define XL_T() __builtin_readcyclecounter()
+#else
+#define XL_T() 0ull
+#endif
     auto phase = [&](auto X, auto WAIT, auto ISSUE, int kt) {
         constexpr int x = decltype(X)::value;
         const uint8_t* buf = smem + (kt & 1) * BUF;
+        [[maybe_unused]] const unsigned long long t0 = XL_T();
         if constexpr (x == 0) {
             read_b(buf, ic<0>{}); read_b(buf, ic<1>{});
             read_a(buf, ic<0>{});
@@ -160,13 +167,21 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        [[maybe_unused]] const unsigned long long t1 = XL_T();
         wait_vmcnt<decltype(WAIT)::value>();
+        [[maybe_unused]] const unsigned long long t1b = XL_T();
         hard_barrier();
+        [[maybe_unused]] const unsigned long long t2 = XL_T();
         __builtin_amdgcn_s_setprio(1);
         if constexpr (x == 0) mma2(ic<0>{});
         else mma2(ic<1>{});
         __builtin_amdgcn_s_setprio(0);
+        [[maybe_unused]] const unsigned long long t3 = XL_T();
         hard_barrier();
+#ifdef XL_PP_PROFILE
+        const unsigned long long t4 = XL_T();
+        pc[x] += t1 - t0; pc[2] += t2 - t1b; pc[3] += t3 - t2; pc[4] += t4 - t3; pc[5] += t1b - t1;
+#endif
     };
 
     auto stamp = [&](int i) {
@@ -192,6 +207,12 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     phase(ic<1>{}, ic<0>{}, ic<0>{}, nkt - 1);
     if (wr == 0) hard_barrier();
     stamp(2);
+#ifdef XL_PP_PROFILE
+    if (p.trace != nullptr && lane == 0 && (wave == 0 || wave == 4)) {
+        unsigned long long* o = p.trace + 4 * 8192 + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 6;
+        for (int i = 0; i < 6; ++i) o[i] = pc[i];
+    }
+#endif
     if (p.ablate & 4) return;
     // ---- epilogue (all fragment reads of the staging LDS are behind the last barrier)
     const bool first = (z == 0);
