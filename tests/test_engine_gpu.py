@@ -157,6 +157,55 @@ def test_trainer_two_steps_fp32_vs_oracle():
             assert d < 1e-4, (t, k, d)
 
 
+def test_gradient_ranges_are_final_when_reported():
+    """The data-parallel exchange queues an in-place all-reduce the moment the engine reports a range (trainer.py
+    _on_grad_ready), on the reporting stream.  Check the report points on the real streams: a copy of every reported
+    range, taken on the stream the callback runs on, equals the gradient at the end of the step bit for bit, the
+    ranges tile the used buffer, and the language stream's block is reported before the visual stack is done."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig(l_layers=3, x_layers=2, r_layers=2)
+    tr = PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1)
+    g = torch.Generator().manual_seed(0)
+    tr.store.view("mask_feat").copy_(torch.randn(cfg.visual_feat_dim, generator=g).relu())
+    tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
+    batch = {k: v.cuda() for k, v in synthetic_batch(cfg, 64, 20, 8, seed=7).items()}
+    eng, st = tr.engine, tr.store
+    snap = torch.full_like(st.grad, float("nan"))
+    seen = []
+
+    def on_ready(lo, hi, flush, lane):
+        snap[lo:hi].copy_(st.grad[lo:hi])                      # current stream = the one a collective would follow
+        seen.append((lo, hi, lane, torch.cuda.current_stream()))
+
+    for _ in range(2):
+        seen.clear()
+        snap.fill_(float("nan"))
+        eng.grad_ready = on_ready
+        eng.set_step_seed(5)
+        eng.set_inputs(batch["input_ids"], batch["attention_mask"], None, batch["visual_pos"],
+                       cluster_ids=batch["cluster_ids"], vis_mask=batch["vis_mask"], obj_labels=batch["obj_labels"],
+                       masked_rows=batch.get("masked_rows"))
+        eng.vis_mask_forward_backward(True)
+        main = torch.cuda.current_stream()
+        for _, _, _, s in seen:
+            main.wait_stream(s)
+        torch.cuda.synchronize()
+        eng.grad_ready = None
+        pos = 0
+        for lo, hi, _, _ in sorted((r for r in seen if r[1] > r[0]), key=lambda r: r[0]):
+            assert lo == pos, (lo, pos)
+            pos = hi
+        assert pos == st.n_used
+        assert torch.equal(snap[:st.n_used], st.grad[:st.n_used])
+        lanes = [r[2] for r in seen if r[1] > r[0]]
+        assert "l" in lanes and lanes.index("l") < len(lanes) - 1 - lanes[::-1].index("v"), lanes
+        lo, hi = st.language_range()
+        assert all((lane == "l") == (lo <= a < hi) for a, b, lane, _ in seen if b > a)
+        if eng.side is not None:
+            assert any(lane == "l" and s != main for _, _, lane, s in seen)
+
+
 def test_full_size_step_properties_bf16():
     """BASELINE sizes (9/5/5, d=768, bs=256, 20x64 tokens, 10k codebook): size-independent properties.
     (1) pad isolation (SURVEY 0.6 V1): changing token ids at padded positions changes no visual output bit;

@@ -181,6 +181,13 @@ def _dp_worker(rank, world, port, out_dir):
     batch = synthetic_batch(cfg, B, L, grid, seed=500 + rank)         # disjoint per-rank minibatch
     tr.step(batch)
     assert len(tr._works) > 3, len(tr._works)
+    # two growing ranges: the language stream's block (language layers + embeddings) is exchanged while the visual
+    # stack's prefix is still growing, and the slices tile the used range exactly
+    lo, hi = tr.store.language_range()
+    order = [("l" if lo <= a < hi else "v") for a, _ in tr._slices]
+    assert "l" in order and order.index("l") < len(order) - 1 - order[::-1].index("v"), order
+    assert sum(b - a for a, b in tr._slices) == tr.store.n_used
+    assert tr._slices[-1][1] == tr.store.n_used                        # the visual feature encoder closes the step
     torch.save({k: tr.store.view(k).clone() for k in tr.store.names()}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -431,7 +431,12 @@ class Engine:
         self.need_lang = need_lang
         self.p_hid = cfg.hidden_dropout_prob if train_dropout else 0.0
         self.p_attn = cfg.attention_probs_dropout_prob if train_dropout else 0.0
-        self.grad_ready = None          # optional callback(hi): gradients in flat range [0, hi) are final
+        # optional callback(lo, hi, flush, lane): gradients in flat range [lo, hi) are final in the order of the CURRENT stream;
+        # flush = nothing more will be appended to this range.  Two growing ranges: main stream [0, language_range.lo) and
+        # then [language_range.hi, n_used); language stream language_range itself (exchange stream, see _ready_lang)
+        self.grad_ready = None
+        self._lane_lo = None
+        self._xs = None
         self._n_sites = 2               # sites 0 / 1: embedding and visual-feature-encoder output dropout
         self._seed = 0
         self._tmp = {}
@@ -660,7 +665,29 @@ class Engine:
         self.flush_reductions()
         self.wgrad_sync()
         if self.grad_ready is not None:
-            self.grad_ready(self.store.range_of(prefix)[1])
+            self._report("v", self.store.range_of(prefix)[1])
+
+    def _report(self, lane, hi, flush=False):
+        lo = self._lane_lo[lane]
+        if hi > lo or flush:
+            self.grad_ready(lo, max(lo, hi), flush, lane)
+            self._lane_lo[lane] = max(lo, hi)
+
+    def _ready_lang(self, hi, flush=False):
+        """inside lang_stream(): the language-range gradients below `hi` are final once the language stream and its
+        weight-gradient companion stream reach this point.  The callback runs on a third stream that waits for both, so
+        the collective it queues never holds up either of them."""
+        if self.grad_ready is None:
+            return
+        if self.side is None:
+            return self._report("l", hi, flush)
+        if self._xs is None:
+            self._xs = torch.cuda.Stream(device=self.dev)
+        self._xs.wait_event(torch.cuda.current_stream().record_event())
+        if self._dw is not None:
+            self._xs.wait_event(self._dw["l"].record_event())
+        with torch.cuda.stream(self._xs):
+            self._report("l", hi, flush)
 
     def sync_compute_weights(self):
         """refresh the compute-dtype copy of the master parameters (after load_state_dict / init)."""
@@ -938,6 +965,7 @@ class Engine:
         st = self.store
         st.grad[st.n_mat:st.n_used].zero_()
         self.defer_reductions(True)
+        self._lane_lo = {"v": 0, "l": st.language_range()[0]}
 
     def head_backward(self, d_vis):
         """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis."""
@@ -1010,6 +1038,7 @@ class Engine:
                 ffn.bwd(GA[:ML], GB[:ML])
                 sa.bwd(GB[:ML], GA[:ML])
                 self.flush_reductions()
+                self._ready_lang(st.range_of(f"bert.encoder.layer.{i}.")[1])
             e = "bert.embeddings"
             if self.p_hid > 0:
                 ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
@@ -1020,6 +1049,7 @@ class Engine:
                           st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
                           self.B, self.L, d)
             self.flush_reductions()
+            self._ready_lang(st.language_range()[1], flush=True)
             self.wgrad_sync()
         # ---- relational (visual) stack
         for i in reversed(range(cfg.r_layers)):
@@ -1053,7 +1083,10 @@ class Engine:
         self.join()                          # language-stack gradients are final from here on
         self.defer_reductions(False)
         if self.grad_ready is not None:
-            self.grad_ready(st.n_used)
+            lo, hi = st.language_range()
+            self._report("v", lo, flush=True)        # (already there: the last visual layer reported it)
+            self._lane_lo["v"] = hi
+            self._report("v", st.n_used, flush=True)
 
     # ------------------------------------------------------------ whole vis_mask step (forward + backward)
     def vis_mask_forward_backward(self, feat_loss=True):

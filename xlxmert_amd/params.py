@@ -160,7 +160,9 @@ def _backward_rank(cfg, name):
     base += cfg.l_layers
     if name.startswith("bert.pooler."):
         return 0               # only used on the pooled-output tasks, where it is finished right after the head
-    return base + 1             # visn_fc, embeddings, mask_feat: finished by the very last kernels
+    if name.startswith("bert.embeddings."):
+        return base + 1         # end of the language stream's backward (right after language layer 0)
+    return base + 2             # visn_fc, mask_feat: finished by the very last kernels of the visual stream
 
 
 class ParamStore:
@@ -170,9 +172,10 @@ class ParamStore:
         self.cfg, self.device, self.compute_dtype, self.task = cfg, torch.device(device), compute_dtype, task
         self.num_answers = num_answers
         units = build_units(cfg, task, num_answers)
-        # used tensors in the order backward FINISHES them (head, cross layers N..0, visual layers, language layers,
-        # visual feature encoder, embeddings): completed gradients form a growing prefix of the flat buffer, so the
-        # data-parallel exchange can start on contiguous buckets while backward is still running.
+        # used tensors in the order backward FINISHES them (head, cross layers N..0, visual layers | language layers,
+        # embeddings | visual feature encoder): the main stream completes a growing prefix and, at the very end, the tail;
+        # the language stream completes the block in between layer by layer (language_range), so the data-parallel
+        # exchange can start on contiguous buckets of either range while backward is still running.
         order = sorted([u for u in units if u.used], key=lambda u: _backward_rank(cfg, u.members[0].name)) \
             + [u for u in units if not u.used]
         off = 0
@@ -241,6 +244,13 @@ class ParamStore:
         n = sum(_numel(m.shape) for m in ms)
         flat = buf[ms[0].offset:ms[0].offset + n]
         return flat.view(-1, ms[0].shape[1]) if len(ms[0].shape) == 2 else flat
+
+    def language_range(self):
+        """[lo, hi) of the gradients the language stream finishes on its own (language layers, then the embeddings): a
+        contiguous block between the visual layers and the visual feature encoder, exchanged as a second growing range."""
+        lo = self.range_of("bert.encoder.layer.")[0]
+        hi = self.range_of("bert.embeddings.")[1]
+        return lo, hi
 
     def range_of(self, prefix):
         """[lo, hi) element range (incl. padding) covered by the units whose first member starts with `prefix`."""

@@ -50,7 +50,7 @@ class PretrainStep:
     def __init__(self, cfg: XLxmertConfig, batch_size, text_len=20, n_grids=64, dtype=torch.bfloat16, device=None,
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=True, train_dropout=False, store=None,
-                 bucket_mb=128, ops=None, task="vis_mask", num_answers=0):
+                 bucket_mb=64, ops=None, task="vis_mask", num_answers=0):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -100,20 +100,38 @@ class PretrainStep:
         self.store.set_centroids(centroids)
 
     # ---- gradient exchange (DDP semantics: SUM over ranks here, the 1/world factor is folded into the optimizer kernel).
-    # The flat gradient buffer is laid out in backward-completion order, so the engine reports a growing finished prefix
-    # [0, hi); every time >= bucket_elems new elements are final an asynchronous all-reduce of that contiguous slice is
-    # queued (RCCL runs it on its own stream behind an event), overlapping with the rest of backward.
+    # The flat gradient buffer is laid out in backward-completion order, so the engine reports growing finished ranges
+    # (one per stream: params.ParamStore.language_range); every time >= bucket_elems new elements of a range are final an
+    # asynchronous all-reduce of that contiguous slice is queued (RCCL runs it on its own stream behind an event recorded
+    # on the reporting stream), overlapping with the rest of backward.  Every rank queues the same slices in the same
+    # order (the order is a function of the model layout only).
     def _begin_exchange(self):
-        self._sent, self._works = 0, []
+        self._lanes, self._works, self._slices = {}, [], []
 
-    def _on_grad_ready(self, hi):
-        final = hi >= self.store.n_used
-        if hi - self._sent >= self.bucket_elems or (final and hi > self._sent):
-            self._works.append(dist.all_reduce(self.store.grad[self._sent:hi], op=dist.ReduceOp.SUM, async_op=True))
-            self._sent = hi
+    def _send(self, lo, hi):
+        self._works.append(dist.all_reduce(self.store.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self._slices.append((lo, hi))
+
+    def _on_grad_ready(self, lo, hi, flush=False, lane="v"):
+        ln = self._lanes.get(lane)
+        if ln is None or ln[1] != lo:                          # a range grows at its end; a jump starts a new one
+            if ln is not None and ln[1] > ln[0]:
+                self._send(ln[0], ln[1])
+            ln = self._lanes[lane] = [lo, lo]                  # [first unsent element, end]
+        ln[1] = hi
+        if hi > ln[0] and (flush or hi - ln[0] >= self.bucket_elems):
+            self._send(ln[0], hi)
+            ln[0] = hi
 
     def _finish_exchange(self):
-        assert self._sent == self.store.n_used, (self._sent, self.store.n_used)
+        for lane in self._lanes.values():
+            if lane[1] > lane[0]:
+                self._send(lane[0], lane[1])
+        pos = 0
+        for lo, hi in sorted(self._slices):                    # the slices tile [0, n_used): nothing twice, nothing missed
+            assert lo == pos, (lo, pos)
+            pos = hi
+        assert pos == self.store.n_used, (pos, self.store.n_used)
         for w in self._works:
             w.wait()
 
