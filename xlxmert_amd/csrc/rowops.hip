@@ -24,6 +24,18 @@ __device__ __forceinline__ void load_row(const T* row, int N, int lane, float (&
     }
 }
 
+__device__ __forceinline__ void unpack_raw(const uint4& t, float (&v)[4]) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+}
+__device__ __forceinline__ void unpack_raw(const uint4& t, float (&v)[8]) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
 template <int NIT, int VEC>
 __device__ __forceinline__ void row_stats(const float (&v)[NIT][VEC], int N, int lane, float eps, float& mean, float& rstd) {
     float s = 0.f;
@@ -73,8 +85,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // per-lane column partials -> block reduce over the 4 waves -> either plain stores into this block's workspace
 // slot (two-stage reduction, finished by reduce_partials_kernel) or atomics straight into `out` (no workspace).
-template <int NIT, int VEC>
-__device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out, int N, float* red /*[WPB][64*VEC]*/,
+template <int NIT, int VEC, int W = WPB>
+__device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out, int N, float* red /*[W][64*VEC]*/,
                                               float* ws_slot = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -90,7 +102,7 @@ __device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out
                 for (int i = 0; i < VEC; ++i) {
                     float s = 0.f;
 #pragma unroll
-                    for (int w = 0; w < WPB; ++w) s += red[(w * 64 + lane) * VEC + i];
+                    for (int w = 0; w < W; ++w) s += red[(w * 64 + lane) * VEC + i];
                     if (ws_slot != nullptr) ws_slot[col + i] = s;
                     else atomicAdd(out + col + i, s);
                 }
@@ -121,51 +133,65 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+constexpr int LNB_W = 8;   // waves per block of the LayerNorm backward: twice the rows in flight for the same number of partial slabs
+template <typename T, int NIT, int W>
+__global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, T* __restrict__ dx,
                                                      float* dgamma, float* dbeta, float* dbias_prev, int M, int N, float* ws,
                                                      T* __restrict__ dx_drop, float p_drop, float inv_keep, uint64_t seed) {
     constexpr int VEC = Elem<T>::VEC;
-    __shared__ float red[WPB * 64 * VEC];
+    __shared__ float red[W * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NIT][VEC] = {}, ab[NIT][VEC] = {}, ax[NIT][VEC] = {};
-    float g[NIT][VEC];
+    __shared__ float sgamma[NIT * 64 * VEC];      // gamma lives in LDS, not in 16 registers: 4 waves per SIMD instead of 3
+    for (int c = threadIdx.x; c < NIT * 64 * VEC; c += W * 64) sgamma[c] = c < N ? gamma[c] : 0.f;
+    __syncthreads();
+    for (int row = blockIdx.x * W + wave; row < M; row += gridDim.x * W) {
+        // the row stays in registers as loaded (16 bytes per vector) and is unpacked in both passes: fp32 copies of x and
+        // dy would cost 16 more registers, one wave per SIMD
+        uint4 xr[NIT], dr[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int col = (it * 64 + lane) * VEC;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) g[it][i] = (col < N) ? gamma[col + i] : 0.f;
-    }
-    for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
-        float xv[NIT][VEC], dv[NIT][VEC];
-        load_row<T, NIT>(x + (size_t)row * N, N, lane, xv);
-        load_row<T, NIT>(dy + (size_t)row * N, N, lane, dv);
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            xr[it] = dr[it] = make_uint4(0, 0, 0, 0);
+            if (col < N) {
+                xr[it] = *reinterpret_cast<const uint4*>(x + (size_t)row * N + col);
+                dr[it] = *reinterpret_cast<const uint4*>(dy + (size_t)row * N + col);
+            }
+        }
+        int goff = lane * VEC;
+        asm volatile("" : "+v"(goff));          // keep the LDS reads inside the loop (hoisted, they cost the registers back)
         const float mean = mean_i[row], rstd = rstd_i[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int col = (it * 64 + lane) * VEC;
-            if (col < N)
+            if (col < N) {
+                float xv[VEC], dv[VEC];
+                unpack_raw(xr[it], xv);
+                unpack_raw(dr[it], dv);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                    const float xh = (xv[it][i] - mean) * rstd;
-                    const float gd = g[it][i] * dv[it][i];
-                    xv[it][i] = xh;
+                    const float xh = (xv[i] - mean) * rstd;
+                    const float gd = sgamma[it * 64 * VEC + goff + i] * dv[i];
                     s1 += gd; s2 += gd * xh;
-                    ag[it][i] += dv[it][i] * xh;
-                    ab[it][i] += dv[it][i];
+                    ag[it][i] += dv[i] * xh;
+                    ab[it][i] += dv[i];
                 }
+            }
         }
         const float c1 = wave_sum(s1) / (float)N, c2 = wave_sum(s2) / (float)N;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int col = (it * 64 + lane) * VEC;
             if (col < N) {
-                float o[VEC];
+                float xv[VEC], dv[VEC], o[VEC];
+                unpack_raw(xr[it], xv);
+                unpack_raw(dr[it], dv);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) o[i] = rstd * (g[it][i] * dv[it][i] - c1 - xv[it][i] * c2);
+                for (int i = 0; i < VEC; ++i)
+                    o[i] = rstd * (sgamma[it * 64 * VEC + goff + i] * dv[i] - c1 - (xv[i] - mean) * rstd * c2);
                 stvec(dx + (size_t)row * N + col, o);
                 if (dx_drop != nullptr) {          // gradient through the dropout of the dense layer feeding this LN
 #pragma unroll
@@ -179,9 +205,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
     }
     float* slot = ws ? ws + (size_t)blockIdx.x * 3 * N : nullptr;
-    flush_colsums<NIT, VEC>(ag, dgamma, N, red, slot);
-    flush_colsums<NIT, VEC>(ab, dbeta, N, red, slot ? slot + N : nullptr);
-    if (dbias_prev != nullptr) flush_colsums<NIT, VEC>(ax, dbias_prev, N, red, slot ? slot + 2 * N : nullptr);
+    flush_colsums<NIT, VEC, W>(ag, dgamma, N, red, slot);
+    flush_colsums<NIT, VEC, W>(ab, dbeta, N, red, slot ? slot + N : nullptr);
+    if (dbias_prev != nullptr) flush_colsums<NIT, VEC, W>(ax, dbias_prev, N, red, slot ? slot + 2 * N : nullptr);
 }
 
 // ------------------------------------------------------------------ visual feature encoder tail (HF:468-476)
@@ -836,9 +862,9 @@ extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamm
     XL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, XL_ERR_BAD_ARG, "xl_layernorm_bwd: p_drop %f", p_drop);
     if (p_drop == 0.f) dx_dropped = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = min((M + WPB - 1) / WPB, workspace ? 512 : 1024);
+    const int grid = min((M + LNB_W - 1) / LNB_W, 512);        // 2 blocks x 8 waves per CU = the 4 waves per SIMD the kernel is built for
     DISPATCH_T(dtype, DISPATCH_NIT(T, N,
-        hipLaunchKernelGGL((ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
+        hipLaunchKernelGGL((ln_bwd_kernel<T, NIT, LNB_W>), dim3(grid), dim3(LNB_W * 64), 0, st,
                            (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace,
                            (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed);));
     XL_CHECK_LAUNCH();
