@@ -222,11 +222,12 @@ def test_layernorm_fwd_bwd(M, N, dtype, use_ws):
         close(gpu[i], cpu[i], torch.float32, "ln " + nm, f32_tol=2e-5 if dtype == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("M,use_ws", [(130, False), (130, True), (3000, True)])
+@pytest.mark.parametrize("M,use_ws,P", [(130, False, 4), (130, True, 4), (3000, True, 4), (5000, True, 3), (130, False, 2),
+                                        (300, True, 6), (130, False, 5)])      # P <= 4: constants-in-LDS kernels
 @pytest.mark.parametrize("dtype", DT)
-def test_visn_ln_fwd_bwd(dtype, M, use_ws):
+def test_visn_ln_fwd_bwd(dtype, M, use_ws, P):
     g = torch.Generator().manual_seed(3)
-    N, P = 768, 4
+    N = 768
     xv = rnd(g, M, N, dtype=dtype)
     pos = torch.rand(M, P, generator=g)
     wbox, bbox = rnd(g, N, P) * 0.5, rnd(g, N) * 0.1
@@ -356,7 +357,7 @@ def test_sdpa_fwd_bwd(nq, nk, dh, masked, dtype, tr):
 
 # ---------------------------------------------------------------- head losses
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("K", [10000, 50])
+@pytest.mark.parametrize("K", [10000, 1024, 50])      # row-in-registers kernel with 5 / 2 chunks per thread, generic kernel
 def test_ce_and_featloss(K, dtype):
     g = torch.Generator().manual_seed(K)
     B, V, F = 4, 16, 64

@@ -353,6 +353,201 @@ __global__ __launch_bounds__(256) void visn_ln_bwd_kernel(const T* __restrict__ 
     if (dbias_visn != nullptr) flush_colsums<NIT, VEC>(axv, dbias_visn, N, red, slot ? slot + 5 * N : nullptr);
 }
 
+// ---- the same two kernels for P <= 4 (X-LXMERT: 4 box coordinates), built around instruction count: the generic ones
+// issue ~9 global loads per element for the per-column constants.  Here the constants sit in LDS as column vectors
+// (16-byte reads along the 8 columns a lane owns), rows stay packed in registers, blocks loop over rows.
+constexpr int VISN_W = 8;          // waves per block
+template <int NC, int CAP>
+struct VisnLds { float c[NC][CAP]; };
+enum { VC_BBOX = 0, VC_W0 = 1, VC_GV = 5, VC_GB = 6, VC_BV = 7, VC_BB = 8 };
+
+template <int NC, int CAP>
+__device__ __forceinline__ void visn_fill(VisnLds<NC, CAP>& L, const float* wbox, const float* bbox, const float* gv,
+                                          const float* gb, const float* bv, const float* bb, int N, int P, int nthreads) {
+    for (int c = threadIdx.x; c < CAP; c += nthreads) {
+        const bool in = c < N;
+        L.c[VC_BBOX][c] = in ? bbox[c] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.c[VC_W0 + q][c] = (in && q < P) ? wbox[(size_t)c * P + q] : 0.f;
+        L.c[VC_GV][c] = in ? gv[c] : 0.f;
+        L.c[VC_GB][c] = in ? gb[c] : 0.f;
+        if constexpr (NC > VC_BV) {
+            L.c[VC_BV][c] = in ? bv[c] : 0.f;
+            L.c[VC_BB][c] = in ? bb[c] : 0.f;
+        }
+    }
+    __syncthreads();
+}
+
+template <int VEC>
+__device__ __forceinline__ void lds_vec(const float* base, int off, float (&v)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; j += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(base + off + j);
+        v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+    }
+}
+
+// box_fc pre-activation of the VEC columns at `off`: bbox + sum_q pos[q] * W[col][q], accumulated in the order q = 0..3
+template <int NC, int CAP, int VEC>
+__device__ __forceinline__ void visn_box(const VisnLds<NC, CAP>& L, int off, const float (&pr)[4], float (&s)[VEC]) {
+    lds_vec<VEC>(L.c[VC_BBOX], off, s);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float w[VEC];
+        lds_vec<VEC>(L.c[VC_W0 + q], off, w);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] = fmaf(pr[q], w[i], s[i]);
+    }
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(VISN_W * 64) void visn_ln_fwd_lds_kernel(
+        const T* __restrict__ xv, const float* __restrict__ pos, const float* __restrict__ wbox, const float* __restrict__ bbox,
+        const float* __restrict__ gv, const float* __restrict__ bv, const float* __restrict__ gb, const float* __restrict__ bb,
+        T* __restrict__ y, float* mean_v, float* rstd_v, float* mean_b, float* rstd_b, int M, int N, int P, float eps) {
+    constexpr int VEC = Elem<T>::VEC, CAP = NIT * 64 * VEC;
+    __shared__ VisnLds<9, CAP> L;
+    visn_fill(L, wbox, bbox, gv, gb, bv, bb, N, P, VISN_W * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * VISN_W + wave; row < M; row += gridDim.x * VISN_W) {
+        float v[NIT][VEC], bx[NIT][VEC];
+        load_row<T, NIT>(xv + (size_t)row * N, N, lane, v);
+        float pr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pr[q] = q < P ? pos[(size_t)row * P + q] : 0.f;
+        int loff = lane * VEC;
+        asm volatile("" : "+v"(loff));                      // constants are re-read from LDS per row, not hoisted into registers
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) visn_box<9, CAP, VEC>(L, it * 64 * VEC + loff, pr, bx[it]);    // 0 past N
+        float mv, rv, mb, rb;
+        row_stats<NIT, VEC>(v, N, lane, eps, mv, rv);
+        row_stats<NIT, VEC>(bx, N, lane, eps, mb, rb);
+        if (lane == 0) { mean_v[row] = mv; rstd_v[row] = rv; mean_b[row] = mb; rstd_b[row] = rb; }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC, off = it * 64 * VEC + loff;
+            if (col < N) {
+                float o[VEC], cgv[VEC], cbv[VEC], cgb[VEC], cbb[VEC];
+                lds_vec<VEC>(L.c[VC_GV], off, cgv); lds_vec<VEC>(L.c[VC_BV], off, cbv);
+                lds_vec<VEC>(L.c[VC_GB], off, cgb); lds_vec<VEC>(L.c[VC_BB], off, cbb);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float a = (v[it][i] - mv) * rv * cgv[i] + cbv[i];
+                    const float b = (bx[it][i] - mb) * rb * cgb[i] + cbb[i];
+                    o[i] = (a + b) / 2;
+                }
+                stvec(y + (size_t)row * N + col, o);
+            }
+        }
+    }
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(VISN_W * 64, 2) void visn_ln_bwd_lds_kernel(
+        const T* __restrict__ dy, const T* __restrict__ xv, const float* __restrict__ pos, const float* __restrict__ wbox,
+        const float* __restrict__ bbox, const float* __restrict__ gv, const float* __restrict__ gb,
+        const float* __restrict__ mean_v, const float* __restrict__ rstd_v, const float* __restrict__ mean_b,
+        const float* __restrict__ rstd_b, T* __restrict__ dxv, float* dgv, float* dbv, float* dgb, float* dbb, float* dwbox,
+        float* dbbox, float* dbias_visn, int M, int N, int P, float* ws) {
+    constexpr int VEC = Elem<T>::VEC, CAP = NIT * 64 * VEC;
+    __shared__ VisnLds<7, CAP> L;
+    visn_fill(L, wbox, bbox, gv, gb, nullptr, nullptr, N, P, VISN_W * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float agv[NIT][VEC] = {}, abv[NIT][VEC] = {}, agb[NIT][VEC] = {}, abx[NIT][VEC] = {}, axv[NIT][VEC] = {};
+    // d(box_fc.weight)[:, q] partials live in LDS, one private slice per wave (index [q][it][i][lane]: conflict-free plain
+    // read-modify-write).  In registers they cost 64 VGPRs and push the kernel into scratch; as ds_add_f32 on a slice shared
+    // by the block they cost 230 us (LDS float atomics run a few lanes per clock).  156 KB of LDS: one block per CU.
+    __shared__ float s_aw[VISN_W][4 * CAP];
+    float* red = &s_aw[0][0];            // reused for the block reductions once the slices are summed
+    float* my_aw = s_aw[wave];
+    for (int c = lane; c < 4 * CAP; c += 64) my_aw[c] = 0.f;
+    for (int row = blockIdx.x * VISN_W + wave; row < M; row += gridDim.x * VISN_W) {
+        uint4 xr[NIT], dr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            xr[it] = dr[it] = make_uint4(0, 0, 0, 0);
+            if (col < N) {
+                xr[it] = *reinterpret_cast<const uint4*>(xv + (size_t)row * N + col);
+                dr[it] = *reinterpret_cast<const uint4*>(dy + (size_t)row * N + col);
+            }
+        }
+        float pr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pr[q] = q < P ? pos[(size_t)row * P + q] : 0.f;
+        const float mv = mean_v[row], rv = rstd_v[row], mb = mean_b[row], rb = rstd_b[row];
+        int loff = lane * VEC;
+        asm volatile("" : "+v"(loff));
+        float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC, off = it * 64 * VEC + loff;
+            if (col < N) {
+                float x[VEC], d[VEC], s[VEC], cgv[VEC], cgb[VEC];
+                unpack_raw(xr[it], x);
+                unpack_raw(dr[it], d);
+                visn_box<7, CAP, VEC>(L, off, pr, s);
+                lds_vec<VEC>(L.c[VC_GV], off, cgv);
+                lds_vec<VEC>(L.c[VC_GB], off, cgb);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float dh = d[i] * 0.5f;                    // d(LN out) of either branch
+                    const float xh = (x[i] - mv) * rv, bh = (s[i] - mb) * rb;
+                    const float g1 = cgv[i] * dh, g2 = cgb[i] * dh;
+                    s1 += g1; s2 += g1 * xh; t1 += g2; t2 += g2 * bh;
+                    agv[it][i] += dh * xh; abv[it][i] += dh; agb[it][i] += dh * bh;
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)N, c2 = wave_sum(s2) / (float)N;
+        const float e1 = wave_sum(t1) / (float)N, e2 = wave_sum(t2) / (float)N;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC, off = it * 64 * VEC + loff;
+            if (col < N) {
+                float x[VEC], d[VEC], s[VEC], cgv[VEC], cgb[VEC], o[VEC];
+                unpack_raw(xr[it], x);
+                unpack_raw(dr[it], d);
+                visn_box<7, CAP, VEC>(L, off, pr, s);
+                lds_vec<VEC>(L.c[VC_GV], off, cgv);
+                lds_vec<VEC>(L.c[VC_GB], off, cgb);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float dh = d[i] * 0.5f;
+                    const float xh = (x[i] - mv) * rv, bh = (s[i] - mb) * rb;
+                    o[i] = rv * (cgv[i] * dh - c1 - xh * c2);
+                    axv[it][i] += o[i];
+                    const float dbx = rb * (cgb[i] * dh - e1 - bh * e2);       // d(box pre-LN)
+                    abx[it][i] += dbx;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) my_aw[((q * NIT + it) * VEC + i) * 64 + lane] += dbx * pr[q];
+                }
+                stvec(dxv + (size_t)row * N + col, o);
+            }
+        }
+    }
+    float* slot = ws ? ws + (size_t)blockIdx.x * 10 * N : nullptr;
+    __syncthreads();
+    for (int c = threadIdx.x; c < 4 * CAP; c += VISN_W * 64) {       // vectors 6..9 of the slab, or atomics without workspace
+        const int l = c & 63, i = (c >> 6) % VEC, it = (c / (64 * VEC)) % NIT, q = c / CAP;
+        const int col = (it * 64 + l) * VEC + i;
+        if (col < N && q < P) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < VISN_W; ++w) t += s_aw[w][c];
+            if (ws != nullptr) slot[(size_t)(6 + q) * N + col] = t;
+            else atomicAdd(dwbox + (size_t)col * P + q, t);
+        }
+    }
+    flush_colsums<NIT, VEC, VISN_W>(agv, dgv, N, red, slot);
+    flush_colsums<NIT, VEC, VISN_W>(abv, dbv, N, red, slot ? slot + N : nullptr);
+    flush_colsums<NIT, VEC, VISN_W>(agb, dgb, N, red, slot ? slot + 2 * N : nullptr);
+    flush_colsums<NIT, VEC, VISN_W>(abv, dbb, N, red, slot ? slot + 3 * N : nullptr);      // d(beta_box) = sum dh (same as d(beta_v))
+    flush_colsums<NIT, VEC, VISN_W>(abx, dbbox, N, red, slot ? slot + 4 * N : nullptr);
+    if (dbias_visn != nullptr) flush_colsums<NIT, VEC, VISN_W>(axv, dbias_visn, N, red, slot ? slot + 5 * N : nullptr);
+}
+
 // ------------------------------------------------------------------ embeddings
 template <typename T, int NIT>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tt,
@@ -591,6 +786,92 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     }
 }
 
+// Same contract, row held in registers: one read of the logits (16-byte loads), 16-byte gradient stores.  Needs K % 8 == 0,
+// K <= 256 * 8 * CH, ldl % 4 == 0, lddl % 8 == 0 (the 10 000-way codebook head: CH = 5, 40 logits per thread).
+__device__ __forceinline__ void store8(float* p, const float (&g)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(g[0], g[1], g[2], g[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(g[4], g[5], g[6], g[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&g)[8]) { stvec(p, g); }
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ counts, T* __restrict__ dlogits,
+                                                     float* loss_out, float* row_lse, int32_t* row_argmax, float* row_maxprob,
+                                                     int M, int K, int ldl, int lddl, float grad_scale) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int row = blockIdx.x;
+    const int64_t lab = labels ? labels[row] : -100;
+    const bool valid = lab >= 0 && lab < K;
+    const bool want_aux = row_lse != nullptr || row_argmax != nullptr || row_maxprob != nullptr;
+    const float* lr = logits + (size_t)row * ldl;
+    T* dr = dlogits ? dlogits + (size_t)row * lddl : nullptr;
+    if (!valid && !want_aux) {
+        if (dr) {
+            const float z[8] = {};
+            for (int k = threadIdx.x * 8; k < K; k += 256 * 8) store8(dr + k, z);
+        }
+        return;
+    }
+    float v[CH][8];
+    float mx = -INFINITY; int am = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int k = (c * 256 + threadIdx.x) * 8;
+        if (k < K) {
+            const float4 a = *reinterpret_cast<const float4*>(lr + k), b = *reinterpret_cast<const float4*>(lr + k + 4);
+            v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w;
+            v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (v[c][i] > mx) { mx = v[c][i]; am = k + i; }
+    }
+    const float bm = block_max(mx, red);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += __expf(v[c][i] - bm);                 // exp(-inf) = 0 for the slots past K
+    const float tot = block_sum(s, red);
+    const float lse = bm + logf(tot);
+    if (want_aux) {
+        int cand = (mx == bm) ? am : 0x7fffffff;                                // smallest index among the maxima (torch.max)
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cand;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (row_argmax) row_argmax[row] = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            if (row_lse) row_lse[row] = lse;
+            if (row_maxprob) row_maxprob[row] = 1.0f / tot;
+        }
+    }
+    if (valid) {
+        const float inv_count = 1.0f / fmaxf(counts[0], 1.0f);
+        if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, (lse - lr[lab]) * inv_count);
+        if (dr) {
+            const float sc = grad_scale * inv_count;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = (c * 256 + threadIdx.x) * 8;
+                if (k < K) {
+                    float g[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] = (__expf(v[c][i] - lse) - (k + i == (int)lab ? 1.0f : 0.f)) * sc;
+                    store8(dr + k, g);
+                }
+            }
+        }
+    } else if (dr) {
+        const float z[8] = {};
+        for (int k = threadIdx.x * 8; k < K; k += 256 * 8) store8(dr + k, z);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pred, const T* __restrict__ cent,
                                                        const int64_t* __restrict__ cid, const uint8_t* __restrict__ mask,
@@ -746,6 +1027,12 @@ using namespace xl;
     }
 
 // NIT = ceil(N / (64*VEC)) rounded to {1,2,4,8}
+#define DISPATCH_NIT2(T, N, ...)   /* kernels that keep per-column state in LDS: rows of at most 2 x 64 vectors */ \
+    {                                                                               \
+        const int per__ = 64 * Elem<T>::VEC;                                        \
+        if ((N) <= per__) { constexpr int NIT = 1; __VA_ARGS__ }                    \
+        else { constexpr int NIT = 2; __VA_ARGS__ }                                 \
+    }
 #define DISPATCH_NIT(T, N, ...)                                                     \
     {                                                                               \
         const int per__ = 64 * Elem<T>::VEC;                                        \
@@ -884,9 +1171,16 @@ extern "C" int xl_visn_ln_fwd(const void* xv, const float* pos, const float* wbo
     CHECK_ROW(N, dtype);
     XL_CHECK_ARG(P >= 1 && P <= 8, XL_ERR_BAD_SHAPE, "xl_visn_ln_fwd: pos dim %d not in 1..8", P);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
-        hipLaunchKernelGGL((visn_ln_fwd_kernel<T, NIT>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
-                           (const T*)xv, pos, wbox, bbox, gv, bv, gb, bb, (T*)y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps);));
+    if (P <= 4 && N <= 128 * vec_of(dtype)) {
+        const int grid = min((M + VISN_W - 1) / VISN_W, 512);
+        DISPATCH_T(dtype, DISPATCH_NIT2(T, N,
+            hipLaunchKernelGGL((visn_ln_fwd_lds_kernel<T, NIT>), dim3(grid), dim3(VISN_W * 64), 0, st,
+                               (const T*)xv, pos, wbox, bbox, gv, bv, gb, bb, (T*)y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps);));
+    } else {
+        DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+            hipLaunchKernelGGL((visn_ln_fwd_kernel<T, NIT>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                               (const T*)xv, pos, wbox, bbox, gv, bv, gb, bb, (T*)y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps);));
+    }
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
@@ -900,11 +1194,19 @@ extern "C" int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, 
     CHECK_ROW(N, dtype);
     XL_CHECK_ARG(P >= 1 && P <= 8, XL_ERR_BAD_SHAPE, "xl_visn_ln_bwd: pos dim %d not in 1..8", P);
     hipStream_t st = (hipStream_t)stream;
-    const int grid = min((M + WPB - 1) / WPB, 256);
-    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
-        hipLaunchKernelGGL((visn_ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
-                           (const T*)dy, (const T*)xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b,
-                           (T*)dxv, dgv, dbv, dgb, dbb, dwbox, dbbox, dbias_visn, M, N, P, workspace);));
+    const bool lds = P <= 4 && N <= 128 * vec_of(dtype);
+    const int grid = lds ? min((M + VISN_W - 1) / VISN_W, 256) : min((M + WPB - 1) / WPB, 256);
+    if (lds) {
+        DISPATCH_T(dtype, DISPATCH_NIT2(T, N,
+            hipLaunchKernelGGL((visn_ln_bwd_lds_kernel<T, NIT>), dim3(grid), dim3(VISN_W * 64), 0, st,
+                               (const T*)dy, (const T*)xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b,
+                               (T*)dxv, dgv, dbv, dgb, dbb, dwbox, dbbox, dbias_visn, M, N, P, workspace);));
+    } else {
+        DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+            hipLaunchKernelGGL((visn_ln_bwd_kernel<T, NIT>), dim3(grid), dim3(256), 0, st,
+                               (const T*)dy, (const T*)xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b,
+                               (T*)dxv, dgv, dbv, dgb, dbb, dwbox, dbbox, dbias_visn, M, N, P, workspace);));
+    }
     XL_CHECK_LAUNCH();
     if (workspace) {
         ReduceOuts o = {};
@@ -995,9 +1297,21 @@ extern "C" int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const f
     XL_CHECK_ARG(M > 0 && K > 0 && ldl >= K && logits, XL_ERR_BAD_SHAPE, "xl_ce_fwd_bwd: bad shape");
     if (labels) XL_CHECK_ARG(counts != nullptr, XL_ERR_BAD_ARG, "xl_ce_fwd_bwd: counts missing");
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL((ce_kernel<T>), dim3(M), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
-                           row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
+    const bool in_regs = K % 8 == 0 && K <= 256 * 8 * 5 && ldl % 4 == 0 && (dlogits == nullptr || lddl % 8 == 0) &&
+                         ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0;
+    if (in_regs && K > 256 * 8 * 2) {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((ce_row_kernel<T, 5>), dim3(M), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+                               row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
+    } else if (in_regs) {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((ce_row_kernel<T, 2>), dim3(M), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+                               row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
+    } else {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((ce_kernel<T>), dim3(M), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+                               row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
+    }
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
