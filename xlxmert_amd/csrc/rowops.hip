@@ -701,20 +701,26 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
 }
 
 // ------------------------------------------------------------------ head losses
-__global__ __launch_bounds__(256) void mask_counts_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ vis_mask,
-                                                          float* counts, float* nmask, int B, int V) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void mask_counts_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ vis_mask,
+                                                           float* counts, float* nmask, int B, int V) {
+    // one 16-wave block (the result is two tiny vectors; what matters is the number of loads in flight)
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float c = 0.f;
-    for (int i = threadIdx.x; i < B * V; i += 256) c += labels[i] != -100 ? 1.f : 0.f;
+    for (int i = threadIdx.x; i < B * V; i += 1024) c += labels[i] != -100 ? 1.f : 0.f;
     c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    if (lane == 0) red[wave] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[0] = red[0] + red[1] + red[2] + red[3];
-    for (int b = threadIdx.x >> 6; b < B; b += 4) {
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        counts[0] = t;
+    }
+    for (int b = wave; b < B; b += 16) {
         float s = 0.f;
-        for (int v = threadIdx.x & 63; v < V; v += 64) s += vis_mask[b * V + v] ? 1.f : 0.f;
+        for (int v = lane; v < V; v += 64) s += vis_mask[b * V + v] ? 1.f : 0.f;
         s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0) nmask[b] = s;
+        if (lane == 0) nmask[b] = s;
     }
 }
 
@@ -801,10 +807,12 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
                                                      int M, int K, int ldl, int lddl, float grad_scale) {
     __shared__ float red[4];
     __shared__ int redi[4];
-    const int row = blockIdx.x;
+    const bool want_aux = row_lse != nullptr || row_argmax != nullptr || row_maxprob != nullptr;
+    const float inv_count = (labels && counts) ? 1.0f / fmaxf(counts[0], 1.0f) : 0.f;
+    float loss_acc = 0.f;                         // thread 0: ONE loss atomic per block (per row they serialise on one address)
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
     const int64_t lab = labels ? labels[row] : -100;
     const bool valid = lab >= 0 && lab < K;
-    const bool want_aux = row_lse != nullptr || row_argmax != nullptr || row_maxprob != nullptr;
     const float* lr = logits + (size_t)row * ldl;
     T* dr = dlogits ? dlogits + (size_t)row * lddl : nullptr;
     if (!valid && !want_aux) {
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
             const float z[8] = {};
             for (int k = threadIdx.x * 8; k < K; k += 256 * 8) store8(dr + k, z);
         }
-        return;
+        continue;
     }
     float v[CH][8];
     float mx = -INFINITY; int am = 0;
@@ -851,8 +859,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
         }
     }
     if (valid) {
-        const float inv_count = 1.0f / fmaxf(counts[0], 1.0f);
-        if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, (lse - lr[lab]) * inv_count);
+        if (threadIdx.x == 0) loss_acc += (lse - lr[lab]) * inv_count;
         if (dr) {
             const float sc = grad_scale * inv_count;
 #pragma unroll
@@ -870,6 +877,8 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
         const float z[8] = {};
         for (int k = threadIdx.x * 8; k < K; k += 256 * 8) store8(dr + k, z);
     }
+    }
+    if (threadIdx.x == 0 && loss_out && loss_acc != 0.f) atomicAdd(loss_out, loss_acc);
 }
 
 template <typename T>
@@ -879,28 +888,36 @@ __global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pre
                                                        float* loss_out, int B, int V, int F, float grad_scale,
                                                        const int* __restrict__ rows, int n_rows) {
     constexpr int VEC = Elem<T>::VEC;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * WPB + (threadIdx.x >> 6);      // row of pred / dpred
-    if (row >= n_rows) return;
-    const int gr = rows ? rows[row] : row;                       // (example, grid position) it belongs to
-    const int b = gr / V;
-    const float w = mask[gr] ? 1.0f / (fmaxf(nmask[b], 1.0f) * (float)B) : 0.f;
-    const T* tgt = cent + (size_t)cid[gr] * F;
-    float s = 0.f;
-    for (int col = lane * VEC; col < F; col += 64 * VEC) {
-        float p[VEC], t[VEC], g[VEC];
-        ldvec(pred + (size_t)row * F + col, p);
-        ldvec(tgt + col, t);
+    __shared__ float red[WPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;                                             // this wave's share of the loss: ONE atomic per block at the
+    for (int row = blockIdx.x * WPB + wave; row < n_rows; row += gridDim.x * WPB) {      // end (8k same-address atomics: 120 us)
+        const int gr = rows ? rows[row] : row;                   // (example, grid position) the row of pred / dpred belongs to
+        const int b = gr / V;
+        const float w = mask[gr] ? 1.0f / (fmaxf(nmask[b], 1.0f) * (float)B) : 0.f;
+        const T* tgt = cent + (size_t)cid[gr] * F;
+        float s = 0.f;
+        for (int col = lane * VEC; col < F; col += 64 * VEC) {
+            float p[VEC], t[VEC], g[VEC];
+            ldvec(pred + (size_t)row * F + col, p);
+            ldvec(tgt + col, t);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float d = p[i] - t[i], ad = fabsf(d);
-            s += ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
-            g[i] = grad_scale * w / (float)F * fminf(fmaxf(d, -1.0f), 1.0f);
+            for (int i = 0; i < VEC; ++i) {
+                const float d = p[i] - t[i], ad = fabsf(d);
+                s += ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+                g[i] = grad_scale * w / (float)F * fminf(fmaxf(d, -1.0f), 1.0f);
+            }
+            if (dpred) stvec(dpred + (size_t)row * F + col, g);
         }
-        if (dpred) stvec(dpred + (size_t)row * F + col, g);
+        s = wave_sum(s);
+        if (w != 0.f) acc += w * s / (float)F;
     }
-    s = wave_sum(s);
-    if (lane == 0 && w != 0.f && loss_out) atomicAdd(loss_out, w * s / (float)F);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (t != 0.f) atomicAdd(loss_out, t);
+    }
 }
 
 // ------------------------------------------------------------------ VQA answer head pieces
@@ -1286,7 +1303,7 @@ extern "C" int xl_colsum(const void* x, float* out, int M, int N, int ldx, float
 
 extern "C" int xl_mask_counts(const int64_t* labels, const uint8_t* vis_mask, float* counts, float* nmask,
                               int B, int V, void* stream) {
-    hipLaunchKernelGGL(mask_counts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, labels, vis_mask, counts, nmask, B, V);
+    hipLaunchKernelGGL(mask_counts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, vis_mask, counts, nmask, B, V);
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
@@ -1301,11 +1318,11 @@ extern "C" int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const f
                          ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0;
     if (in_regs && K > 256 * 8 * 2) {
         DISPATCH_T(dtype,
-            hipLaunchKernelGGL((ce_row_kernel<T, 5>), dim3(M), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+            hipLaunchKernelGGL((ce_row_kernel<T, 5>), dim3(min(M, 2048)), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
                                row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
     } else if (in_regs) {
         DISPATCH_T(dtype,
-            hipLaunchKernelGGL((ce_row_kernel<T, 2>), dim3(M), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+            hipLaunchKernelGGL((ce_row_kernel<T, 2>), dim3(min(M, 2048)), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
                                row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
     } else {
         DISPATCH_T(dtype,
@@ -1324,7 +1341,7 @@ extern "C" int xl_featloss_fwd_bwd(const void* pred, const void* centroids, cons
     const int M = rows ? n_rows : B * V;
     XL_CHECK_ARG(M > 0 && M <= B * V, XL_ERR_BAD_ARG, "xl_featloss_fwd_bwd: n_rows=%d", n_rows);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((featloss_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+        hipLaunchKernelGGL((featloss_kernel<T>), dim3(min((M + WPB - 1) / WPB, 1024)), dim3(256), 0, st,
                            (const T*)pred, (const T*)centroids, cluster_ids, vis_mask, nmask, (T*)dpred, loss_out, B, V, F, grad_scale,
                            rows, M););
     XL_CHECK_LAUNCH();
