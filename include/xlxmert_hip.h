@@ -193,7 +193,10 @@ int xl_sdpa_bwd(const void* q, const void* k, const void* v, const uint8_t* key_
                 const void* dout, const float* lse,
                 void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
                 int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
-                float p_drop, uint64_t seed, int dtype, void* stream);
+                float p_drop, uint64_t seed, float* bias_grad, float* workspace, int dtype, void* stream);
+/* bias_grad (optional, fp32 [3*H*dh]): bias_grad[q | k | v] += column sums of dq / dk / dv over all B*n rows - the bias
+ * gradients of the query/key/value projections (HF:232-239 nn.Linear) - from per-token scalars inside the kernel, without
+ * re-reading dq/dk/dv; `workspace` as for xl_colsum (the second stage obeys xl_set_deferred_reduce). */
 
 /* ---------------------------------------------------------------- head losses (ref lxrt/modeling.py:237-290)
  * counts[0] = #labels != -100 ; nmask[b] = sum_v vis_mask[b,v]            (device-side, no host sync) */

@@ -240,7 +240,7 @@ class FakeOps:
         self._heads(o, B, nq, H, dh, ldo).copy_((torch.softmax(s, -1) * self._pmask(B, H, nq, nk, p_drop, seed)) @ V_)
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
-                 lddv, scale, p_drop=0.0, seed=0):
+                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None):
         Q, K_, V_, dO = (self._heads(t, B, n, H, dh, ld).float()
                          for t, n, ld in ((q, nq, ldq), (k, nk, ldk), (v, nk, ldv), (dout, nq, ldo)))
         s = Q @ K_.transpose(-1, -2) * scale
@@ -255,6 +255,10 @@ class FakeOps:
         self._heads(dq, B, nq, H, dh, lddq).copy_(ds @ K_)
         self._heads(dk, B, nk, H, dh, lddk).copy_(ds.transpose(-1, -2) @ Q)
         self._heads(dv, B, nk, H, dh, lddv).copy_(p.transpose(-1, -2) @ dO)
+        if bias_grad is not None:
+            HD = H * dh
+            for i, g in enumerate((ds @ K_, ds.transpose(-1, -2) @ Q, p.transpose(-1, -2) @ dO)):
+                bias_grad[i * HD:(i + 1) * HD] += g.sum(dim=(0, 2)).reshape(HD)       # [B,H,n,dh] -> [H*dh]
 
     def mask_counts(self, labels, vis_mask, counts, nmask, B, V):
         counts[0] = (labels != -100).sum().float()

@@ -342,11 +342,15 @@ def test_sdpa_fwd_bwd(nq, nk, dh, masked, dtype, tr):
         dout = rnd(g, B * nq, d, dtype=dtype)
         cdq, cdk = torch.zeros(B * nq, ld, dtype=dtype), torch.zeros(B * nk, ld, dtype=dtype)
         gdq, gdk = cdq.cuda(), cdk.cuda()
+        # bias gradients of the q/k/v projections (column sums of dq | dk | dv) come out of the same call, ACCUMULATED
+        cbg = rnd(g, 3 * d)
+        gbg, gws = cbg.cuda(), torch.zeros(go.workspace_floats(d), device="cuda")
         fo.sdpa_bwd(cq, ck[:, d:], ck[:, 2 * d:], km, dout, cl, cdq, cdk[:, d:], cdk[:, 2 * d:], B, H, nq, nk, dh,
-                    ld, ld, ld, d, ld, ld, ld, scale)
+                    ld, ld, ld, d, ld, ld, ld, scale, bias_grad=cbg)
         go.sdpa_bwd(gq, gk[:, d:], gk[:, 2 * d:], gkm, dout.cuda(), cl.cuda(), gdq, gdk[:, d:], gdk[:, 2 * d:], B, H,
-                    nq, nk, dh, ld, ld, ld, d, ld, ld, ld, scale)
+                    nq, nk, dh, ld, ld, ld, d, ld, ld, ld, scale, bias_grad=gbg, ws=gws)
         torch.cuda.synchronize()
+        close(gbg.cpu(), cbg, torch.float32, "sdpa bias grads", f32_tol=1e-4 if dtype == torch.float32 else 3e-2)
         close(gdq.cpu()[:, :d], cdq[:, :d], dtype, "sdpa dq", bf16_tol=2.5e-2)
         close(gdk.cpu()[:, d:2 * d], cdk[:, d:2 * d], dtype, "sdpa dk", bf16_tol=2.5e-2)
         close(gdk.cpu()[:, 2 * d:], cdk[:, 2 * d:], dtype, "sdpa dv", bf16_tol=2.5e-2)
@@ -480,6 +484,16 @@ def test_sdpa_dropout_fwd_bwd(nq, nk, dh, dtype):
                                               scale], dict(p_drop=pd, seed=seed))
     for i, nm in ((6, "dq"), (7, "dk"), (8, "dv")):
         close(gpu2[i], cpu2[i], dtype, "sdpa dropout " + nm, bf16_tol=2.5e-2)
+    # fused bias gradients under dropout: colsum(dV) uses the dropped probabilities, colsum(dQ | dK) the dropped dP
+    cbg = torch.zeros(3 * d)
+    FakeOps(dtype).sdpa_bwd(q, k, v, None, dout, cpu[5], dq.clone(), dk.clone(), dv.clone(), B, H, nq, nk, dh, d, d, d, d, d, d,
+                            d, scale, p_drop=pd, seed=seed, bias_grad=cbg)
+    ops = hip(dtype)
+    gbg, gws = torch.zeros(3 * d, device="cuda"), torch.zeros(ops.workspace_floats(d), device="cuda")
+    ops.sdpa_bwd(q.cuda(), k.cuda(), v.cuda(), None, dout.cuda(), cpu[5].cuda(), dq.cuda(), dk.cuda(), dv.cuda(), B, H, nq, nk,
+                 dh, d, d, d, d, d, d, d, scale, p_drop=pd, seed=seed, bias_grad=gbg, ws=gws)
+    torch.cuda.synchronize()
+    close(gbg.cpu(), cbg, torch.float32, "sdpa dropout bias grads", f32_tol=1e-4 if dtype == torch.float32 else 3e-2)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -289,13 +289,18 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
                                                     bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                     int H, int nq, int nk, int ldq, int ldk, int ldv, int ldo,
                                                     int lddq, int lddk, int lddv, float scale,
-                                                    float p_drop, float inv_keep, uint64_t seed) {
+                                                    float p_drop, float inv_keep, uint64_t seed, float* __restrict__ cs_ws) {
     __shared__ __attribute__((aligned(16))) uint8_t tk[NKF * 32 * Tile<DH>::PITCH];     // K   [key][d]
     __shared__ __attribute__((aligned(16))) uint8_t tq[NQF * 32 * Tile<DH>::PITCH];     // Q   [q][d]
     __shared__ __attribute__((aligned(16))) uint8_t tdo[NQF * 32 * Tile<DH>::PITCH];    // dO  [q][d]
     __shared__ __attribute__((aligned(16))) uint8_t tv[NKF * 32 * Tile<DH>::PITCH];     // V   [key][d]
     __shared__ float s_delta[MAXN];
     __shared__ float s_lse[MAXN];
+    // bias gradients of the q/k/v projections without re-reading dQ/dK/dV: column sums factor through per-token scalars,
+    //   colsum(dK)[d] = sum_q Q[q][d] * (sum_key dS[q][key]),  colsum(dV)[d] = sum_q dO[q][d] * (sum_key P~[q][key]),
+    //   colsum(dQ)[d] = sum_key K[key][d] * (sum_q dS[q][key]),
+    // and each inner sum runs over the registers of the lane that owns the token (phase 1: query, phase 2: key).
+    __shared__ float s_ds_q[MAXN], s_p_q[MAXN], s_ds_k[MAXN];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     // NW waves share the staged tiles of one (batch, head) problem; the 32-query fragments of phase 1 and the 32-key
     // fragments of phase 2 are independent tasks dealt round-robin to the waves.
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
         }
         const int qi = j * 32 + l31;
         const float l = s_lse[qi];
-        float delta = 0.f;
+        float delta = 0.f, psum = 0.f;
 #pragma unroll
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
@@ -339,19 +344,32 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
                 bool ok = key < nk;
                 if (key_mask != nullptr) ok = ok && key_mask[b * nk + min(key, nk - 1)] != 0;
                 const float e = __expf(st[i][r] * scale - l);
-                const float pv = ok ? e : 0.f;
+                const float pv = (ok && qi < nq) ? e : 0.f;
                 float dp = dpt[i][r];
-                if (DROP) dp *= dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)key, p_drop, inv_keep);
+                if (DROP) {
+                    const float msk = dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)key, p_drop, inv_keep);
+                    dp *= msk;
+                    psum += pv * msk;
+                } else psum += pv;
                 st[i][r] = pv;
                 dpt[i][r] = dp;
                 delta += pv * dp;
             }
         delta += __shfl_xor(delta, 32, 64);
         if (hi == 0) s_delta[qi] = delta;
+        float dssum = 0.f;
 #pragma unroll
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[i][r] = st[i][r] * (dpt[i][r] - delta) * scale;       // dS^T
+            for (int r = 0; r < 16; ++r) {
+                st[i][r] = st[i][r] * (dpt[i][r] - delta) * scale;       // dS^T
+                dssum += st[i][r];
+            }
+        if (cs_ws != nullptr) {
+            psum += __shfl_xor(psum, 32, 64);
+            dssum += __shfl_xor(dssum, 32, 64);
+            if (hi == 0) { s_p_q[qi] = psum; s_ds_q[qi] = dssum; }
+        }
         // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
 #pragma unroll
         for (int id = 0; id < ND; ++id) {
@@ -396,6 +414,15 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
                 dp2[j][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
                 s2[j][r] = pv * msk;                              // P~[q][key]
             }
+        if (cs_ws != nullptr) {
+            float ksum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NQF; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ksum += dp2[j][r];
+            ksum += __shfl_xor(ksum, 32, 64);
+            if (hi == 0) s_ds_k[key] = ksum;
+        }
         // dV^T[d][key] = sum_q dO^T[d][q] P~[q][key] ;  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
 #pragma unroll
         for (int id = 0; id < ND; ++id) {
@@ -411,6 +438,26 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
             store_rows<DH>(ka, dk + (size_t)b * nk * lddk, lddk, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
         }
     }
+    if (cs_ws != nullptr) {
+        // slab b of the workspace: [q | k | v] x [H*DH] partial bias gradients of this batch element (plain stores: every
+        // element has exactly one writer; the second stage sums the B slabs)
+        __syncthreads();
+        constexpr int PITCH = Tile<DH>::PITCH;
+        for (int w = tid; w < 3 * DH; w += NW * 64) {
+            const int which = w / DH, d = w % DH;
+            float acc = 0.f;
+            if (which == 0) {
+                for (int key = 0; key < NKF * 32; ++key)
+                    acc += bf2f(*reinterpret_cast<const bf16_t*>(tk + key * PITCH + d * 2)) * s_ds_k[key];
+            } else {
+                const uint8_t* tile = which == 1 ? tq : tdo;
+                const float* sc = which == 1 ? s_ds_q : s_p_q;
+                for (int qi = 0; qi < NQF * 32; ++qi)
+                    acc += bf2f(*reinterpret_cast<const bf16_t*>(tile + qi * PITCH + d * 2)) * sc[qi];
+            }
+            cs_ws[((size_t)b * 3 + which) * (H * DH) + h * DH + d] = acc;
+        }
+    }
 }
 
 struct SdpaArgs {
@@ -418,6 +465,7 @@ struct SdpaArgs {
     void *dq, *dk, *dv;
     int B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float scale, p_drop, inv_keep; uint64_t seed;
+    float* cs_ws;
 };
 
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
@@ -432,7 +480,7 @@ static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP, NW>), dim3(a.B * a.H), dim3(NW * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq,
                        (bf16_t*)a.dk, (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv,
-                       a.scale, a.p_drop, a.inv_keep, a.seed);
+                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws);
 }
 template <int DH, int NQF, int NKF>
 static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
@@ -516,7 +564,7 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
                            const void* dout, const float* lse,
                            void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
                            int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
-                           float p_drop, uint64_t seed, int dtype, void* stream) {
+                           float p_drop, uint64_t seed, float* bias_grad, float* workspace, int dtype, void* stream) {
     SdpaArgs a = {};
     a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.dout = dout; a.lse = const_cast<float*>(lse);
     a.dq = dq; a.dk = dk; a.dv = dv;
@@ -527,10 +575,20 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
     if (rc) return rc;
     XL_CHECK_ARG(q && k && v && dout && lse && dq && dk && dv, XL_ERR_BAD_ARG, "xl_sdpa_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    const int HD = H * dh;
+    const bool fused_bias = bias_grad != nullptr && workspace != nullptr && dtype == XL_BF16 && mfma_eligible(a, true) &&
+                            (int64_t)B * 3 * HD <= xl_workspace_floats(HD);
     if (dtype == XL_BF16 && mfma_eligible(a, true)) {
+        a.cs_ws = fused_bias ? workspace : nullptr;
         if (dh == 64) dispatch_frags<false, 64>(a, st);
         else if (dh == 32) dispatch_frags<false, 32>(a, st);
         else dispatch_frags<false, 16>(a, st);
+        XL_CHECK_LAUNCH();
+        if (fused_bias) {
+            xl::launch_colsum_reduce(workspace, B, 3 * HD, bias_grad, st);        // bias_grad[q | k | v] += sum of the B slabs
+            XL_CHECK_LAUNCH();
+            return XL_OK;
+        }
     } else if (dtype == XL_BF16) {
         hipLaunchKernelGGL((sdpa_bwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, key_mask, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, H, nq,
@@ -541,5 +599,11 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
                            dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed);
     }
     XL_CHECK_LAUNCH();
+    if (bias_grad != nullptr) {          // no fused partials on this path: column sums of the stored gradients
+        int rc2 = xl_colsum(dq, bias_grad, B * nq, HD, lddq, workspace, dtype, stream);
+        if (rc2 == XL_OK) rc2 = xl_colsum(dk, bias_grad + HD, B * nk, HD, lddk, workspace ? workspace + 1365 * (size_t)HD : nullptr, dtype, stream);
+        if (rc2 == XL_OK) rc2 = xl_colsum(dv, bias_grad + 2 * HD, B * nk, HD, lddv, workspace ? workspace + 2730 * (size_t)HD : nullptr, dtype, stream);
+        return rc2;
+    }
     return XL_OK;
 }

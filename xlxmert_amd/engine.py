@@ -77,8 +77,7 @@ class SelfAttBlock:
         km = e.kmask if self.masked else None
         ops.sdpa_bwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
-                     e.scale, e.p_attn, e.seed(self.site))
-        ops.colsum(dqkv, p.gbqkv, M, 3 * d, 3 * d, ws=e.ws)
+                     e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws)      # + d(b_q | b_k | b_v)
         e.wgrad_defer(dqkv, self.x, p.gwqkv, 3 * d, d, M, 3 * d, d, d)
         e.wgrad_flush()
         ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
@@ -203,20 +202,17 @@ class CrossAttBlock:
         qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
         ops.sdpa_bwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], e.kmask, dctx_full[ML:], self.lse_v, dqkv_v, dqkv_l[:, d:],
                      dqkv_l[:, 2 * d:], e.B, e.H, e.V, e.L, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
-                     e.p_attn, e.seed(self.site + 1))
+                     e.p_attn, e.seed(self.site + 1), bias_grad=p.gbqkv, ws=e.ws)
         X = self.X
         if self.need_lang:
             ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, dctx_full[:ML], self.lse_l, dqkv_l, dqkv_v[:, d:],
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
-                         e.p_attn, e.seed(self.site))
-            ops.colsum(dqkv, p.gbqkv, MX, 3 * d, 3 * d, ws=e.ws)
+                         e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws)      # both directions share the projections
             e.wgrad_defer(dqkv, X, p.gwqkv, 3 * d, d, MX, 3 * d, d, d)
             e.wgrad_flush()
             ops.gemm(dqkv, p.wqkv, dX, None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
         else:
-            ops.colsum(dqkv_v, p.gbqkv, MV, d, 3 * d, ws=e.ws)
-            ops.colsum(dqkv_l[:, d:], p.gbqkv[d:], ML, 2 * d, 3 * d, ws=e.ws)
             e.wgrad_defer(dqkv_v, X[ML:], p.gwqkv, d, d, MV, 3 * d, d, d)
             e.wgrad_defer(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], 2 * d, d, ML, 3 * d, d, d)
             e.wgrad_flush()
@@ -238,9 +234,8 @@ class CrossAttBlock:
         dqkv_l, dqkv_v = dqkv[:ML], dqkv[ML:]
         qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
         ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, dctx, self.lse_l, dqkv_l, dqkv_v[:, d:], dqkv_v[:, 2 * d:],
-                     e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale, e.p_attn, e.seed(self.site))
-        ops.colsum(dqkv_l, p.gbqkv, ML, d, 3 * d, ws=e.ws)
-        ops.colsum(dqkv_v[:, d:], p.gbqkv[d:], MV, 2 * d, 3 * d, ws=e.ws)
+                     e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale, e.p_attn, e.seed(self.site),
+                     bias_grad=p.gbqkv, ws=e.ws)
         e.wgrad_defer(dqkv_l, X[:ML], p.gwqkv, d, d, ML, 3 * d, d, d)
         e.wgrad_defer(dqkv_v[:, d:], X[ML:], p.gwqkv[d:], 2 * d, d, MV, 3 * d, d, d)
         e.wgrad_flush()

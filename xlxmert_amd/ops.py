@@ -154,10 +154,11 @@ class HipOps:
                       self._stream())
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
-                 lddv, scale, p_drop=0.0, seed=0):
+                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None):
         self.lib.call("xl_sdpa_bwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(dout),
                       self._p(lse), self._p(dq), self._p(dk), self._p(dv), B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq,
-                      lddk, lddv, float(scale), float(p_drop), int(seed), self.dt, self._stream())
+                      lddk, lddv, float(scale), float(p_drop), int(seed), self._p(bias_grad), self._p(ws), self.dt,
+                      self._stream())
 
     # -- head losses
     def mask_counts(self, labels, vis_mask, counts, nmask, B, V):
