@@ -206,6 +206,51 @@ def test_gradient_ranges_are_final_when_reported():
             assert any(lane == "l" and s != main for _, _, lane, s in seen)
 
 
+def test_exchange_on_one_rank_rccl_group_is_identity():
+    """The data-parallel exchange through a real RCCL process group (one rank: every all-reduce is the identity): the
+    collectives are queued from three streams (main, language-range reports, end of step) exactly as on N GPUs, and two
+    training steps must give the same losses, gradient norm and parameters as the same two steps without the exchange."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig(l_layers=3, x_layers=2, r_layers=2)
+    batch = {k: v.cuda() for k, v in synthetic_batch(cfg, 64, 20, 8, seed=7).items()}
+    g = torch.Generator().manual_seed(0)
+    mask_feat = torch.randn(cfg.visual_feat_dim, generator=g).relu()
+    cent = torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu()
+
+    def run(tr):
+        tr.store.view("mask_feat").copy_(mask_feat)
+        tr.set_centroids(cent)
+        out = [tr.step(batch).clone() for _ in range(2)]
+        torch.cuda.synchronize()
+        return out, tr.store.master.clone(), tr.grad_norm()
+
+    ref = run(PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1, bucket_mb=8))
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    os.environ["XL_FORCE_EXCHANGE"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        tr = PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1, bucket_mb=8)
+        assert tr.exchange and tr.world == 1
+        got = run(tr)
+        assert len(tr._works) > 4, len(tr._works)
+        lo, hi = tr.store.language_range()
+        assert any(lo <= a < hi for a, _ in tr._slices)
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("XL_FORCE_EXCHANGE", None)
+    # (not bit-identical: split-K and loss sums use float atomics, whose order differs from run to run)
+    for a, b in zip(ref[0], got[0]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)
+    assert (ref[1] - got[1]).abs().max().item() < 2e-5 and abs(ref[2] - got[2]) < 1e-4 * ref[2]
+
+
 def test_full_size_step_properties_bf16():
     """BASELINE sizes (9/5/5, d=768, bs=256, 20x64 tokens, 10k codebook): size-independent properties.
     (1) pad isolation (SURVEY 0.6 V1): changing token ids at padded positions changes no visual output bit;

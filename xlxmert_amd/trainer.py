@@ -10,6 +10,7 @@ one forward, one backward, gradient all-reduce (DDP mean), `clip_grad_norm_(1.0)
 scripts/pretrain.bash suggests) have no value anywhere in the reference: assumptions.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -62,6 +63,10 @@ class PretrainStep:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        # the exchange also runs on a one-rank group when asked to (XL_FORCE_EXCHANGE=1): the collectives are identities then,
+        # which is how the RCCL stream plumbing is tested on a single GPU
+        self.exchange = self.world > 1 or (dist.is_available() and dist.is_initialized()
+                                           and os.environ.get("XL_FORCE_EXCHANGE", "0") == "1")
         self.store = store if store is not None else ParamStore(cfg, self.device, dtype, task=task, num_answers=num_answers)
         self.ops = ops if ops is not None else HipOps(dtype)
         if store is None:
@@ -151,12 +156,12 @@ class PretrainStep:
             # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels | matched_labels
             eng.set_step_seed(self.t * self.world + self.rank)
             eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"])
-            if self.world > 1:
+            if self.exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
             loss = (eng.word_mask_forward_backward(batch["word_labels"]) if run == "word_mask"
                     else eng.matched_forward_backward(batch["matched_labels"]))
-            if self.world > 1:
+            if self.exchange:
                 self._finish_exchange()
             self.optimizer_step()
             return loss
@@ -164,11 +169,11 @@ class PretrainStep:
             # batch: input_ids (word_ids), visual_feats [B,V,F] (vis_feats), visual_pos (boxes), targets [B,A] soft scores
             eng.set_step_seed(self.t * self.world + self.rank)
             eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], visual_feats=batch["visual_feats"])
-            if self.world > 1:
+            if self.exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
             loss = eng.vqa_forward_backward(batch["targets"])
-            if self.world > 1:
+            if self.exchange:
                 self._finish_exchange()
             self.optimizer_step()
             return loss
@@ -179,11 +184,11 @@ class PretrainStep:
         eng.set_step_seed(self.t * self.world + self.rank)
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                        vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"))
-        if self.world > 1:
+        if self.exchange:
             self._begin_exchange()
             eng.grad_ready = self._on_grad_ready
         losses = eng.vis_mask_forward_backward(self.feat_loss)
-        if self.world > 1:
+        if self.exchange:
             self._finish_exchange()
         self.optimizer_step()
         return losses
