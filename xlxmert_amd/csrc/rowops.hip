@@ -596,26 +596,42 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     }
 }
 
+// Scatter of d(pre-LN) into the word and token-type tables: a wave per row, lanes on consecutive columns, so every atomic
+// instruction covers 256 contiguous bytes (two lines).  padding_idx = 0 rows of both tables are frozen (HF:411-413).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ ids,
-                                                        const int64_t* __restrict__ tt, float* dword, float* dpos,
-                                                        float* dtype_tab, int M, int L, int N) {
-    constexpr int VEC = Elem<T>::VEC;
+                                                        const int64_t* __restrict__ tt, float* dword, float* dtype_tab,
+                                                        int M, int N) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (row >= M) return;
     const int64_t id = ids[row], ty = tt ? tt[row] : 0;
-    const int l = row % L;
-    for (int col = lane * VEC; col < N; col += 64 * VEC) {
-        float d[VEC];
-        ldvec(dpre + (size_t)row * N + col, d);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            if (id != 0) atomicAdd(dword + (size_t)id * N + col + i, d[i]);     // padding_idx=0 rows are frozen
-            if (l != 0) atomicAdd(dpos + (size_t)l * N + col + i, d[i]);
-            if (ty != 0) atomicAdd(dtype_tab + (size_t)ty * N + col + i, d[i]);
-        }
+    if (id == 0 && ty == 0) return;
+    for (int col = lane; col < N; col += 64) {
+        const float d = Elem<T>::ld(dpre + (size_t)row * N + col);
+        if (id != 0) atomicAdd(dword + (size_t)id * N + col, d);
+        if (ty != 0) atomicAdd(dtype_tab + (size_t)ty * N + col, d);
     }
+}
+
+// Position table: position l is shared by all B examples, so its gradient is a strided column sum, not a scatter (the
+// atomics of B rows on one table row serialise).  grid (L, N / 256, slices of the batch); position 0 is frozen (padding_idx).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict__ dpre, float* dpos, int B, int L, int N) {
+    const int l = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+    if (l == 0 || col >= N) return;
+    const int per = (B + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(B, b0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        s0 += Elem<T>::ld(dpre + ((size_t)(b + 0) * L + l) * N + col);
+        s1 += Elem<T>::ld(dpre + ((size_t)(b + 1) * L + l) * N + col);
+        s2 += Elem<T>::ld(dpre + ((size_t)(b + 2) * L + l) * N + col);
+        s3 += Elem<T>::ld(dpre + ((size_t)(b + 3) * L + l) * N + col);
+    }
+    for (; b < b1; ++b) s0 += Elem<T>::ld(dpre + ((size_t)b * L + l) * N + col);
+    if (b1 > b0) atomicAdd(dpos + (size_t)l * N + col, (s0 + s1) + (s2 + s3));
 }
 
 // ------------------------------------------------------------------ codebook gather + [MASK] substitution
@@ -1255,9 +1271,12 @@ extern "C" int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t*
     CHECK_ROW(N, dtype);
     hipStream_t st = (hipStream_t)stream;
     const int M = B * L;
+    const int slices = B >= 64 ? 8 : 1;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
-                           (const T*)dpre, ids, tt, dword, dpos, dtype_tab, M, L, N););
+                           (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
+        hipLaunchKernelGGL((embed_bwd_pos_kernel<T>), dim3(L, (N + 255) / 256, slices), dim3(256), 0, st,
+                           (const T*)dpre, dpos, B, L, N););
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
