@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     const int64_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 v = g4[i];
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(g4) + i);
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
@@ -29,6 +30,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__device__ __forceinline__ void store4(float* dst, const float (&a)[4]) {
+    *reinterpret_cast<float4*>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* dst, const float (&a)[4]) {      // one 8-byte store, hardware conversion
+    uint2 w;
+    w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
+    *reinterpret_cast<uint2*>(dst) = w;
 }
 
 // one thread = 4 consecutive parameters (n is padded to a multiple of 256 by the caller's layout)
@@ -53,10 +63,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             const float t = (float)chunk_steps[i >> 6];
             step = lr * sqrtf(1.0f - exp2f(t * log2f(beta2))) / (1.0f - exp2f(t * log2f(beta1)));
         }
-        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
-        float4 mv = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+        const float4 mv = reinterpret_cast<float4*>(m)[i];
+        const float4 vv = reinterpret_cast<float4*>(v)[i];
         const bool dec = wd > 0.f && (fl & 1);
         float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
         float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -71,10 +81,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
         reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
         reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
-        if (pc != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Elem<T>::st(pc + i * 4 + j, pa[j]);
-        }
+        if (pc != nullptr) store4(pc + i * 4, pa);
     }
 }
 
