@@ -130,6 +130,48 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
 }
 
+// Two elements at a time (v_pk_mul/fma/add_f32 are full rate on gfx950: the 13 non-transcendental operations of the
+// Abramowitz-Stegun form cost half; the exp and rcp stay scalar).  Same arithmetic as erf_parts, element for element.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void erf_parts2(f32x2_t x, f32x2_t& erf_v, f32x2_t& e) {
+    f32x2_t ax = x * 0.70710678118654752440f;
+    ax.x = fabsf(ax.x); ax.y = fabsf(ax.y);
+    const f32x2_t den = ax * 0.3275911f + 1.0f;
+    f32x2_t t;
+    t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+    // exp(-ax^2) as a bare v_exp_f32 (2^x): __expf adds a denormal-range fix-up of ~4 instructions per element, and below
+    // 2^-126 the term only ever meets 1.0 (erf) or a value it cannot change (pdf term of the derivative)
+    const f32x2_t nx2 = ax * ax * -1.44269504088896340736f;
+    e.x = __builtin_amdgcn_exp2f(nx2.x); e.y = __builtin_amdgcn_exp2f(nx2.y);
+    f32x2_t poly = t * 1.061405429f + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const f32x2_t r = 1.0f - poly * t * e;
+    erf_v.x = copysignf(r.x, x.x); erf_v.y = copysignf(r.y, x.y);
+}
+__device__ __forceinline__ void gelu_fast8(float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_t x = {v[i], v[i + 1]};
+        f32x2_t er, e;
+        erf_parts2(x, er, e);
+        const f32x2_t y = x * 0.5f * (er + 1.0f);
+        v[i] = y.x; v[i + 1] = y.y;
+    }
+}
+// v[i] *= gelu'(a[i])
+__device__ __forceinline__ void gelu_grad_mul8(float (&v)[8], const float (&a)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_t x = {a[i], a[i + 1]};
+        f32x2_t er, e;
+        erf_parts2(x, er, e);
+        const f32x2_t g = (er + 1.0f) * 0.5f + x * 0.39894228040143267794f * e;
+        v[i] *= g.x; v[i + 1] *= g.y;
+    }
+}
+
 // ------------------------------------------------------------------ counter-based dropout
 // keep-mask draw for element (row, col) under (seed): one 32-bit multiply-xorshift mix ("lowbias32" constants) of
 // (row, col >> 1, seed) yields TWO 16-bit draws, for the even and the odd column of the pair; keep iff draw >= p * 2^16.

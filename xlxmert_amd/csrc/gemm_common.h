@@ -327,8 +327,7 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
         for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bv[e];
         if constexpr (EPI == XL_EPI_GELU) {
             stvec(reinterpret_cast<bf16_t*>(p.aux) + m * p.ldx + n, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+            gelu_fast8(v);
         } else if constexpr (EPI == XL_EPI_RESIDUAL) {
             float rv[8];
             unpack8(op.row[ps], rv);
@@ -341,8 +340,7 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
         } else if constexpr (EPI == XL_EPI_DGELU) {
             float av[8];
             unpack8(op.row[ps], av);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast(av[e]);
+            gelu_grad_mul8(v, av);
         }
         if (p.out_f32) {
             float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
