@@ -303,12 +303,10 @@ __device__ __forceinline__ void colsum_flush(const GemmParams& p, int lane, int 
     p.colsum_ws[(size_t)slab * p.N + nq + (lane & 7) * 8 + col] = tot;
 }
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const float* wbuf, int lane, bool first, int mq, int nq,
-                                                   const QuadOperand& op, float (&cs)[8]) {
-    const int c8 = lane & 7, rr = lane >> 3;
-    const int n = nq + c8 * 8;
-    float bv[8];
+// the 8 bias values of a lane's column segment in the fast epilogue (zeros when the launch has no bias or this is not the
+// first K split)
+__device__ __forceinline__ void load_bias8(const GemmParams& p, int lane, bool first, int nq, float (&bv)[8]) {
+    const int n = nq + (lane & 7) * 8;
     if (first && p.bias != nullptr) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
         bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
@@ -316,6 +314,13 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = 0.f;
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const float* wbuf, int lane, bool first, int mq, int nq,
+                                                   const QuadOperand& op, float (&cs)[8], const float (&bv)[8]) {
+    const int c8 = lane & 7, rr = lane >> 3;
+    const int n = nq + c8 * 8;
     const bool drop = p.p_drop > 0.0f;
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
@@ -368,8 +373,10 @@ __device__ __forceinline__ void epilogue_quad_fast(const GemmParams& p, float* w
                                                    const QuadOperand& op, const f32x16_t& a00, const f32x16_t& a01,
                                                    const f32x16_t& a10, const f32x16_t& a11) {
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bv[8];
+    load_bias8(p, lane, first, nq, bv);
     quad_to_lds(wbuf, lane, a00, a01, a10, a11);
-    epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op, cs);
+    epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op, cs, bv);
     if (p.colsum_ws != nullptr) colsum_flush(p, lane, mq >> 6, nq, cs);          // one slab per 64 rows
 }
 

@@ -188,6 +188,12 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         if (p.trace != nullptr && tid == 0) p.trace[(size_t)blockIdx.x * 4 + i] = wall_clock64();
     };
     stamp(0);
+    // the epilogue's bias segment is requested before the first DMA: older than every counted load, so the K loop's vmcnt
+    // arithmetic is unchanged, and its latency (a full miss after 15 us of streaming operands) is off the epilogue's front
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPIK >= 0) {
+        if (n0 + wc * 64 + 64 <= p.N) load_bias8(p, lane, z == 0, n0 + wc * 64, bias8);
+    }
     const int nkt = (kend - kbeg + BK - 1) / BK;
     // prologue: tile 0 complete, plus A0 | B0 | B1 of tile 1; A0, B0, B1 of tile 0 must have landed before P0(0)
     stage(ic<0>{}, 0); stage(ic<1>{}, 0); stage(ic<2>{}, 0); stage(ic<3>{}, 0);
@@ -237,11 +243,11 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
             quad_operand_load<EPIK>(p, lane, mw + 64, nw, op1);
             __builtin_amdgcn_sched_barrier(0);
             float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs);
+            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8);
             __builtin_amdgcn_sched_barrier(0);
             quad_to_lds(wbuf, lane, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1, cs);
+            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1, cs, bias8);
             if (p.colsum_ws != nullptr) colsum_flush(p, lane, mw >> 7, nw, cs);      // one slab per 128 rows
             if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
             return;
