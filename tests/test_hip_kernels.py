@@ -361,13 +361,17 @@ def test_sdpa_fwd_bwd(nq, nk, dh, masked, dtype, tr):
 
 # ---------------------------------------------------------------- head losses
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("K", [10000, 1024, 50])      # row-in-registers kernel with 5 / 2 chunks per thread, generic kernel
-def test_ce_and_featloss(K, dtype):
+@pytest.mark.parametrize("K,padded", [(10000, True), (1024, True), (30522, True), (1003, True), (50, True), (50, False)])
+def test_ce_and_featloss(K, padded, dtype):
+    """row-in-registers kernels (256 threads x 5 / 2 chunks, 1024 x 4 for the 30522-way vocabulary; K not a multiple of 8 with
+    the row stride padded to 8 and garbage in the pad columns), generic kernel for an unpadded stride."""
     g = torch.Generator().manual_seed(K)
     B, V, F = 4, 16, 64
     M = B * V
     Kp = (K + 7) // 8 * 8
-    logits = rnd(g, M, K) * 8
+    ldl = Kp if padded else K
+    logits = torch.full((M, ldl), 1e4)
+    logits[:, :K] = rnd(g, M, K) * 8
     vm = (torch.rand(B, V, generator=g) < 0.5)
     vm[3] = False                                   # an example without masked tokens (n_mask clamp)
     cid = torch.randint(0, K, (B, V), generator=g)
@@ -379,7 +383,8 @@ def test_ce_and_featloss(K, dtype):
     dl = torch.zeros(M, Kp, dtype=dtype)
     loss = torch.zeros(2)
     lse, am, mp = torch.zeros(M), torch.zeros(M, dtype=torch.int32), torch.zeros(M)
-    cpu2, gpu2 = run_both(dtype, "ce_fwd_bwd", [logits, labels, cpu[2], dl, loss, lse, am, mp, M, K, K, Kp])
+    cpu2, gpu2 = run_both(dtype, "ce_fwd_bwd", [logits, labels, cpu[2], dl, loss, lse, am, mp, M, K, ldl, Kp])
+    assert gpu2[3][:, K:].abs().max().item() == 0 if Kp > K else True          # pad columns of d(logits) stay zero
     close(gpu2[4], cpu2[4], torch.float32, "ce loss", f32_tol=1e-5)
     close(gpu2[3], cpu2[3], dtype, "ce dlogits", scale=1.0 / max(cpu[2][0].item(), 1), bf16_tol=1e-2, f32_tol=1e-4)
     close(gpu2[5], cpu2[5], torch.float32, "row lse", f32_tol=1e-5)

@@ -816,13 +816,39 @@ __device__ __forceinline__ void store8(float* p, const float (&g)[8]) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&g)[8]) { stvec(p, g); }
 
-template <typename T, int CH>
-__global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+template <int NW>
+__device__ __forceinline__ float block_max_n(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = fmaxf(r, red[w]);
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ float block_sum_n(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r += red[w];
+    return r;
+}
+
+// NT threads x CH chunks of 8 logits per thread (10 000-way codebook: 256 x 5; 30 522-way vocabulary: 1024 x 4).  K need not be
+// a multiple of 8: the row stride is (ldl, lddl >= K rounded up to 8), slots past K count as -inf and get a zero gradient.
+template <typename T, int CH, int NT>
+__global__ __launch_bounds__(NT) void ce_row_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                      const float* __restrict__ counts, T* __restrict__ dlogits,
                                                      float* loss_out, float* row_lse, int32_t* row_argmax, float* row_maxprob,
                                                      int M, int K, int ldl, int lddl, float grad_scale) {
-    __shared__ float red[4];
-    __shared__ int redi[4];
+    constexpr int NW = NT / 64;
+    __shared__ float red[NW];
+    __shared__ int redi[NW];
     const bool want_aux = row_lse != nullptr || row_argmax != nullptr || row_maxprob != nullptr;
     const float inv_count = (labels && counts) ? 1.0f / fmaxf(counts[0], 1.0f) : 0.f;
     float loss_acc = 0.f;                         // thread 0: ONE loss atomic per block (per row they serialise on one address)
@@ -834,7 +860,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
     if (!valid && !want_aux) {
         if (dr) {
             const float z[8] = {};
-            for (int k = threadIdx.x * 8; k < K; k += 256 * 8) store8(dr + k, z);
+            for (int k = threadIdx.x * 8; k < K; k += NT * 8) store8(dr + k, z);
         }
         continue;
     }
@@ -842,11 +868,15 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
     float mx = -INFINITY; int am = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int k = (c * 256 + threadIdx.x) * 8;
+        const int k = (c * NT + threadIdx.x) * 8;
         if (k < K) {
             const float4 a = *reinterpret_cast<const float4*>(lr + k), b = *reinterpret_cast<const float4*>(lr + k + 4);
             v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w;
             v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
+            if (k + 8 > K) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (k + i >= K) v[c][i] = -INFINITY;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[c][i] = -INFINITY;
@@ -854,13 +884,13 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
 #pragma unroll
         for (int i = 0; i < 8; ++i) if (v[c][i] > mx) { mx = v[c][i]; am = k + i; }
     }
-    const float bm = block_max(mx, red);
+    const float bm = block_max_n<NW>(mx, red);
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += __expf(v[c][i] - bm);                 // exp(-inf) = 0 for the slots past K
-    const float tot = block_sum(s, red);
+    const float tot = block_sum_n<NW>(s, red);
     const float lse = bm + logf(tot);
     if (want_aux) {
         int cand = (mx == bm) ? am : 0x7fffffff;                                // smallest index among the maxima (torch.max)
@@ -869,7 +899,12 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
         if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cand;
         __syncthreads();
         if (threadIdx.x == 0) {
-            if (row_argmax) row_argmax[row] = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            if (row_argmax) {
+                int r = redi[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) r = min(r, redi[w]);
+                row_argmax[row] = r;
+            }
             if (row_lse) row_lse[row] = lse;
             if (row_maxprob) row_maxprob[row] = 1.0f / tot;
         }
@@ -880,7 +915,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
             const float sc = grad_scale * inv_count;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                const int k = (c * 256 + threadIdx.x) * 8;
+                const int k = (c * NT + threadIdx.x) * 8;
                 if (k < K) {
                     float g[8];
 #pragma unroll
@@ -891,7 +926,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ l
         }
     } else if (dr) {
         const float z[8] = {};
-        for (int k = threadIdx.x * 8; k < K; k += 256 * 8) store8(dr + k, z);
+        for (int k = threadIdx.x * 8; k < K; k += NT * 8) store8(dr + k, z);
     }
     }
     if (threadIdx.x == 0 && loss_out && loss_acc != 0.f) atomicAdd(loss_out, loss_acc);
@@ -1333,15 +1368,20 @@ extern "C" int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const f
     XL_CHECK_ARG(M > 0 && K > 0 && ldl >= K && logits, XL_ERR_BAD_SHAPE, "xl_ce_fwd_bwd: bad shape");
     if (labels) XL_CHECK_ARG(counts != nullptr, XL_ERR_BAD_ARG, "xl_ce_fwd_bwd: counts missing");
     hipStream_t st = (hipStream_t)stream;
-    const bool in_regs = K % 8 == 0 && K <= 256 * 8 * 5 && ldl % 4 == 0 && (dlogits == nullptr || lddl % 8 == 0) &&
+    const int K8 = (K + 7) / 8 * 8;
+    const bool in_regs = K8 <= 1024 * 8 * 4 && ldl >= K8 && ldl % 4 == 0 && (dlogits == nullptr || (lddl >= K8 && lddl % 8 == 0)) &&
                          ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0;
-    if (in_regs && K > 256 * 8 * 2) {
+    if (in_regs && K8 > 256 * 8 * 5) {
         DISPATCH_T(dtype,
-            hipLaunchKernelGGL((ce_row_kernel<T, 5>), dim3(min(M, 2048)), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+            hipLaunchKernelGGL((ce_row_kernel<T, 4, 1024>), dim3(min(M, 1024)), dim3(1024), 0, st, logits, labels, counts, (T*)dlogits,
+                               loss_out, row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
+    } else if (in_regs && K8 > 256 * 8 * 2) {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((ce_row_kernel<T, 5, 256>), dim3(min(M, 2048)), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
                                row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
     } else if (in_regs) {
         DISPATCH_T(dtype,
-            hipLaunchKernelGGL((ce_row_kernel<T, 2>), dim3(min(M, 2048)), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
+            hipLaunchKernelGGL((ce_row_kernel<T, 2, 256>), dim3(min(M, 2048)), dim3(256), 0, st, logits, labels, counts, (T*)dlogits, loss_out,
                                row_lse, row_argmax, row_maxprob, M, K, ldl, lddl, grad_scale););
     } else {
         DISPATCH_T(dtype,
