@@ -469,15 +469,20 @@ def test_language_pretraining_steps_bf16_stated_tolerance(task):
     from xlxmert_amd.ops import HipOps
     g = load_golden("lang_tasks_tiny")
     eng, inp = make_lang_task_engine(g, task, HipOps(torch.bfloat16), device="cuda", dtype=torch.bfloat16)
+    from test_engine_cpu import labelled_rows
     labels = inp["word_labels" if task == "word_mask" else "matched_labels"].cuda()
-    loss = eng.word_mask_forward_backward(labels) if task == "word_mask" else eng.matched_forward_backward(labels)
-    torch.cuda.synchronize()
-    assert abs(loss.item() - float(g[task + ":loss"])) < 2e-2
-    for k in [str(n) for n in g[task + ":grad_names"]]:
-        ref = torch.from_numpy(g[task + ":grad:" + k]).double()
-        got = eng.store.gview(k).cpu().double()
-        rel = (got - ref).norm().item() / max(ref.norm().item(), 1e-4)
-        assert rel < 6e-2, (k, rel)
+    for rows in ((False, True) if task == "word_mask" else (False,)):      # True: decoder + loss on the labelled rows only
+        if task == "word_mask":
+            loss = eng.word_mask_forward_backward(labels, labelled_rows(labels) if rows else None)
+        else:
+            loss = eng.matched_forward_backward(labels)
+        torch.cuda.synchronize()
+        assert abs(loss.item() - float(g[task + ":loss"])) < 2e-2
+        for k in [str(n) for n in g[task + ":grad_names"]]:
+            ref = torch.from_numpy(g[task + ":grad:" + k]).double()
+            got = eng.store.gview(k).cpu().double()
+            rel = (got - ref).norm().item() / max(ref.norm().item(), 1e-4)
+            assert rel < 6e-2, (k, rel, rows)
 
 
 def test_word_mask_full_size_step_properties_bf16():
@@ -512,7 +517,7 @@ def test_task_round_robin_full_size_bf16():
     """one multi-task parameter set, full size: vis_mask / word_mask / matched steps in turn; tensors outside a step's branch
     are bit-identical after it, everything stays finite."""
     from xlxmert_amd.config import XLxmertConfig
-    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch, word_rows_of
     cfg = XLxmertConfig()
     B = 64
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=2, task="all", train_dropout=True, warmup_ratio=0.0,
@@ -525,11 +530,15 @@ def test_task_round_robin_full_size_bf16():
         batch = synthetic_batch(cfg, B, 20, 8, seed=40 + t)
         wl, ml = O.make_lang_task_labels(oc, batch["input_ids"], 50 + t)
         batch["word_labels"], batch["matched_labels"] = wl, ml
+        dev_batch = {k: v.cuda() for k, v in batch.items()}
+        dev_batch["word_rows"] = word_rows_of(wl)                  # host-side row list: masked-row decoder of the word_mask step
         before = {k: tr.store.view(k).clone() for k in ("obj_predict_head.linear_feat.weight", "cls.seq_relationship.weight",
                                                         "cls.predictions.transform.dense.weight", "bert.encoder.layer.0.output.dense.weight")}
-        loss = tr.step({k: v.cuda() for k, v in batch.items()}, task=task)
+        loss = tr.step(dev_batch, task=task)
         torch.cuda.synchronize()
         assert torch.isfinite(loss).all() and torch.isfinite(tr.store.master).all()
+        if task == "word_mask":
+            assert tr.engine.lang_heads.n_rows == int((wl >= 0).sum().item())
         same = {k: torch.equal(before[k], tr.store.view(k)) for k in before}
         assert same["obj_predict_head.linear_feat.weight"] == (task != "vis_mask")
         assert same["cls.seq_relationship.weight"] == (task != "matched")

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 import lxmert_oracle as O
 from xlxmert_amd.config import XLxmertConfig
-from xlxmert_amd.trainer import PretrainStep
+from xlxmert_amd.trainer import PretrainStep, word_rows_of
 
 cfg, oc = XLxmertConfig(), O.OracleConfig()
 dev = "cuda"
@@ -43,6 +43,7 @@ for task in ("word_mask", "matched"):
     wl, ml = O.make_lang_task_labels(oc, inp["input_ids"], 3)
     batch = cuda({"input_ids": inp["input_ids"], "visual_pos": inp["visual_pos"], "cluster_ids": inp["cluster_ids"],
                   "word_labels": wl, "matched_labels": ml})
+    batch["word_rows"] = word_rows_of(wl)          # from the loader, on the host: decoder + loss on the labelled rows only
     dt = timed(lambda: tr.step(batch))
     print(f"{task:10s} step  bs {B:4d}: {dt * 1e3:7.2f} ms  {B / dt:9.0f} examples/s")
     del tr

@@ -329,6 +329,12 @@ class LangHeads:
             self.scores = torch.zeros(ML, self.Vp, dtype=torch.float32, device=eng.dev)       # row stride padded to 8
             self.dscores = eng.act(ML, self.Vp)
             self.word_labels = torch.full((B, eng.L), -100, dtype=torch.int64, device=eng.dev)
+            # masked-row mode (training step, row list from the data loader): the 30522-way decoder, its loss and their
+            # backward run on the labelled rows only - exact, the loss reads nothing else (same idea as Engine._hrows)
+            self.rows = torch.zeros(ML, dtype=torch.int32, device=eng.dev)
+            self.rows_long = torch.zeros(ML, dtype=torch.int64, device=eng.dev)
+            self.labels_c = torch.zeros(ML, dtype=torch.int64, device=eng.dev)
+            self.n_rows = 0
         if self.has_rel:
             self.wr, self.gwr = st.cview("cls.seq_relationship.weight"), st.gview("cls.seq_relationship.weight")
             self.br, self.gbr = st.view("cls.seq_relationship.bias"), st.gview("cls.seq_relationship.bias")
@@ -342,36 +348,62 @@ class LangHeads:
         return self.e.store.grad[m.offset:m.offset + self.Vp]
 
     # ---- word_mask
+    def set_rows(self, word_rows):
+        """word_rows: flat indices b*L+l of the labelled positions (host tensor / list: its length is the launch size), or None."""
+        self.n_rows = 0
+        if word_rows is not None and 0 < len(word_rows) < self.e.ML:
+            idx = torch.as_tensor(word_rows, dtype=torch.int64)
+            self.n_rows = int(idx.numel())
+            self.rows_long[:self.n_rows].copy_(idx, non_blocking=True)
+            self.rows[:self.n_rows].copy_(idx, non_blocking=True)
+
     def mlm_fwd(self, lang):
-        e, d, ML = self.e, self.e.d, self.e.ML
+        e, d = self.e, self.e.d
         ops, st = e.ops, e.store
-        ops.gemm(lang, self.wt, self.h, self.bt, None, self.pre, ML, d, d, d, d, d, ldx=d, epilogue=EPI_GELU)
-        ops.layernorm_fwd(self.h, self.g, self.b, self.hn, self.mean, self.rstd, ML, d, 1e-12)
+        M = self.n_rows if self.n_rows else e.ML
+        if self.n_rows:
+            self.x = e.tmp("mlm_x", e.ML, d)[:M]
+            ops.gather_rows(lang, self.rows, self.x, M, d, d, d)
+        else:
+            self.x = lang
+        ops.gemm(self.x, self.wt, self.h, self.bt, None, self.pre, M, d, d, d, d, d, ldx=d, epilogue=EPI_GELU)
+        ops.layernorm_fwd(self.h, self.g, self.b, self.hn, self.mean, self.rstd, M, d, 1e-12)
         ops.gemm(self.hn, st.cview("bert.embeddings.word_embeddings.weight"), self.scores, self.vb, None, None,
-                 ML, self.Vn, d, d, d, self.Vp, out_f32=True)
+                 M, self.Vn, d, d, d, self.Vp, out_f32=True)
         return self.scores
 
     def mlm_loss_bwd(self, d_lang):
-        """CE over the masked tokens (labels -100 ignored) + backward down to d(language_output) (written to d_lang)."""
-        e, d, ML, Vn, Vp = self.e, self.e.d, self.e.ML, self.Vn, self.Vp
+        """CE over the masked tokens (labels -100 ignored) + backward down to d(language_output) (written to d_lang, which
+        the caller has zeroed)."""
+        e, d, Vn, Vp = self.e, self.e.d, self.Vn, self.Vp
         ops, st = e.ops, e.store
+        M = self.n_rows if self.n_rows else e.ML
         self.loss.zero_()
         ops.mask_counts(self.word_labels, e.kmask, self.counts, self.dummy, e.B, e.L)
-        ops.ce_fwd_bwd(self.scores, self.word_labels, self.counts, self.dscores, self.loss[0:], None, None, None,
-                       ML, Vn, Vp, Vp, 1.0)
+        labels = self.word_labels
+        if self.n_rows:
+            labels = self.labels_c[:M]
+            torch.index_select(self.word_labels.view(-1), 0, self.rows_long[:M], out=labels)
+        ops.ce_fwd_bwd(self.scores, labels, self.counts, self.dscores, self.loss[0:], None, None, None,
+                       M, Vn, Vp, Vp, 1.0)
         emb = "bert.embeddings.word_embeddings.weight"
-        ops.colsum(self.dscores, self._gvb_pad(), ML, Vp, Vp, ws=e.ws)
-        e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, ML, Vp, d, d)             # tied decoder: d(word embeddings)
-        dhn = e.tmp("dctx", ML, d)
-        ops.gemm(self.dscores, st.cview(emb), dhn, None, None, None, ML, d, Vn, Vp, d, d, a_kmajor=1, b_kmajor=0)
-        dh = e.tmp("dz", ML, d)
-        ops.layernorm_bwd(dhn, self.h, self.g, self.mean, self.rstd, dh, self.gg, self.gb, None, ML, d, ws=e.ws)
-        dpre = e.tmp("dzm", ML, d)
-        ops.gelu_bwd(dh, self.pre, dpre, ML * d)
-        ops.colsum(dpre, self.gbt, ML, d, d, ws=e.ws)
-        e.wgrad_defer(dpre, e.lang_final, self.gwt, d, d, ML, d, d, d)
+        ops.colsum(self.dscores, self._gvb_pad(), M, Vp, Vp, ws=e.ws)
+        e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, M, Vp, d, d)              # tied decoder: d(word embeddings)
+        dhn = e.tmp("dctx", e.ML, d)
+        ops.gemm(self.dscores, st.cview(emb), dhn, None, None, None, M, d, Vn, Vp, d, d, a_kmajor=1, b_kmajor=0)
+        dh = e.tmp("dz", e.ML, d)
+        ops.layernorm_bwd(dhn, self.h, self.g, self.mean, self.rstd, dh, self.gg, self.gb, None, M, d, ws=e.ws)
+        dpre = e.tmp("dzm", e.ML, d)
+        ops.gelu_bwd(dh, self.pre, dpre, M * d)
+        ops.colsum(dpre, self.gbt, M, d, d, ws=e.ws)
+        e.wgrad_defer(dpre, self.x, self.gwt, d, d, M, d, d, d)
         e.wgrad_flush()
-        ops.gemm(dpre, self.wt, d_lang, None, None, None, ML, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        if self.n_rows:
+            dx = e.tmp("mlm_dx", e.ML, d)[:M]
+            ops.gemm(dpre, self.wt, dx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+            ops.scatter_rows(dx, self.rows, d_lang, M, d, d, d)
+        else:
+            ops.gemm(dpre, self.wt, d_lang, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         return self.loss
 
     # ---- matched
@@ -843,13 +875,14 @@ class Engine:
         ops.gemm(dz, st.cview("bert.pooler.dense.weight"), d_cls, None, None, None, B, d, d, d, d, L * d,
                  a_kmajor=1, b_kmajor=0)
 
-    def word_mask_forward_backward(self, word_labels):
+    def word_mask_forward_backward(self, word_labels, word_rows=None):
         """XLxmertForPretraining.forward(task='word_mask') + backward (ref lxrt/modeling.py:211-219): un-masked codebook
         features in (set_inputs(cluster_ids=..., vis_mask=None)), MLM loss over `word_labels` (negative = ignored)."""
         lh = self.lang_heads
         wl = word_labels.clone()
         wl[wl < 0] = -100               # the reference's data code writes -1, its loss ignores -100: any negative = not masked
         lh.word_labels.copy_(wl, non_blocking=True)
+        lh.set_rows(word_rows)          # flat indices of the labelled positions (from the data loader): masked-row head
         self.encoder_forward(want_pooled=False)
         lh.mlm_fwd(self.lang_final)
         self.zero_accumulated_grads()

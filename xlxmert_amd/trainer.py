@@ -153,13 +153,14 @@ class PretrainStep:
             am = ids > 0                                       # ref lxmert_pretrain.py:206 / tasks/vqa.py:178
         if run in ("word_mask", "matched"):
             # language pretraining branches (ref lxmert_pretrain.py:159-160,180-182,192-195): un-masked codebook features;
-            # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels | matched_labels
+            # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels (+ optional word_rows:
+            # word_rows_of(word_labels), the masked-row decoder) | matched_labels
             eng.set_step_seed(self.t * self.world + self.rank)
             eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"])
             if self.exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
-            loss = (eng.word_mask_forward_backward(batch["word_labels"]) if run == "word_mask"
+            loss = (eng.word_mask_forward_backward(batch["word_labels"], batch.get("word_rows")) if run == "word_mask"
                     else eng.matched_forward_backward(batch["matched_labels"]))
             if self.exchange:
                 self._finish_exchange()
@@ -244,6 +245,12 @@ def synthetic_batch(cfg, B, L=20, grid=8, seed=9595, device="cpu", ragged=True):
              "cluster_ids": cid, "vis_mask": vm, "obj_labels": lab, "visual_pos": pos[None].expand(B, -1, -1).contiguous(),
              "masked_rows": vm.reshape(-1).nonzero().reshape(-1)}      # computed where the mask is drawn: on the host
     return {k: v.to(device) for k, v in batch.items()}
+
+
+def word_rows_of(word_labels):
+    """flat indices b*L+l of the positions that carry an MLM label - what the data loader hands over next to `word_labels`
+    (batch["word_rows"], kept on the host: its length sizes the masked-row decoder launches without a device round trip)."""
+    return (word_labels.reshape(-1) >= 0).nonzero().reshape(-1).to(torch.int32).cpu()
 
 
 def random_word_batch(input_ids, mask_token_id=103, vocab_size=30522, mlm_probability=0.15, generator=None):
