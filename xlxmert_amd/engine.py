@@ -37,6 +37,28 @@ class _Att:
         self.b, self.gb = st.view(o + ".LayerNorm.bias"), st.gview(o + ".LayerNorm.bias")
 
 
+_RESERVED_STREAMS = {}
+
+
+def reserve_streams(device):
+    """The engine's three extra HIP streams (language stream + the two weight-gradient companions), created and FIRST USED
+    here.  HIP binds a stream to one of its few hardware queues (GPU_MAX_HW_QUEUES = 4) at first use, round-robin: with the
+    main stream these four must land on four different queues, or two of them serialise behind each other's barrier
+    packets and the step loses its overlap (+3.3 ms measured).  Any stream that gets used in between shifts the assignment -
+    RCCL's does: call this BEFORE torch.distributed.init_process_group (bench.py does; measured 24.4 -> 20.5 ms per step
+    with a process group present).  Engines on one device share the streams."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _RESERVED_STREAMS:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.zeros(8, device=dev).add_(1.0)
+        torch.cuda.synchronize(dev)
+        _RESERVED_STREAMS[key] = streams
+    return _RESERVED_STREAMS[key]
+
+
 class SelfAttBlock:
     """LxmertSelfAttentionLayer (HF:304-316): y = LN(dense(attn(x,x,mask)) + x)."""
 
@@ -463,7 +485,6 @@ class Engine:
         # then [language_range.hi, n_used); language stream language_range itself (exchange stream, see _ready_lang)
         self.grad_ready = None
         self._lane_lo = None
-        self._xs = None
         self._n_sites = 2               # sites 0 / 1: embedding and visual-feature-encoder output dropout
         self._seed = 0
         self._tmp = {}
@@ -562,11 +583,12 @@ class Engine:
         # The language stream (B*20 rows) fills less than half the chip per kernel; its layers are independent of the
         # visual stream inside the L/R stacks and between two cross-attention blocks, so they run on a second HIP stream.
         self._tag = "v"
-        self.side = torch.cuda.Stream(device=self.dev) if (two_streams and self.dev.type == "cuda") else None
         # Weight-gradient GEMMs (dW = dY^T X) are off the dX dependency chain: each stream gets a companion stream for
         # them, so they co-run with the chain's next kernels (and their epilogue bursts interleave).
-        self._dw = ({"v": torch.cuda.Stream(device=self.dev), "l": torch.cuda.Stream(device=self.dev)}
-                    if (two_streams and self.dev.type == "cuda") else None)
+        self.side, self._dw = None, None
+        if two_streams and self.dev.type == "cuda":
+            self.side, dwv, dwl = reserve_streams(self.dev)
+            self._dw = {"v": dwv, "l": dwl}
 
     # ------------------------------------------------------------ memory helpers
     def act(self, *shape):
@@ -702,19 +724,12 @@ class Engine:
 
     def _ready_lang(self, hi, flush=False):
         """inside lang_stream(): the language-range gradients below `hi` are final once the language stream and its
-        weight-gradient companion stream reach this point.  The callback runs on a third stream that waits for both, so
-        the collective it queues never holds up either of them."""
+        weight-gradient companion stream reach this point: the language stream waits for the companion and issues the
+        report itself (a third stream for this would need a fifth hardware queue: see reserve_streams)."""
         if self.grad_ready is None:
             return
-        if self.side is None:
-            return self._report("l", hi, flush)
-        if self._xs is None:
-            self._xs = torch.cuda.Stream(device=self.dev)
-        self._xs.wait_event(torch.cuda.current_stream().record_event())
-        if self._dw is not None:
-            self._xs.wait_event(self._dw["l"].record_event())
-        with torch.cuda.stream(self._xs):
-            self._report("l", hi, flush)
+        self.wgrad_sync()
+        self._report("l", hi, flush)
 
     def sync_compute_weights(self):
         """refresh the compute-dtype copy of the master parameters (after load_state_dict / init)."""
