@@ -208,11 +208,14 @@ int xl_mask_counts(const int64_t* labels, const uint8_t* vis_mask, float* counts
 int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const float* counts,
                   void* dlogits, float* loss_out, float* row_lse, int32_t* row_argmax, float* row_maxprob,
                   int M, int K, int ldl, int lddl, float grad_scale, int dtype, void* stream);
-/* masked SmoothL1 feature regression: target row = centroids[cluster_ids[m]] (never masked);
+/* masked SmoothL1 feature regression (ref lxrt/modeling.py:273-287): target row m = targets[m,:] when `targets` != NULL
+ * (label_dict['feat_labels'], [B*V, F] in `dtype`: the real grid features of lxmert_pretrain.py:177-179), else
+ * centroids[cluster_ids[m]] (never masked);
  * loss_out[0] += mean_b( sum_v mask*mean_F sl1 / max(nmask_b,1) ); dpred written for every row. */
 int xl_featloss_fwd_bwd(const void* pred, const void* centroids, const int64_t* cluster_ids,
                         const uint8_t* vis_mask, const float* nmask, void* dpred, float* loss_out,
-                        int B, int V, int F, float grad_scale, const int* rows, int n_rows, int dtype, void* stream);
+                        int B, int V, int F, float grad_scale, const int* rows, int n_rows, const void* targets,
+                        int dtype, void* stream);
 /* Both head losses only read the masked positions (labels are -100 / the SmoothL1 term is multiplied by vis_mask elsewhere:
  * ref lxrt/modeling.py:253-256, 273-287), so the training step runs the head on the masked rows only:
  * xl_gather_rows: dst[r,:] = src[rows[r],:]; xl_scatter_rows: dst[rows[r],:] = src[r,:]  (rows: int32 [n_rows], ascending row
@@ -224,6 +227,11 @@ int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int
 /* ---------------------------------------------------------------- optimizer side (ref lxmert_pretrain.py:343-364)
  * sumsq[0] += sum g^2 over n fp32 elements */
 int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream);
+/* Device-side update counter and schedule (ref lxmert_pretrain.py:138-139 get_linear_schedule_with_warmup; 4.1.1 AdamW bias
+ * corrections): *step += 1 (t = the update about to be applied), lr_and_steps = {base_lr * schedule(t-1), 1-beta1^t,
+ * 1-beta2^t, t}.  Stream-ordered before xl_adamw, so the host never writes step scalars into memory a queued step reads. */
+int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, int total_steps, float beta1, float beta2,
+                     float* lr_and_steps, void* stream);
 /* transformers==4.1.1 AdamW on flat fp32 buffers with fused gradient clipping:
  * clip = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) (max_norm<=0 disables), g' = g*clip*grad_scale;
  * decay_flags: uint8 per 256-element chunk: bit 0 = apply weight decay, bit 1 = SKIP the chunk (a tensor that got no

@@ -145,6 +145,39 @@ def gen_config1(seed=9595, B=2):
     print("config1", {k: float(out[k]) for k in ("obj_loss", "feat_loss")}, "n_grads", len(grads))
 
 
+def slice_idx(n, count=192):
+    """indices of the stored gradient samples of an n-element tensor: the first 64 plus an even stride over the rest."""
+    if n <= count:
+        return np.arange(n)
+    return np.unique(np.concatenate([np.arange(64), np.linspace(64, n - 1, count - 64).astype(np.int64)]))
+
+
+def gen_full(name="full_955", seed=2718, B=8):
+    """The BENCHMARKED architecture (9/5/5 layers, d=768, 12 heads, dff=3072, 2048-d features, 10k codebook; 20 text tokens
+    with ragged lengths x 64 grid positions) run through the reference: losses, encoder outputs, sampled logits rows, the norm of
+    EVERY parameter gradient and strided samples of each (slice_idx) -- pins the d=768 kernels (256x256 ping-pong GEMM, grouped
+    weight gradients, compact head) against the reference end to end without storing 0.9 GB of gradients."""
+    cfg = O.OracleConfig()
+    torch.manual_seed(0)
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, 20, 8)
+    out, grads, bo, head = run_reference(m, inp)
+    obj = head["obj"].reshape(B * 64, -1)
+    rows = np.arange(0, B * 64, 32)
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp))
+    d.update(lang=bo.language_output.numpy(), vis=bo.vision_output.numpy(), pooled=bo.pooled_output.numpy(),
+             feat_rows=head["feat"].reshape(B * 64, -1)[rows].numpy(), obj_rows_idx=rows, obj_rows=obj[rows].numpy(),
+             obj_lse=torch.logsumexp(obj.double(), 1).numpy(), obj_argmax=obj.argmax(1).numpy())
+    for k in ("obj_loss", "feat_loss", "vis_loss", "total_loss"):
+        d[k] = out[k].detach().numpy()
+    d["grad_names"] = np.array(sorted(grads.keys()))
+    for k, g in grads.items():
+        d["gnorm:" + k] = np.array(g.double().norm().item())
+        d["gslice:" + k] = g.reshape(-1)[torch.from_numpy(slice_idx(g.numel()))].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, {k: float(out[k]) for k in ("obj_loss", "feat_loss")}, "n_grads", len(grads))
+
+
 def gen_blocks(seed=77):
     """Reference sub-modules called directly on random activations (localises a failure)."""
     cfg = O.OracleConfig(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
@@ -363,6 +396,10 @@ def gen_sampler(name, cfg, seed, B, L, grid, n_steps):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
+    if only == ["full"]:
+        gen_full()
+        sys.exit(0)
     tiny = dict(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
                 max_position_embeddings=32, visual_feat_dim=32, num_clusters=50)
     gen_blocks()
@@ -370,6 +407,7 @@ if __name__ == "__main__":
     gen_tiny("tiny_955", O.OracleConfig(l_layers=9, x_layers=5, r_layers=5, **tiny), seed=4321, B=2, L=8, grid=4,
              store_grads=False)
     gen_config1()
+    gen_full()
     gen_lang_tasks("lang_tasks_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=8642, B=3, L=8, grid=4)
     gen_sampler_ar("sampler_ar_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=9753, B=3, L=8, grid=4)
     gen_sampler("sampler_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, B=3, L=8, grid=4, n_steps=4)

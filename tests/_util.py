@@ -27,3 +27,10 @@ def maxdiff(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return (a - b).abs().max().item()
+
+
+def slice_idx(n, count=192):
+    """indices of the gradient samples stored in full_955.npz (`gslice:*`; same rule as oracle/gen_golden.py::slice_idx)."""
+    if n <= count:
+        return np.arange(n)
+    return np.unique(np.concatenate([np.arange(64), np.linspace(64, n - 1, count - 64).astype(np.int64)]))

@@ -290,11 +290,11 @@ class FakeOps:
             v2(dlogits, M, K, lddl).copy_(g)
 
     def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F, grad_scale=1.0,
-                         rows=None, n_rows=0):
+                         rows=None, n_rows=0, targets=None):
         g = torch.arange(B * V) if rows is None else rows.view(-1)[:n_rows].long()
         M = g.numel()
         p = v2(pred, M, F, F).float()
-        t = centroids[cluster_ids.view(-1)[g]].float()
+        t = (centroids[cluster_ids.view(-1)[g]] if targets is None else targets.view(B * V, F)[g]).float()
         d = p - t
         sl1 = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5).mean(1)
         w = ((vis_mask.view(-1) != 0).float() / (nmask.clamp(min=1).repeat_interleave(V) * B))[g]
@@ -313,6 +313,13 @@ class FakeOps:
 
     def sumsq(self, g, out, n):
         out[0] += (g[:n].double() ** 2).sum().float()
+
+    def schedule_step(self, step, base_lr, warmup_steps, total_steps, beta1, beta2, lr_and_steps):
+        step[0] += 1
+        t = int(step[0])
+        done = t - 1
+        f = done / max(1, warmup_steps) if done < warmup_steps else max(0.0, (total_steps - done) / max(1, total_steps - warmup_steps))
+        lr_and_steps[0], lr_and_steps[1], lr_and_steps[2], lr_and_steps[3] = base_lr * f, 1.0 - beta1 ** t, 1.0 - beta2 ** t, float(t)
 
     def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
               max_norm, grad_scale=1.0, chunk_steps=None):

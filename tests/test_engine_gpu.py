@@ -122,6 +122,104 @@ def test_config1_logits_bf16_stated_tolerance():
     assert d.max() < 1.5 and d.mean() < 0.25 and agree >= 0.9
 
 
+# ---------------------------------------------------------------- the benchmarked architecture against the reference
+def _grad_report(eng, g, slice_rel_floor=1e-3):
+    """per-tensor (relative norm error, relative L2 error of the stored samples) against full_955.npz / config1.npz."""
+    from _util import slice_idx
+    worst_n, worst_s = ("", 0.0), ("", 0.0)
+    all_s = []
+    for k in [str(n) for n in g["grad_names"]]:
+        got = eng.store.gview(k).detach().cpu().double().reshape(-1)
+        ref_n = g["gnorm:" + k].item()
+        en = abs(got.norm().item() - ref_n) / max(ref_n, 1e-6)
+        if en > worst_n[1] and ref_n > 1e-5:
+            worst_n = (k, en)
+        if "gslice:" + k in g:
+            ref = torch.from_numpy(g["gslice:" + k]).double()
+            smp = got[torch.from_numpy(slice_idx(got.numel()))]
+        elif "grad:" + k in g:
+            ref = torch.from_numpy(g["grad:" + k]).double().reshape(-1)
+            smp = got
+        else:
+            continue
+        # samples of a tensor: error relative to the samples' own norm, floored by the tensor's rms (a handful of
+        # near-zero samples must not decide)
+        rms = ref_n / max(got.numel(), 1) ** 0.5
+        es = (smp - ref).norm().item() / max(ref.norm().item(), slice_rel_floor * rms * ref.numel() ** 0.5, 1e-12)
+        if ref_n > 1e-5:            # (key biases: analytically zero gradient, the fixture holds rounding noise)
+            all_s.append(es)
+            if es > worst_s[1]:
+                worst_s = (k, es)
+    all_s.sort()
+    return worst_n, worst_s, all_s[len(all_s) // 2]
+
+
+def test_full_width_fp32_matches_reference_fixture():
+    """9/5/5 layers, d=768, 12 heads, dff=3072, 10k codebook, B=8 with ragged lengths (tests/golden/full_955.npz, outputs of
+    the reference itself): outputs, logits within 1e-3, losses, and the norm + stored samples of all 439 gradients."""
+    g = load_golden("full_955")
+    eng, oc, sd, inp = build(g, torch.float32, False)
+    eng.encoder_forward(want_pooled=False)
+    feat, logits = eng.head_forward()
+    torch.cuda.synchronize()
+    rows = g["obj_rows_idx"]
+    lg = logits.cpu()
+    assert maxdiff(eng.vis_final.cpu().view(g["vis"].shape), g["vis"]) < 2e-4
+    err = maxdiff(lg[rows], g["obj_rows"])
+    print("full_955 fp32 logits max abs err:", err)
+    assert err < 1e-3
+    assert (lg.argmax(1).numpy() == g["obj_argmax"]).all()
+    losses = eng.vis_mask_forward_backward()
+    torch.cuda.synchronize()
+    assert abs(losses[0].item() - g["obj_loss"].item()) < 1e-4 * g["obj_loss"].item()
+    assert abs(losses[1].item() - g["feat_loss"].item()) < 1e-4
+    wn, ws, med = _grad_report(eng, g)
+    print("full_955 fp32 worst gradient-norm error", wn, "worst sample error", ws, "median", med)
+    assert wn[1] < 1e-3 and ws[1] < 2e-3, (wn, ws)
+
+
+@pytest.mark.parametrize("pingpong", [2, 1])
+def test_full_width_bf16_benchmark_configuration_close_to_reference(pingpong):
+    """The configuration bench.py times -- bf16, 256x256 ping-pong GEMM forced (pingpong=2) or chosen by shape, grouped weight
+    gradients, deferred column reductions, two streams, codebook head on the masked rows only -- against the same reference
+    fixture.  Yardstick for the tolerance: the reference's own arithmetic under torch bf16 autocast (CPU, same fixture) is off
+    by 4.5 % in the worst gradient norm, 15.4 % relative L2 in the worst tensor's samples (r_layers.0 key weight, 19 layers
+    from the loss), 5.0 % in the median tensor.  This path keeps fp32 accumulators / LayerNorm / softmax and measures
+    2.2 % / 9.2 % / ~2 %: asserted below the yardstick, the median at 3 %."""
+    g = load_golden("full_955")
+    eng, oc, sd, inp = build(g, torch.bfloat16, False)
+    assert eng.compact_head and eng.side is not None
+    eng.ops.set_gemm_pingpong(pingpong)
+    try:
+        eng.set_inputs(*[inp[k].cuda() for k in ("input_ids", "attention_mask", "token_type_ids", "visual_pos")],
+                       cluster_ids=inp["cluster_ids"].cuda(), vis_mask=inp["vis_mask"].cuda(), obj_labels=inp["obj_labels"].cuda(),
+                       masked_rows=inp["vis_mask"].reshape(-1).nonzero().reshape(-1))
+        losses = eng.vis_mask_forward_backward()
+        torch.cuda.synchronize()
+    finally:
+        eng.ops.set_gemm_pingpong(1)
+    assert eng._deferred is False and 0 < eng.n_mrows < eng.MV
+    rel_loss = abs(losses[0].item() - g["obj_loss"].item()) / g["obj_loss"].item()
+    wn, ws, med = _grad_report(eng, g)
+    print(f"full_955 bf16 (pingpong={pingpong}): loss rel err {rel_loss:.4f}, worst gradient-norm error {wn}, worst sample error {ws}, "
+          f"median sample error {med:.4f}")
+    assert rel_loss < 5e-3 and abs(losses[1].item() - g["feat_loss"].item()) < 2e-3
+    assert wn[1] < 4.5e-2 and ws[1] < 0.154 and med < 3e-2, (wn, ws, med)
+
+
+@pytest.mark.parametrize("dtype,tn,ts", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 3e-2, 6e-2)])
+def test_config1_gradients_match_reference_fixture(dtype, tn, ts):
+    """BASELINE config 1 (1+1+1 layers at d=768): the norm of all 79 reference gradients (`gnorm:*`) and the stored ones."""
+    g = load_golden("config1")
+    eng, oc, sd, inp = build(g, dtype, False)
+    losses = eng.vis_mask_forward_backward()
+    torch.cuda.synchronize()
+    assert abs(losses[0].item() - g["obj_loss"].item()) < (1e-3 if dtype == torch.float32 else 1e-2 * g["obj_loss"].item())
+    wn, ws, med = _grad_report(eng, g)
+    print(f"config1 {dtype}: worst gradient-norm error {wn}, worst sample error {ws}, median {med}")
+    assert wn[1] < tn and ws[1] < ts, (wn, ws)
+
+
 def test_trainer_two_steps_fp32_vs_oracle():
     from xlxmert_amd.config import XLxmertConfig
     from xlxmert_amd.params import ParamStore
@@ -133,7 +231,7 @@ def test_trainer_two_steps_fp32_vs_oracle():
     store = ParamStore(cfg, "cuda", torch.float32)
     store.load_named(sd)
     tr = PretrainStep(cfg, 3, 8, 16, dtype=torch.float32, device="cuda", store=store, lr=1e-2, weight_decay=0.01,
-                      warmup_ratio=0.2, total_steps=10)
+                      warmup_ratio=0.2, total_steps=10, visual_losses="obj,feat")
     ref = {k: v.clone() for k, v in sd.items()}
     m = {k: torch.zeros_like(v) for k, v in ref.items()}
     v2 = {k: torch.zeros_like(v) for k, v in ref.items()}
@@ -368,16 +466,18 @@ def test_vqa_step_bf16_close_to_reference_fixture():
         assert rel < 6e-2, (k, rel)
 
 
-def test_vqa_full_size_step_properties_bf16():
-    """BASELINE config 4 geometry (full encoder, 3129 answers, real 2048-d features) at bs 64: finite loss near
-    ln(2)-level for near-zero logits, finite gradients, d(visn_fc.weight) non-zero (real-feature input path)."""
+@pytest.mark.parametrize("B", [64, 512])
+def test_vqa_full_size_step_properties_bf16(B):
+    """BASELINE config 3 geometry (full encoder, 3129 answers, real 2048-d features) at bs 64 and at the configuration's own
+    bs 512: finite loss near ln(2)-level for near-zero logits, finite gradients, d(visn_fc.weight) non-zero (real-feature
+    input path), and batch consistency: the first 64 examples' logits do not depend on what else is in the batch."""
     from xlxmert_amd.config import XLxmertConfig
     from xlxmert_amd.engine import Engine
     from xlxmert_amd.ops import HipOps
     from xlxmert_amd.params import ParamStore
     from xlxmert_amd.trainer import init_reference_weights
     cfg = XLxmertConfig()
-    B, L, V, A = 64, 20, 64, 3129
+    L, V, A = 20, 64, 3129
     store = ParamStore(cfg, "cuda", torch.bfloat16, task="vqa", num_answers=A)
     init_reference_weights(store, 7)
     eng = Engine(cfg, store, HipOps(torch.bfloat16), B, L, V, need_lang=True)
@@ -393,6 +493,18 @@ def test_vqa_full_size_step_properties_bf16():
     assert torch.isfinite(gr).all()
     assert store.gview("bert.encoder.visn_fc.visn_fc.weight").abs().max().item() > 0
     assert store.gview("answer_head.logit_fc.3.weight").abs().max().item() > 0
+    if B > 64:
+        # examples are independent (no cross-example op on the path): the first 64 examples alone give the same logits
+        # (different tile shapes / kernel choices at M = 64*20 vs 512*20 rows: agreement to bf16 rounding, not bit-wise)
+        logit_big = eng.answer.logit[:64].clone()
+        small = Engine(cfg, store, HipOps(torch.bfloat16), 64, L, V, need_lang=True)
+        small.set_inputs(inp["input_ids"][:64].cuda(), inp["attention_mask"][:64].cuda(), None, inp["visual_pos"][:64].cuda(),
+                         visual_feats=inp["visual_feats"][:64].cuda())
+        logit_small = small.vqa_forward().clone()
+        torch.cuda.synchronize()
+        d = (logit_big - logit_small).abs().max().item()
+        print("vqa bs512 vs bs64 logits max abs diff:", d, "logit scale", logit_small.abs().max().item())
+        assert d < 2e-2 * max(1.0, logit_small.abs().max().item())
 
 
 # ---------------------------------------------------------------- on-device iterative sampler

@@ -397,6 +397,13 @@ def test_ce_and_featloss(K, padded, dtype):
     cpu3, gpu3 = run_both(dtype, "featloss_fwd_bwd", [pred, cent, cid, vmu, cpu[3], dp, loss2, B, V, F])
     close(gpu3[6], cpu3[6], torch.float32, "feat loss", f32_tol=1e-5)
     close(gpu3[5], cpu3[5], dtype, "feat dpred", f32_tol=1e-5)
+    # explicit regression targets (label_dict['feat_labels'], ref lxrt/modeling.py:275) instead of the centroid rows
+    tgt = rnd(g, M, F, dtype=dtype).relu()
+    dp4, loss4 = torch.zeros(M, F, dtype=dtype), torch.zeros(2)
+    cpu4, gpu4 = run_both(dtype, "featloss_fwd_bwd", [pred, cent, cid, vmu, cpu[3], dp4, loss4, B, V, F], {"targets": tgt})
+    close(gpu4[6], cpu4[6], torch.float32, "feat loss (targets)", f32_tol=1e-5)
+    close(gpu4[5], cpu4[5], dtype, "feat dpred (targets)", f32_tol=1e-5)
+    assert abs(cpu4[6][0].item() - cpu3[6][0].item()) > 1e-4
 
 
 # ---------------------------------------------------------------- optimizer side

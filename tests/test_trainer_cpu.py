@@ -29,6 +29,7 @@ def make_step(cfg, B, L, grid, seed=3, **kw):
     store = ParamStore(cfg, "cpu", torch.float32, task="vis_mask")
     sd = O.make_state_dict(oracle_cfg(cfg), seed)
     store.load_named(sd)
+    kw.setdefault("visual_losses", "obj,feat")      # what the fixtures / the oracle's total_loss hold (the model code computes both)
     return PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store,
                         ops=FakeOps(torch.float32), total_steps=10, **kw), sd
 
@@ -68,6 +69,45 @@ def test_two_steps_match_closed_form():
             assert d < 2e-5, (t, k, d)
     # tensors without a gradient are never touched (the reference's AdamW skips grad-None tensors)
     assert torch.equal(tr.store.view("bert.pooler.dense.weight"), sd["bert.pooler.dense.weight"])
+
+
+def test_visual_losses_default_is_obj_only_and_feat_labels_are_used():
+    """--visualLosses obj (scripts/pretrain.bash:15) is the default: no feature loss, gradients = those of obj_loss alone.
+    With "obj,feat" and batch["feat_labels"] (the real grid features, ref lxmert_pretrain.py:177-179) the SmoothL1 term
+    regresses onto THOSE targets (ref lxrt/modeling.py:273-287), not onto the centroids."""
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    B, L, grid = 3, 8, 4
+    batch = synthetic_batch(cfg, B, L, grid, seed=77)
+
+    def oracle(feat_labels, with_feat):
+        leaf = {k: v.clone().requires_grad_(v.is_floating_point() and k != "vis_emb.weight")
+                for k, v in O.make_state_dict(oc, 3).items()}
+        leaf["obj_predict_head.out_cluster.weight"] = leaf["vis_emb.weight"]
+        out = O.xlxmert_vis_mask_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                         batch["cluster_ids"], batch["vis_mask"], batch["obj_labels"], feat_labels=feat_labels)
+        (out["total_loss"] if with_feat else out["obj_loss"]).backward()
+        return out, {k: v.grad for k, v in leaf.items() if v.grad is not None and k != "obj_predict_head.out_cluster.weight"}
+
+    # default: obj only
+    tr, sd = make_step(cfg, B, L, grid, visual_losses="obj")
+    assert tr.feat_loss is False and PretrainStep.__init__.__defaults__ is not None
+    tr.engine.set_inputs(batch["input_ids"], batch["attention_mask"], None, batch["visual_pos"], cluster_ids=batch["cluster_ids"],
+                         vis_mask=batch["vis_mask"], obj_labels=batch["obj_labels"])
+    losses = tr.engine.vis_mask_forward_backward(tr.feat_loss)
+    out, grads = oracle(None, False)
+    assert abs(losses[0].item() - out["obj_loss"].item()) < 3e-5 and losses[1].item() == 0.0
+    for k, g in grads.items():
+        assert (tr.store.gview(k) - g).abs().max().item() < 2e-5, k
+    # obj,feat with explicit targets
+    tgt = torch.randn(B, grid * grid, cfg.visual_feat_dim, generator=torch.Generator().manual_seed(5)).relu()
+    tr, sd = make_step(cfg, B, L, grid, visual_losses="obj,feat")
+    b2 = dict(batch, feat_labels=tgt)
+    losses = tr.step(b2)
+    out, grads = oracle(tgt, True)
+    assert abs(losses[1].item() - out["feat_loss"].item()) < 3e-5
+    out_c, _ = oracle(None, True)
+    assert abs(out["feat_loss"].item() - out_c["feat_loss"].item()) > 1e-3        # the targets really differ from the centroids
 
 
 def test_vqa_two_steps_match_closed_form():
@@ -120,7 +160,7 @@ def test_task_round_robin_on_one_parameter_set():
     sd = O.make_cls_state_dict(oc, 11)
     store.load_named(sd)
     tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
-                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="all")
+                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="all", visual_losses="obj,feat")
     ref = {k: v.clone() for k, v in sd.items() if k != "cls.predictions.decoder.weight"}
     ref["obj_predict_head.out_cluster.weight"] = ref["vis_emb.weight"]
     m = {k: torch.zeros_like(v) for k, v in ref.items()}

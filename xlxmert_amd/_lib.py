@@ -54,13 +54,15 @@ class Lib:
             fn = getattr(self._dll, name)        # raises AttributeError if the .so lacks a declared symbol
             fn.argtypes = [_ctype(t) for t, _ in args]
             fn.restype = {"char*": ctypes.c_char_p, "int64_t": ctypes.c_int64}.get(ret, ctypes.c_int)
-        self._checked = {n for n, (r, _) in self.protos.items() if r == "int"}
         self.path = path
 
     def call(self, name, *args):
+        """status-returning entry points: 0 = ok, negative = XL_ERR_* (the error convention of include/xlxmert_hip.h).
+        Value-returning ones (xl_version, xl_workspace_floats, xl_last_error) go through raw()."""
         rc = getattr(self._dll, name)(*args)
-        if rc != 0:
+        if rc < 0:
             raise XlError(f"{name} failed ({rc}): {self._dll.xl_last_error().decode()}")
+        return rc
 
     def raw(self, name):
         return getattr(self._dll, name)

@@ -94,6 +94,21 @@ __global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* __restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = Elem<T>::ld(src + i);
 }
 
+// one thread: advance the device-side update counter and derive the step's scalars from it (transformers
+// get_linear_schedule_with_warmup + the 4.1.1 AdamW bias corrections): no host buffer a running-ahead host could overwrite
+__global__ void schedule_step_kernel(int64_t* step, float base_lr, int warmup, int total, float beta1, float beta2, float* out) {
+    const int64_t t = *step + 1;                       // 1-based index of the update that follows
+    *step = t;
+    const double done = (double)(t - 1);               // completed updates = the scheduler's step
+    double f;
+    if (done < (double)warmup) f = done / fmax(1.0, (double)warmup);
+    else f = fmax(0.0, ((double)total - done) / fmax(1.0, (double)(total - warmup)));
+    out[0] = (float)((double)base_lr * f);
+    out[1] = (float)(1.0 - pow((double)beta1, (double)t));
+    out[2] = (float)(1.0 - pow((double)beta2, (double)t));
+    out[3] = (float)t;
+}
+
 static inline int stream_grid(int64_t work_items) {
     int64_t b = (work_items + 255) / 256;
     if (b > 4096) b = 4096;
@@ -108,6 +123,15 @@ using namespace xl;
 extern "C" const char* xl_last_error(void) { return g_err; }
 extern "C" int xl_version(void) { return 1; }
 extern "C" int xl_set_lds_transpose_read(int enable) { g_use_tr_read = enable ? 1 : 0; return XL_OK; }
+
+extern "C" int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, int total_steps, float beta1, float beta2,
+                                float* lr_and_steps, void* stream) {
+    XL_CHECK_ARG(step && lr_and_steps && warmup_steps >= 0 && total_steps > 0, XL_ERR_BAD_ARG, "xl_schedule_step: bad args");
+    hipLaunchKernelGGL(schedule_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, base_lr, warmup_steps, total_steps,
+                       beta1, beta2, lr_and_steps);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
 
 extern "C" int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream) {
     XL_CHECK_ARG(g && sumsq && n > 0 && aligned16(g), XL_ERR_BAD_ARG, "xl_sumsq: bad args");

@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pre
                                                        const int64_t* __restrict__ cid, const uint8_t* __restrict__ mask,
                                                        const float* __restrict__ nmask, T* __restrict__ dpred,
                                                        float* loss_out, int B, int V, int F, float grad_scale,
-                                                       const int* __restrict__ rows, int n_rows) {
+                                                       const int* __restrict__ rows, int n_rows, const T* __restrict__ targets) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[WPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -946,7 +946,9 @@ __global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pre
         const int gr = rows ? rows[row] : row;                   // (example, grid position) the row of pred / dpred belongs to
         const int b = gr / V;
         const float w = mask[gr] ? 1.0f / (fmaxf(nmask[b], 1.0f) * (float)B) : 0.f;
-        const T* tgt = cent + (size_t)cid[gr] * F;
+        // regression target: the caller's feat_labels row (ref lxrt/modeling.py:275: label_dict['feat_labels'], the real grid
+        // features of lxmert_pretrain.py:177-179) or, without one, the centroid of the position's cluster id
+        const T* tgt = targets != nullptr ? targets + (size_t)gr * F : cent + (size_t)cid[gr] * F;
         float s = 0.f;
         for (int col = lane * VEC; col < F; col += 64 * VEC) {
             float p[VEC], t[VEC], g[VEC];
@@ -1394,15 +1396,18 @@ extern "C" int xl_ce_fwd_bwd(const float* logits, const int64_t* labels, const f
 
 extern "C" int xl_featloss_fwd_bwd(const void* pred, const void* centroids, const int64_t* cluster_ids,
                                    const uint8_t* vis_mask, const float* nmask, void* dpred, float* loss_out,
-                                   int B, int V, int F, float grad_scale, const int* rows, int n_rows, int dtype, void* stream) {
+                                   int B, int V, int F, float grad_scale, const int* rows, int n_rows, const void* targets,
+                                   int dtype, void* stream) {
     CHECK_ROW(F, dtype);
+    XL_CHECK_ARG(targets != nullptr || (centroids != nullptr && cluster_ids != nullptr), XL_ERR_BAD_ARG,
+                 "xl_featloss_fwd_bwd: needs either targets or centroids + cluster_ids");
     hipStream_t st = (hipStream_t)stream;
     const int M = rows ? n_rows : B * V;
     XL_CHECK_ARG(M > 0 && M <= B * V, XL_ERR_BAD_ARG, "xl_featloss_fwd_bwd: n_rows=%d", n_rows);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((featloss_kernel<T>), dim3(min((M + WPB - 1) / WPB, 1024)), dim3(256), 0, st,
                            (const T*)pred, (const T*)centroids, cluster_ids, vis_mask, nmask, (T*)dpred, loss_out, B, V, F, grad_scale,
-                           rows, M););
+                           rows, M, (const T*)targets););
     XL_CHECK_LAUNCH();
     return XL_OK;
 }

@@ -538,6 +538,7 @@ class Engine:
         self.vmask = torch.zeros(B, V, dtype=torch.uint8, device=self.dev)
         self.labels = torch.full((B, V), -100, dtype=torch.int64, device=self.dev)
         self._hrows, self._hvis = None, None
+        self.feat_tgt, self._feat_tgt_buf = None, None
         import os
         self.compact_head = os.environ.get("XL_COMPACT_HEAD", "1") != "0"   # training step: codebook head on the masked rows only
         self.task = getattr(store, "task", "vis_mask")
@@ -739,9 +740,12 @@ class Engine:
 
     # ------------------------------------------------------------ inputs
     def set_inputs(self, input_ids, attention_mask=None, token_type_ids=None, visual_pos=None, cluster_ids=None,
-                   vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None):
+                   vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None, feat_labels=None):
         """masked_rows (optional): ascending ids b*V+v of the masked positions, i.e. vis_mask.flatten().nonzero(), as the data
-        loader can compute them on the CPU next to vis_mask itself; given, the step needs no host <-> device round trip."""
+        loader can compute them on the CPU next to vis_mask itself; given, the step needs no host <-> device round trip.
+        feat_labels (optional, [B,V,F]): regression targets of the feature loss (label_dict['feat_labels'], ref
+        lxrt/modeling.py:275; the trainer passes the real grid features, lxmert_pretrain.py:177-179); without them the
+        feature loss regresses onto the centroid of each position's cluster id."""
         B, L, V = self.B, self.L, self.V
         assert tuple(input_ids.shape) == (B, L), (input_ids.shape, (B, L))
         self.ids.copy_(input_ids, non_blocking=True)
@@ -771,6 +775,12 @@ class Engine:
             self.feats.copy_(visual_feats.reshape(self.MV, self.F), non_blocking=True)
         if obj_labels is not None:
             self.labels.copy_(obj_labels, non_blocking=True)
+        self.feat_tgt = None
+        if feat_labels is not None:
+            if self._feat_tgt_buf is None:
+                self._feat_tgt_buf = self.act(self.MV, self.F)
+            self._feat_tgt_buf.copy_(feat_labels.reshape(self.MV, self.F), non_blocking=True)
+            self.feat_tgt = self._feat_tgt_buf
 
     # ------------------------------------------------------------ forward
     def encoder_forward(self, want_pooled=True):
@@ -876,7 +886,7 @@ class Engine:
         if feat_loss:
             ops.featloss_fwd_bwd(self.feat, self.store.centroids_c, self.cid, self.vmask, self.nmask,
                                  self.dfeat if want_grad else None, self.losses[1:], self.B, self.V, F, 1.0,
-                                 rows=rows, n_rows=M if rows is not None else 0)
+                                 rows=rows, n_rows=M if rows is not None else 0, targets=self.feat_tgt)
         return self.losses
 
     def pooler_backward(self, dpooled, dz, cls_rows, d_cls):
@@ -1007,8 +1017,13 @@ class Engine:
         """start of a training step's backward: clear the gradient buffer, defer the column reductions' second stages."""
         st = self.store
         st.grad[st.n_mat:st.n_used].zero_()
+        self.begin_backward()
+
+    def begin_backward(self):
+        """start of a backward pass that ACCUMULATES into the gradient buffer (the nn.Module path: zeroing is the caller's
+        zero_grad(), as with autograd): second stages of the column reductions deferred until encoder_backward ends."""
         self.defer_reductions(True)
-        self._lane_lo = {"v": 0, "l": st.language_range()[0]}
+        self._lane_lo = {"v": 0, "l": self.store.language_range()[0]}
 
     def head_backward(self, d_vis):
         """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis."""

@@ -205,7 +205,6 @@ class _VisMaskStepFn(torch.autograd.Function):
         eng = model.bert._engine
         eng.encoder_forward(want_pooled=False)
         eng.head_forward()
-        eng.zero_accumulated_grads()
         losses = eng.losses_forward_backward(True, feat_loss)
         ctx.model = model
         return losses[:2].clone()
@@ -216,6 +215,9 @@ class _VisMaskStepFn(torch.autograd.Function):
         s = d_losses.tolist()
         if abs(s[0] - s[1]) > 1e-12 and eng.with_feat_loss:
             raise NotImplementedError("obj_loss and feat_loss must be weighted equally (total_loss = obj + feat)")
+        # gradients ACCUMULATE into the flat buffer (several forward/backward calls per update, --update > 1): clearing is
+        # zero_grad()'s job, as with autograd; the deferred column reductions are switched on and off inside this backward
+        eng.begin_backward()
         eng.head_backward(eng.GA[eng.ML:])
         eng.encoder_backward(False)
         if s[0] != 1.0:
@@ -287,9 +289,14 @@ class XLxmertForPretraining(nn.Module):
         V = cluster_ids.shape[1]
         eng = self._step_engine(B, L, V)
         labels = label_dict["obj_labels"]
+        # feature regression iff the caller supplies its targets: the reference trainer adds label_dict['feat_labels'] (the
+        # real grid features) exactly when 'feat' is in --visualLosses (lxmert_pretrain.py:177-179); the canonical recipe
+        # (scripts/pretrain.bash:15, --visualLosses obj) has no feature loss.  (The published model code keys the branch on
+        # visual_obj_loss and then fails on the missing label: SURVEY App. A item 10.)
+        feat_labels = label_dict.get("feat_labels")
         eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, cluster_ids=cluster_ids, vis_mask=vis_mask,
-                       obj_labels=labels)
-        feat_loss = True
+                       obj_labels=labels, feat_labels=feat_labels)
+        feat_loss = feat_labels is not None
         if torch.is_grad_enabled():
             losses = _VisMaskStepFn.apply(self, self._anchor, feat_loss)
         else:
@@ -297,6 +304,8 @@ class XLxmertForPretraining(nn.Module):
             eng.head_forward()
             losses = eng.losses_forward_backward(False, feat_loss)[:2].clone()
         obj_loss, feat_l = losses[0], losses[1]
+        if not feat_loss:
+            return {"obj_loss": obj_loss.detach(), "vis_loss": obj_loss.detach(), "total_loss": obj_loss}
         total = obj_loss + feat_l
         return {"obj_loss": obj_loss.detach(), "feat_loss": feat_l.detach(), "vis_loss": total.detach(), "total_loss": total}
 

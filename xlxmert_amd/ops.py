@@ -172,10 +172,11 @@ class HipOps:
                       float(grad_scale), self.dt, self._stream())
 
     def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F,
-                         grad_scale=1.0, rows=None, n_rows=0):
+                         grad_scale=1.0, rows=None, n_rows=0, targets=None):
+        """targets: optional [B*V, F] regression targets (label_dict['feat_labels']); default = centroids[cluster_ids]."""
         self.lib.call("xl_featloss_fwd_bwd", self._p(pred), self._p(centroids), self._p(cluster_ids),
                       self._p(vis_mask), self._p(nmask), self._p(dpred), self._p(loss_out), B, V, F, float(grad_scale),
-                      self._p(rows), int(n_rows), self.dt, self._stream())
+                      self._p(rows), int(n_rows), self._p(targets), self.dt, self._stream())
 
     def gather_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
         self.lib.call("xl_gather_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
@@ -185,6 +186,11 @@ class HipOps:
 
     def sumsq(self, g, out, n):
         self.lib.call("xl_sumsq", self._p(g), self._p(out), n, self._stream())
+
+    def schedule_step(self, step, base_lr, warmup_steps, total_steps, beta1, beta2, lr_and_steps):
+        """device-side: step[0] += 1; lr_and_steps = {lr(t), 1-beta1^t, 1-beta2^t, t} (stream-ordered before adamw)."""
+        self.lib.call("xl_schedule_step", self._p(step), float(base_lr), int(warmup_steps), int(total_steps), float(beta1),
+                      float(beta2), self._p(lr_and_steps), self._stream())
 
     def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
               max_norm, grad_scale=1.0, chunk_steps=None):

@@ -50,14 +50,18 @@ def linear_schedule(step, warmup_steps, total_steps):
 class PretrainStep:
     def __init__(self, cfg: XLxmertConfig, batch_size, text_len=20, n_grids=64, dtype=torch.bfloat16, device=None,
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
-                 betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=True, train_dropout=False, store=None,
-                 bucket_mb=64, ops=None, task="vis_mask", num_answers=0):
+                 betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
+                 bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj"):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
         ref tasks/vqa.py:166-198) -- same clip / AdamW / schedule.  task="all": the three pretraining branches on ONE
         parameter set, `step(batch, task=...)` per call (the reference's round-robin, lxmert_pretrain.py:296-298): tensors
-        without a gradient in the step's branch are skipped by the optimizer and keep their own update count."""
+        without a gradient in the step's branch are skipped by the optimizer and keep their own update count.
+        visual_losses: the reference's --visualLosses ("obj" in scripts/pretrain.bash:15 = the canonical recipe and the
+        default here; "obj,feat" adds the masked SmoothL1 feature regression onto batch["feat_labels"] -- the real grid
+        features, ref lxmert_pretrain.py:177-179 -- or, when the batch carries none, onto the centroid of each position's
+        cluster id).  feat_loss=True/False overrides it (older call sites)."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -78,28 +82,37 @@ class PretrainStep:
         self.lr, self.wd, self.clip = lr, weight_decay, clip_grad_norm
         self.betas, self.eps = betas, eps
         self.total_steps, self.warmup_steps = total_steps, int(total_steps * warmup_ratio)
-        self.feat_loss = feat_loss
+        self.feat_loss = ("feat" in visual_losses.split(",")) if feat_loss is None else bool(feat_loss)
         self.t = 0
         # task round-robin on one parameter set (ref lxmert_pretrain.py:296-298): per-tensor update counts, as transformers'
         # AdamW keeps them (a tensor skipped in a step does not advance its bias correction)
         self.chunk_steps = (torch.zeros(self.store.n_total // 256, dtype=torch.int32, device=self.device)
                             if task == "all" else None)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # update counter, learning rate and bias corrections live on the device and are advanced by a kernel queued in front
+        # of AdamW (xl_schedule_step): the host, which runs several steps ahead of the GPU, never writes step scalars into
+        # memory a queued step still has to read
         self.lrs = torch.zeros(4, dtype=torch.float32, device=self.device)
-        self._lrs_host = torch.zeros(4, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.zeros(4)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // 4)
         if self.world > 1:
-            self._check_replicas()
+            self.sync_replicas()
 
-    def _check_replicas(self):
-        """identical initial parameters on every rank (stands in for DDP's constructor broadcast)."""
-        s = self.store.master[:self.store.n_used].double().sum().reshape(1)
-        lo, hi = s.clone(), s.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if lo.item() != hi.item():
-            dist.broadcast(self.store.master, src=0)
-            self.engine.sync_compute_weights()
+    def sync_replicas(self):
+        """DDP's constructor broadcast (ref lxmert_pretrain.py:102-106): rank 0's parameters AND optimizer state (Adam
+        moments, update counters -- a resumed store carries them) go to every rank, unconditionally: a one-time cost."""
+        st = self.store
+        bufs = [st.master, st.exp_avg, st.exp_avg_sq, self.step_dev]
+        if self.chunk_steps is not None:
+            bufs.append(self.chunk_steps)
+        if st.centroids is not None:
+            bufs.append(st.centroids)
+        for b in bufs:
+            dist.broadcast(b, src=0)
+        if st.centroids is not None and st.centroids_c is not st.centroids:
+            st.centroids_c.copy_(st.centroids)
+        self.t = int(self.step_dev.item())
+        self.engine.sync_compute_weights()
 
     def set_centroids(self, centroids):
         self.store.set_centroids(centroids)
@@ -184,7 +197,8 @@ class PretrainStep:
             labels[~batch["vis_mask"].bool()] = -100           # ref lxmert_pretrain.py:163-166
         eng.set_step_seed(self.t * self.world + self.rank)
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
-                       vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"))
+                       vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"),
+                       feat_labels=batch.get("feat_labels") if self.feat_loss else None)
         if self.exchange:
             self._begin_exchange()
             eng.grad_ready = self._on_grad_ready
@@ -196,13 +210,9 @@ class PretrainStep:
 
     def optimizer_step(self):
         st, ops = self.store, self.ops
-        self.t += 1
+        self.t += 1                      # host mirror of step_dev (seeds, logging): never read by a kernel
         b1, b2 = self.betas
-        lr = self.lr * linear_schedule(self.t - 1, self.warmup_steps, self.total_steps)
-        self._lrs_host[0] = lr
-        self._lrs_host[1] = 1.0 - b1 ** self.t
-        self._lrs_host[2] = 1.0 - b2 ** self.t
-        self.lrs.copy_(self._lrs_host, non_blocking=True)
+        ops.schedule_step(self.step_dev, self.lr, self.warmup_steps, self.total_steps, b1, b2, self.lrs)
         n = st.n_used
         if self.clip > 0:
             self.sumsq.zero_()
