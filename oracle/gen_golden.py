@@ -302,6 +302,59 @@ def gen_lang_tasks(name, cfg, seed, B, L, grid):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
 
 
+def gen_qa_tasks(name, cfg, num_qa, seed, B, L, grid):
+    """SURVEY 8f N3, QA branch: the reference built with `task_qa=True` (ref lxrt/modeling.py:89-90 answer_head;
+    :292-304 qa_loss added in EVERY task branch because the condition is `self.task_qa`, not the `task` argument).  Tasks
+    'qa', 'vis_mask', 'word_mask', 'matched' on one model: losses, qa_pred, every gradient of the 'qa' task and
+    norm + samples of the gradients of the other three."""
+    hf = LxmertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                      num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                      max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                      l_layers=cfg.l_layers, x_layers=cfg.x_layers, r_layers=cfg.r_layers,
+                      visual_feat_dim=cfg.visual_feat_dim, visual_pos_dim=cfg.visual_pos_dim,
+                      visual_attr_loss=False, task_qa=True, num_qa_labels=num_qa, task_mask_lm=True, task_matched=True)
+    m = Shim(hf, num_clusters=cfg.num_clusters)
+    sd = O.make_qa_state_dict(cfg, num_qa, seed)
+    m.set_visual_embedding(sd["vis_emb.weight"].clone())
+    m.config.n_centroids = cfg.num_clusters
+    res = m.load_state_dict({k: v for k, v in sd.items() if k not in ("vis_emb.weight", "obj_predict_head.out_cluster.weight",
+                                                                      "cls.predictions.decoder.weight")}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert not [k for k in res.missing_keys if "decoder" not in k and "vis_emb" not in k and "out_cluster.weight" not in k], res.missing_keys
+    m.cls.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
+    m.eval()
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    word_labels, matched_labels = O.make_lang_task_labels(cfg, inp["input_ids"], seed + 2)
+    qa_labels = O.make_qa_labels(num_qa, B, seed + 3)
+    d = dict(seed=np.array(seed), num_qa_labels=np.array(num_qa), **cfg_fields(cfg), **np_inputs(inp),
+             in_word_labels=word_labels.numpy(), in_matched_labels=matched_labels.numpy(), in_qa_labels=qa_labels.numpy())
+    for task in ("qa", "vis_mask", "word_mask", "matched"):
+        ld = {"qa_labels": qa_labels}
+        if task == "vis_mask":
+            ld.update(obj_labels=inp["obj_labels"], feat_labels=m.vis_emb(inp["cluster_ids"]))
+        elif task == "word_mask":
+            ld["word_labels"] = word_labels
+        elif task == "matched":
+            ld["matched_labels"] = matched_labels
+        m.zero_grad(set_to_none=True)
+        out = m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+                cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], token_type_ids=inp["token_type_ids"],
+                return_dict=True, label_dict=ld, task=task)
+        out["total_loss"].backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        for k, v in out.items():
+            d[f"{task}:{k}"] = v.detach().numpy()
+        d[task + ":grad_names"] = np.array(sorted(grads.keys()))
+        for k, g in grads.items():
+            d[f"{task}:gnorm:{k}"] = np.array(g.double().norm().item())
+            if task == "qa":
+                d[f"{task}:grad:{k}"] = g.numpy()
+            else:
+                d[f"{task}:gslice:{k}"] = g.reshape(-1)[torch.from_numpy(slice_idx(g.numel()))].numpy()
+        print(name, task, {k: float(v) for k, v in out.items() if k.endswith("loss")}, "n_grads", len(grads))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+
+
 def gen_sampler_ar(name, cfg, seed, B, L, grid):
     """SURVEY 8f N2 (AR variant): the loop body of tasks/imggen_model.py:96-153 on the reference's own modules, for the
     three position policies; `random` uses random.Random(7).shuffle as the reference does with seed=7."""
@@ -400,6 +453,11 @@ if __name__ == "__main__":
     if only == ["full"]:
         gen_full()
         sys.exit(0)
+    if only == ["qa"]:
+        gen_qa_tasks("qa_tasks_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
+                     num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
+                     num_clusters=50), num_qa=13, seed=7531, B=4, L=8, grid=4)
+        sys.exit(0)
     tiny = dict(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
                 max_position_embeddings=32, visual_feat_dim=32, num_clusters=50)
     gen_blocks()
@@ -409,6 +467,7 @@ if __name__ == "__main__":
     gen_config1()
     gen_full()
     gen_lang_tasks("lang_tasks_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=8642, B=3, L=8, grid=4)
+    gen_qa_tasks("qa_tasks_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_qa=13, seed=7531, B=4, L=8, grid=4)
     gen_sampler_ar("sampler_ar_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=9753, B=3, L=8, grid=4)
     gen_sampler("sampler_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, B=3, L=8, grid=4, n_steps=4)
     gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)

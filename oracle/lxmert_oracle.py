@@ -220,22 +220,68 @@ def lm_prediction_head(sd, cfg, lang, prefix="cls.predictions"):
     return F.linear(h, sd["bert.embeddings.word_embeddings.weight"]) + sd[prefix + ".bias"]
 
 
-def xlxmert_word_mask_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, word_labels, token_type_ids=None):
+def qa_loss_term(sd, cfg, pooled, qa_labels):
+    """ref:x-lxmert/src/lxrt/modeling.py:292-304: `if self.task_qa:` (the model was built with the QA head, ref :89-90) the
+    answer-head cross-entropy over `label_dict['qa_labels']` (ignore_index -100) is added to total_loss in EVERY task
+    branch -- the condition is on the model, not on the `task` argument."""
+    score = visual_answer_head(sd, cfg, pooled)
+    return F.cross_entropy(score.view(-1, score.shape[-1]), qa_labels.view(-1)), score
+
+
+def xlxmert_word_mask_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, word_labels, token_type_ids=None,
+                              qa_labels=None):
     """ref:x-lxmert/src/lxrt/modeling.py:154-225, task == 'word_mask': un-masked centroid features in, MLM CE (ignore -100)."""
     feats = codebook_features(sd, cluster_ids, None)
     lang, vis, pooled = lxmert_model(sd, cfg, input_ids, feats, visual_pos, attention_mask, token_type_ids)
     scores = lm_prediction_head(sd, cfg, lang)
     lm_loss = F.cross_entropy(scores.view(-1, cfg.vocab_size), word_labels.view(-1))
-    return {"lm_loss": lm_loss, "total_loss": lm_loss, "scores": scores}
+    out = {"lm_loss": lm_loss, "total_loss": lm_loss, "scores": scores}
+    if qa_labels is not None:
+        out["qa_loss"], out["qa_score"] = qa_loss_term(sd, cfg, pooled, qa_labels)
+        out["total_loss"] = lm_loss + out["qa_loss"]
+    return out
 
 
-def xlxmert_matched_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, matched_labels, token_type_ids=None):
+def xlxmert_matched_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, matched_labels, token_type_ids=None,
+                            qa_labels=None):
     """ref:x-lxmert/src/lxrt/modeling.py:154-235, task == 'matched': seq_relationship(pooled_output), 2-way CE (HF:648-657)."""
     feats = codebook_features(sd, cluster_ids, None)
     lang, vis, pooled = lxmert_model(sd, cfg, input_ids, feats, visual_pos, attention_mask, token_type_ids)
     score = _linear(sd, "cls.seq_relationship", pooled)
     loss = F.cross_entropy(score.view(-1, 2), matched_labels.view(-1))
-    return {"matched_loss": loss, "total_loss": loss, "score": score}
+    out = {"matched_loss": loss, "total_loss": loss, "score": score}
+    if qa_labels is not None:
+        out["qa_loss"], out["qa_score"] = qa_loss_term(sd, cfg, pooled, qa_labels)
+        out["total_loss"] = loss + out["qa_loss"]
+    return out
+
+
+def xlxmert_qa_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, qa_labels, token_type_ids=None):
+    """ref:x-lxmert/src/lxrt/modeling.py:154-210, 292-306, task == 'qa' on a task_qa model: un-masked centroid features in
+    (the [MASK] substitution is for task == 'vis_mask' only, :190-193), total_loss = qa_loss; qa_pred = argmax (:300)."""
+    feats = codebook_features(sd, cluster_ids, None)
+    lang, vis, pooled = lxmert_model(sd, cfg, input_ids, feats, visual_pos, attention_mask, token_type_ids)
+    loss, score = qa_loss_term(sd, cfg, pooled, qa_labels)
+    return {"qa_loss": loss, "total_loss": loss, "qa_score": score, "qa_pred": score.argmax(1)}
+
+
+def make_qa_state_dict(cfg, num_qa_labels, seed, perturb=True):
+    """make_cls_state_dict(cfg, seed) + the deterministic answer head of make_vqa_state_dict (same recipe, seed + 7)."""
+    sd = make_cls_state_dict(cfg, seed, perturb)
+    vq = make_vqa_state_dict(cfg, num_qa_labels, seed, perturb)
+    for name, _ in answer_head_shapes(cfg, num_qa_labels):
+        sd[name] = vq[name]
+    return sd
+
+
+def make_qa_labels(num_qa_labels, B, seed):
+    """one answer id per example, ~1 in 4 without an answer (-100: ignored by the loss, ref lxmert_pretrain.py:186-190)."""
+    rng = np.random.default_rng(seed)
+    lab = rng.integers(0, num_qa_labels, size=B, dtype=np.int64)
+    lab[rng.random(B) < 0.25] = -100
+    if (lab == -100).all():
+        lab[0] = 0
+    return torch.from_numpy(lab)
 
 
 def cls_head_shapes(cfg):
@@ -451,7 +497,7 @@ def vis_mask_losses(cfg, feat, obj, obj_labels, feat_labels, vis_mask):
 
 
 def xlxmert_vis_mask_forward(sd, cfg, input_ids, visual_pos, attention_mask, cluster_ids, vis_mask,
-                             obj_labels, feat_labels=None, token_type_ids=None, return_all=False):
+                             obj_labels, feat_labels=None, token_type_ids=None, return_all=False, qa_labels=None):
     """ref:x-lxmert/src/lxrt/modeling.py:154-308, task == 'vis_mask'.
     `feat_labels` defaults to the un-masked centroid features (ref lxmert_pretrain.py:177-179)."""
     feats = codebook_features(sd, cluster_ids, vis_mask)
@@ -462,6 +508,9 @@ def xlxmert_vis_mask_forward(sd, cfg, input_ids, visual_pos, attention_mask, clu
     obj_loss, feat_loss = vis_mask_losses(cfg, feat, obj, obj_labels, feat_labels, vis_mask)
     out = {"obj_loss": obj_loss, "feat_loss": feat_loss, "vis_loss": obj_loss + feat_loss,
            "total_loss": obj_loss + feat_loss}
+    if qa_labels is not None:               # task_qa model (ref lxrt/modeling.py:292-304)
+        out["qa_loss"], out["qa_score"] = qa_loss_term(sd, cfg, pooled, qa_labels)
+        out["total_loss"] = out["total_loss"] + out["qa_loss"]
     if return_all:
         out.update(lang=lang, vis=vis, pooled=pooled, feat=feat, obj=obj)
     return out

@@ -255,6 +255,75 @@ def test_language_pretraining_steps_vs_reference_fixture(task):
         check_lang_task(g, task, eng, inp, 5e-6, 1e-4, rows=True)
 
 
+def make_qa_engine(g, task, ops, device="cpu", dtype=torch.float32, store_task=None):
+    """engine over a task_qa pretraining model (tests/golden/qa_tasks_tiny.npz): store task = the step's task, or "all"."""
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    A = int(g["num_qa_labels"])
+    sd = O.make_qa_state_dict(oc, A, int(g["seed"]))
+    inp = golden_inputs(g)
+    B, L = inp["input_ids"].shape
+    V = inp["cluster_ids"].shape[1]
+    store = ParamStore(cfg, device, dtype, task=store_task or task, num_answers=A)
+    store.load_named(sd)
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=True)
+    eng.sync_compute_weights()
+    return eng, inp
+
+
+def run_qa_task(eng, inp, task, dev="cpu"):
+    x = {k: v.to(dev) for k, v in inp.items()}
+    base = (x["input_ids"], x["attention_mask"], x["token_type_ids"], x["visual_pos"])
+    ql = x["qa_labels"]
+    if task == "vis_mask":
+        eng.set_inputs(*base, cluster_ids=x["cluster_ids"], vis_mask=x["vis_mask"], obj_labels=x["obj_labels"])
+        losses = eng.vis_mask_forward_backward(True, qa_labels=ql)
+        return losses[0] + losses[1] + eng.answer.loss[0]
+    eng.set_inputs(*base, cluster_ids=x["cluster_ids"])                 # un-masked codebook features (ref modeling.py:190-193)
+    if task == "qa":
+        return eng.qa_forward_backward(ql)[0]
+    if task == "word_mask":
+        return eng.word_mask_forward_backward(x["word_labels"], qa_labels=ql)[0] + eng.answer.loss[0]
+    return eng.matched_forward_backward(x["matched_labels"], qa_labels=ql)[0] + eng.answer.loss[0]
+
+
+def check_qa_task(g, task, eng, inp, loss_tol, grad_tol, dev="cpu", exact_set=True):
+    from _util import slice_idx
+    total = run_qa_task(eng, inp, task, dev)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    assert abs(total.item() - float(g[task + ":total_loss"])) < loss_tol, (total.item(), float(g[task + ":total_loss"]))
+    assert abs(eng.answer.loss[0].item() - float(g[task + ":qa_loss"])) < loss_tol
+    if task == "qa":
+        assert (eng.answer.row_argmax.cpu().numpy() == g["qa:qa_pred"]).all()
+    names = [str(n) for n in g[task + ":grad_names"]]
+    if exact_set:
+        used = {m.name for u in eng.store.units if u.used for m in u.members}
+        assert set(names) == used, (sorted(set(names) ^ used))[:6]  # optimizer range == the reference's grad-carrying set
+    for k in names:
+        got = eng.store.gview(k).cpu()
+        if f"{task}:grad:{k}" in g:
+            ref = torch.from_numpy(g[f"{task}:grad:{k}"])
+            assert maxdiff(got, ref) <= grad_tol * max(1.0, ref.abs().max().item()), k
+        else:
+            ref = torch.from_numpy(g[f"{task}:gslice:{k}"])
+            smp = got.reshape(-1)[torch.from_numpy(slice_idx(got.numel()))]
+            assert maxdiff(smp, ref) <= grad_tol * max(1.0, ref.abs().max().item()), k
+            assert abs(got.double().norm().item() - g[f"{task}:gnorm:{k}"].item()) <= 10 * grad_tol * max(1.0, g[f"{task}:gnorm:{k}"].item()), k
+
+
+@pytest.mark.parametrize("task", ["qa", "vis_mask", "word_mask", "matched"])
+def test_qa_branch_steps_vs_reference_fixture(task):
+    """SURVEY 8f N3, QA branch: a model built with task_qa adds the answer-head CE to every task's loss (ref
+    lxrt/modeling.py:89-90, 292-304); fixture = the reference's own branches."""
+    g = load_golden("qa_tasks_tiny")
+    eng, inp = make_qa_engine(g, task, FakeOps(torch.float32))
+    check_qa_task(g, task, eng, inp, 1e-5, 1e-4)
+
+
 def check_ar_sampler(g, eng, mode):
     trace = []
     cid, code, prob = eng.sample_codes_ar(None, mode, positions=g["random_positions"].tolist(), trace=trace)

@@ -691,3 +691,33 @@ def test_training_reduces_the_loss_full_size_bf16():
     assert first > 8.0, first                        # ~ ln(10000) = 9.2 at initialisation
     assert last < 0.6 * first, (first, last)
     assert torch.isfinite(tr.store.master).all()
+
+
+# ---------------------------------------------------------------- QA branch (task_qa model)
+@pytest.mark.parametrize("task", ["qa", "vis_mask", "word_mask", "matched"])
+def test_qa_branch_steps_fp32_match_reference_fixture(task):
+    from test_engine_cpu import check_qa_task, make_qa_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("qa_tasks_tiny")
+    eng, inp = make_qa_engine(g, task, HipOps(torch.float32), device="cuda")
+    check_qa_task(g, task, eng, inp, 2e-5, 1e-4, dev="cuda")
+
+
+@pytest.mark.parametrize("task", ["qa", "vis_mask"])
+def test_qa_branch_steps_bf16_stated_tolerance(task):
+    """bf16, multi-task ("all") store: total loss within 1 %, every stored gradient within 5 % of the tensor's scale."""
+    from test_engine_cpu import make_qa_engine, run_qa_task
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("qa_tasks_tiny")
+    eng, inp = make_qa_engine(g, task, HipOps(torch.bfloat16), device="cuda", dtype=torch.bfloat16, store_task="all")
+    total = run_qa_task(eng, inp, task, "cuda")
+    torch.cuda.synchronize()
+    assert abs(total.item() - float(g[task + ":total_loss"])) < 1e-2 * float(g[task + ":total_loss"])
+    worst = 0.0
+    for k in [str(n) for n in g[task + ":grad_names"]]:
+        ref_n = g[f"{task}:gnorm:{k}"].item()
+        got_n = eng.store.gview(k).double().norm().item()
+        if ref_n > 1e-4:
+            worst = max(worst, abs(got_n - ref_n) / ref_n)
+    print(f"qa fixture bf16 {task}: worst gradient-norm error {worst:.4f}")
+    assert worst < 5e-2

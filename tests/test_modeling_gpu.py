@@ -135,3 +135,119 @@ def test_sample_codes_dropin_matches_reference_fixture():
     B = code.shape[0]
     ref = torch.from_numpy(g["code"]).permute(0, 2, 1).reshape(B, -1, grid, grid)
     assert maxdiff(code.cpu(), ref) == 0.0
+
+
+# ---------------------------------------------------------------- SURVEY 8f N3 through the reference's nn.Module surface
+def _qa_model(g, dtype=torch.float32):
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.modeling import XLxmertForPretraining
+    oc = golden_cfg(g)
+    A = int(g["num_qa_labels"])
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in CFG_KEYS}, task_qa=True, num_qa_labels=A)
+    m = XLxmertForPretraining(cfg, device="cuda", dtype=dtype).eval()
+    sd = O.make_qa_state_dict(oc, A, int(g["seed"]))
+    missing, unexpected = m.load_state_dict({"module." + k: v for k, v in sd.items()})
+    assert not missing and not unexpected, (missing, unexpected)
+    return m, sd
+
+
+def _qa_call(m, g, task):
+    inp = {k: v.cuda() for k, v in golden_inputs(g).items()}
+    ld = {"qa_labels": inp["qa_labels"]}
+    if task == "vis_mask":
+        ld.update(obj_labels=inp["obj_labels"], feat_labels=m.vis_emb(inp["cluster_ids"]))
+    elif task == "word_mask":
+        ld["word_labels"] = inp["word_labels"]
+    elif task == "matched":
+        ld["matched_labels"] = inp["matched_labels"]
+    return m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+             cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], token_type_ids=inp["token_type_ids"],
+             return_dict=True, label_dict=ld, task=task)
+
+
+@pytest.mark.parametrize("task", ["qa", "vis_mask", "word_mask", "matched"])
+def test_pretraining_module_dispatches_every_task_like_the_reference(task):
+    """XLxmertForPretraining.forward(task=...) on a task_qa model (ref lxrt/modeling.py:85-90, 211-235, 292-304): `.cls`,
+    `.answer_head` with the App. C keys, out_dict keys / losses / qa_pred and, after total_loss.backward(), the reference's
+    gradients (tests/golden/qa_tasks_tiny.npz = the reference's own branches)."""
+    from _util import slice_idx
+    g = load_golden("qa_tasks_tiny")
+    m, sd = _qa_model(g)
+    keys = set(m.state_dict().keys())
+    assert {"cls.predictions.bias", "cls.predictions.transform.dense.weight", "cls.predictions.transform.LayerNorm.bias",
+            "cls.predictions.decoder.weight", "cls.seq_relationship.weight", "answer_head.logit_fc.0.weight",
+            "answer_head.logit_fc.2.bias", "answer_head.logit_fc.3.weight", "bert.pooler.dense.bias"} <= keys
+    names = {n for n, _ in m.named_parameters()}
+    assert {"cls.seq_relationship.bias", "cls.predictions.transform.dense.bias", "answer_head.logit_fc.3.bias"} <= names
+    m.zero_grad()
+    out = _qa_call(m, g, task)
+    want = {"qa": {"qa_loss"}, "vis_mask": {"obj_loss", "feat_loss", "vis_loss", "qa_loss"}, "word_mask": {"lm_loss", "qa_loss"},
+            "matched": {"matched_loss", "qa_loss"}}[task] | {"qa_pred", "total_loss"}
+    assert set(out) == want, set(out) ^ want
+    for k in want - {"qa_pred"}:
+        assert abs(out[k].item() - float(g[f"{task}:{k}"])) < 2e-5, k
+    assert (out["qa_pred"].cpu().numpy() == g[f"{task}:qa_pred"]).all()
+    out["total_loss"].backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    tied = "cls.predictions.decoder.weight"
+    for k in [str(n) for n in g[task + ":grad_names"] if str(n) != tied]:
+        got = params[k].grad.cpu()
+        if f"{task}:grad:{k}" in g:
+            ref = torch.from_numpy(g[f"{task}:grad:{k}"])
+            assert maxdiff(got, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), k
+        else:
+            ref = torch.from_numpy(g[f"{task}:gslice:{k}"])
+            assert maxdiff(got.reshape(-1)[torch.from_numpy(slice_idx(got.numel()))], ref) <= 1e-4 * max(1.0, ref.abs().max().item()), k
+    # tensors outside the branch (e.g. the codebook head in task 'qa') got nothing
+    if task == "qa":
+        assert params["obj_predict_head.linear_feat.weight"].grad.abs().max().item() == 0.0
+        assert params["cls.seq_relationship.weight"].grad.abs().max().item() == 0.0
+
+
+def test_module_backward_accumulates_until_zero_grad():
+    """--update > 1 idiom: two forward/backward calls without zero_grad() leave the SUM of both gradients (autograd semantics);
+    a scaled loss scales only what that call adds."""
+    g = load_golden("qa_tasks_tiny")
+    m, sd = _qa_model(g)
+    m.zero_grad()
+    _qa_call(m, g, "vis_mask")["total_loss"].backward()
+    g1 = m._store.grad[:m._store.n_used].clone()
+    _qa_call(m, g, "word_mask")["total_loss"].backward()
+    g12 = m._store.grad[:m._store.n_used].clone()
+    m.zero_grad()
+    _qa_call(m, g, "word_mask")["total_loss"].backward()
+    g2 = m._store.grad[:m._store.n_used].clone()
+    torch.cuda.synchronize()
+    assert g1.abs().max().item() > 0 and maxdiff(g12.cpu(), (g1 + g2).cpu()) < 1e-5 * max(1.0, g12.abs().max().item())
+    (0.5 * _qa_call(m, g, "word_mask")["total_loss"]).backward()
+    torch.cuda.synchronize()
+    assert maxdiff(m._store.grad[:m._store.n_used].cpu(), (1.5 * g2).cpu()) < 1e-5 * max(1.0, g2.abs().max().item())
+
+
+def test_pretraining_module_without_qa_head_and_default_tasks():
+    """the canonical configuration (pretrain.bash: Mask_LM + Matched + Obj prediction, no --taskQA): `.cls` exists, no
+    `.answer_head`; word_mask / matched dispatch matches the reference fixture of that configuration."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.modeling import XLxmertForPretraining
+    g = load_golden("lang_tasks_tiny")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in CFG_KEYS})
+    m = XLxmertForPretraining(cfg, device="cuda", dtype=torch.float32).eval()
+    assert hasattr(m, "cls") and not hasattr(m, "answer_head")
+    m.load_state_dict(O.make_cls_state_dict(oc, int(g["seed"])))
+    inp = {k: v.cuda() for k, v in golden_inputs(g).items()}
+    for task, key in (("word_mask", "word_labels"), ("matched", "matched_labels")):
+        m.zero_grad()
+        out = m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+                cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], token_type_ids=inp["token_type_ids"],
+                return_dict=True, label_dict={key: inp[key]}, task=task)
+        assert abs(out["total_loss"].item() - float(g[task + ":loss"])) < 2e-5
+        out["total_loss"].backward()
+        torch.cuda.synchronize()
+        params = dict(m.named_parameters())
+        for k in [str(n) for n in g[task + ":grad_names"] if str(n) != "cls.predictions.decoder.weight"]:
+            ref = torch.from_numpy(g[f"{task}:grad:{k}"])
+            assert maxdiff(params[k].grad.cpu(), ref) <= 1e-4 * max(1.0, ref.abs().max().item()), (task, k)
+    with pytest.raises(ValueError):
+        m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], cluster_ids=inp["cluster_ids"], task="attr_mask", label_dict={})

@@ -25,6 +25,10 @@ class XLxmertConfig:
     visual_obj_loss: bool = True
     visual_feat_loss: bool = True               # the model code computes both
     task_obj_predict: bool = True
+    task_mask_lm: bool = True                   # `cls` heads are built when task_mask_lm or task_matched (ref lxrt/modeling.py:85-86)
+    task_matched: bool = True
+    task_qa: bool = False                       # --taskQA is off in scripts/pretrain.bash; True builds `answer_head` (ref :89-90)
+    num_qa_labels: int = 9500                   # LxmertConfig default
     use_return_dict: bool = True
 
     @property

@@ -288,6 +288,11 @@ class AnswerHead:
         self.dhn, self.dh, self.dpre = eng.act(B, 2 * d), eng.act(B, 2 * d), eng.act(B, 2 * d)
         self.dpooled, self.dz = eng.act(B, d), eng.act(B, d)
         self.loss = eng.f32(1)
+        # pretraining QA branch (ref lxrt/modeling.py:292-304): CrossEntropyLoss over one answer id per example (-100 = none)
+        self.labels = torch.full((B,), -100, dtype=torch.int64, device=eng.dev)
+        self.counts, self._ones, self._nm = eng.f32(4), torch.ones(B, dtype=torch.uint8, device=eng.dev), eng.f32(B)
+        self.row_argmax = torch.zeros(B, dtype=torch.int32, device=eng.dev)
+        self.row_lse, self.row_maxprob = eng.f32(B), eng.f32(B)
 
     def fwd(self, pooled):
         e, d, B, A = self.e, self.e.d, self.e.B, self.A
@@ -303,9 +308,27 @@ class AnswerHead:
         self.e.ops.bce_logits_fwd_bwd(self.logit, self.targets, self.dlogit if want_grad else None, self.loss, B, A, A, A, self.Ap)
         return self.loss
 
-    def bwd(self, pooled, cls_rows, d_cls):
-        """consumes dlogit; accumulates the head's and the pooler's parameter gradients; writes d(lang_output[:, 0]) into
-        d_cls (a [B, d] view with row stride L*d)."""
+    def ce_loss_fwd_bwd(self, want_grad=True):
+        """qa_loss = CrossEntropyLoss()(answer_score, qa_labels) (ref lxrt/modeling.py:295-298; ignore_index -100) and its
+        d(logit); also records qa_pred = argmax (ref :300)."""
+        B, A = self.e.B, self.A
+        ops = self.e.ops
+        self.loss.zero_()
+        ops.mask_counts(self.labels, self._ones, self.counts, self._nm, B, 1)          # counts[0] = #labels != -100
+        if want_grad and self.Ap > A:
+            self.dlogit.zero_()                                                        # pad columns
+        ops.ce_fwd_bwd(self.logit, self.labels, self.counts, self.dlogit if want_grad else None, self.loss, self.row_lse,
+                       self.row_argmax, self.row_maxprob, B, A, A, self.Ap, 1.0)
+        return self.loss
+
+    def bwd(self, pooled, cls_rows, d_cls, accumulate=False):
+        """consumes dlogit; accumulates the head's and the pooler's parameter gradients; writes (or, accumulate=True, adds)
+        d(lang_output[:, 0]) into d_cls (a [B, d] view with row stride L*d)."""
+        self.bwd_to_pooled(pooled)
+        self.e.pooler_backward(self.dpooled, self.dz, cls_rows, d_cls, accumulate=accumulate)
+
+    def bwd_to_pooled(self, pooled):
+        """consumes dlogit; accumulates the head's parameter gradients; leaves d(pooled_output) in self.dpooled."""
         e, d, B, A, Ap = self.e, self.e.d, self.e.B, self.A, self.Ap
         ops, st = e.ops, e.store
         L = e.L
@@ -317,7 +340,6 @@ class AnswerHead:
         ops.colsum(self.dpre, self.gb0, B, 2 * d, 2 * d, ws=e.ws)
         e.wgrad_defer(self.dpre, pooled, self.gw0, 2 * d, d, B, 2 * d, d, d)
         ops.gemm(self.dpre, self.w0, self.dpooled, None, None, None, B, d, 2 * d, 2 * d, d, d, a_kmajor=1, b_kmajor=0)
-        e.pooler_backward(self.dpooled, self.dz, cls_rows, d_cls)
 
     def gb3_pad(self):
         """bias-gradient view padded to the 8-column granule of dlogit (the bias unit is padded in the flat buffer)."""
@@ -336,7 +358,7 @@ class LangHeads:
         self.has_mlm = "cls.predictions.bias" in st.index and eng.task in ("word_mask", "all")
         self.has_rel = "cls.seq_relationship.weight" in st.index and eng.task in ("matched", "all")
         self.loss = eng.f32(2)                  # [lm_loss, matched_loss]
-        self.counts, self.dummy = eng.f32(4), eng.f32(B)
+        self.counts, self.dummy, self.rel_counts = eng.f32(4), eng.f32(B), eng.f32(4)
         if self.has_mlm:
             t = "cls.predictions.transform"
             self.wt, self.gwt = st.cview(t + ".dense.weight"), st.gview(t + ".dense.weight")
@@ -397,10 +419,15 @@ class LangHeads:
     def mlm_loss_bwd(self, d_lang):
         """CE over the masked tokens (labels -100 ignored) + backward down to d(language_output) (written to d_lang, which
         the caller has zeroed)."""
-        e, d, Vn, Vp = self.e, self.e.d, self.Vn, self.Vp
-        ops, st = e.ops, e.store
+        self.mlm_loss()
+        return self.mlm_bwd(d_lang)
+
+    def mlm_loss(self):
+        """lm_loss and d(scores) (nothing of the parameter gradients is touched)."""
+        e, Vn, Vp = self.e, self.Vn, self.Vp
+        ops = e.ops
         M = self.n_rows if self.n_rows else e.ML
-        self.loss.zero_()
+        self.loss[0:1].zero_()
         ops.mask_counts(self.word_labels, e.kmask, self.counts, self.dummy, e.B, e.L)
         labels = self.word_labels
         if self.n_rows:
@@ -408,6 +435,12 @@ class LangHeads:
             torch.index_select(self.word_labels.view(-1), 0, self.rows_long[:M], out=labels)
         ops.ce_fwd_bwd(self.scores, labels, self.counts, self.dscores, self.loss[0:], None, None, None,
                        M, Vn, Vp, Vp, 1.0)
+        return self.loss
+
+    def mlm_bwd(self, d_lang):
+        e, d, Vn, Vp = self.e, self.e.d, self.Vn, self.Vp
+        ops, st = e.ops, e.store
+        M = self.n_rows if self.n_rows else e.ML
         emb = "bert.embeddings.word_embeddings.weight"
         ops.colsum(self.dscores, self._gvb_pad(), M, Vp, Vp, ws=e.ws)
         e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, M, Vp, d, d)              # tied decoder: d(word embeddings)
@@ -434,12 +467,20 @@ class LangHeads:
         e.ops.gemm(pooled, self.wr, self.rel, self.br, None, None, B, 2, d, d, d, 8, out_f32=True)
         return self.rel
 
-    def rel_loss_bwd(self, pooled, cls_rows, d_cls):
+    def rel_loss_bwd(self, pooled, cls_rows, d_cls, extra_dpooled=None):
+        self.rel_loss()
+        return self.rel_bwd(pooled, cls_rows, d_cls, extra_dpooled)
+
+    def rel_loss(self):
+        e, B = self.e, self.e.B
+        self.loss[1:2].zero_()
+        self.rel_counts.fill_(float(B))                                 # every example carries a matched label
+        e.ops.ce_fwd_bwd(self.rel, self.matched_labels, self.rel_counts, self.drel, self.loss[1:], None, None, None, B, 2, 8, 8, 1.0)
+        return self.loss
+
+    def rel_bwd(self, pooled, cls_rows, d_cls, extra_dpooled=None):
         e, d, B = self.e, self.e.d, self.e.B
         ops = e.ops
-        self.loss.zero_()
-        self.counts.fill_(float(B))                                     # every example carries a matched label
-        ops.ce_fwd_bwd(self.rel, self.matched_labels, self.counts, self.drel, self.loss[1:], None, None, None, B, 2, 8, 8, 1.0)
         # the two output rows of seq_relationship: tiny contractions, done on the 8-column padded gradient
         g8 = torch.zeros(8, d, dtype=torch.float32, device=e.dev) if not hasattr(self, "_g8") else self._g8
         self._g8 = g8
@@ -456,6 +497,8 @@ class LangHeads:
         self._w8 = w8
         w8[:2].copy_(self.wr)
         ops.gemm(self.drel, w8, self.dpooled, None, None, None, B, d, 8, 8, d, d, a_kmajor=1, b_kmajor=0)
+        if extra_dpooled is not None:            # task_qa model: the answer head's d(pooled_output) joins here
+            self.dpooled.add_(extra_dpooled)
         e.pooler_backward(self.dpooled, self.dz, cls_rows, d_cls)
         return self.loss
 
@@ -505,7 +548,7 @@ class Engine:
             p = f"{e_}.x_layers.{i}"
             lang_on = need_lang or i < cfg.x_layers - 1
             # VQA / word_mask / matched read only the language (pooled) output: the visual side of the last cross layer is dead
-            vis_on = not (task0 in ("vqa", "word_mask", "matched") and i == cfg.x_layers - 1)
+            vis_on = not (task0 in ("vqa", "word_mask", "matched", "qa") and i == cfg.x_layers - 1)
             blk = {"cross": CrossAttBlock(self, p + ".visual_attention", lang_on, f"x{i}", need_vis=vis_on), "lang_on": lang_on,
                    "vis_on": vis_on}
             if vis_on:
@@ -542,9 +585,12 @@ class Engine:
         import os
         self.compact_head = os.environ.get("XL_COMPACT_HEAD", "1") != "0"   # training step: codebook head on the masked rows only
         self.task = getattr(store, "task", "vis_mask")
-        self.answer = AnswerHead(self, store.num_answers) if self.task == "vqa" else None
+        # answer head on pooled_output: the VQA/GQA fine-tune model, or a pretraining model built with task_qa (then its CE
+        # loss joins every task's loss, ref lxrt/modeling.py:292-304)
+        self.answer = AnswerHead(self, store.num_answers) if getattr(store, "num_answers", 0) > 0 else None
+        self.task_qa = self.answer is not None and self.task != "vqa"
         self.lang_heads = LangHeads(self) if self.task in ("word_mask", "matched", "all") else None
-        if self.task in ("vqa", "word_mask", "matched", "all"):
+        if self.task in ("vqa", "word_mask", "matched", "qa", "all") or self.task_qa:
             assert need_lang, "this task reads the language / pooled output: build the engine with need_lang=True"
         # ---- head (ref lxrt/modeling.py:38-53) + losses
         h = "obj_predict_head"
@@ -711,11 +757,19 @@ class Engine:
         return dzm
 
     def _ready(self, prefix):
+        self._ready_upto(self.store.range_of(prefix)[1])
+
+    def _ready_heads(self):
+        """every head that sits on top of the encoder (codebook head, cls.*, answer head, pooler) is done: their gradients
+        are the first block of the flat buffer (params._backward_rank 0)."""
+        self._ready_upto(self.store.heads_end())
+
+    def _ready_upto(self, hi):
         assert not self._pending["v"] and not self._pending["l"], "weight gradients registered but never flushed"
         self.flush_reductions()
         self.wgrad_sync()
         if self.grad_ready is not None:
-            self._report("v", self.store.range_of(prefix)[1])
+            self._report("v", hi)
 
     def _report(self, lane, hi, flush=False):
         lo = self._lane_lo[lane]
@@ -889,47 +943,139 @@ class Engine:
                                  rows=rows, n_rows=M if rows is not None else 0, targets=self.feat_tgt)
         return self.losses
 
-    def pooler_backward(self, dpooled, dz, cls_rows, d_cls):
+    def pooler_backward(self, dpooled, dz, cls_rows, d_cls, accumulate=False):
         """LxmertPooler backward (HF:566-572): pooled = tanh(W_p cls + b_p).  cls_rows / d_cls are [B, d] views of the
-        language output / its gradient with row stride L*d (the [CLS] rows)."""
+        language output / its gradient with row stride L*d (the [CLS] rows); accumulate: d_cls += instead of =."""
         ops, st, d, B, L = self.ops, self.store, self.d, self.B, self.L
         ops.tanh_bwd(dpooled, self.pooled, dz, B * d)
         ops.colsum(dz, st.gview("bert.pooler.dense.bias"), B, d, d, ws=self.ws)
         self.wgrad_defer(dz, cls_rows, st.gview("bert.pooler.dense.weight"), d, d, B, d, L * d, d)
         self.wgrad_flush()
-        ops.gemm(dz, st.cview("bert.pooler.dense.weight"), d_cls, None, None, None, B, d, d, d, d, L * d,
-                 a_kmajor=1, b_kmajor=0)
+        if accumulate:              # in-place: every output element is read (residual) and written by the same lane
+            ops.gemm(dz, st.cview("bert.pooler.dense.weight"), d_cls, None, d_cls, None, B, d, d, d, d, L * d, ldr=L * d,
+                     a_kmajor=1, b_kmajor=0, epilogue=EPI_RESIDUAL)
+        else:
+            ops.gemm(dz, st.cview("bert.pooler.dense.weight"), d_cls, None, None, None, B, d, d, d, d, L * d,
+                     a_kmajor=1, b_kmajor=0)
 
-    def word_mask_forward_backward(self, word_labels, word_rows=None):
+    # ---- QA branch of a task_qa pretraining model (ref lxrt/modeling.py:292-304): rides on every task
+    def _qa_forward(self, qa_labels):
+        """answer_score = answer_head(pooled_output) and qa_loss / d(answer_score); True when the branch is active."""
+        if not self.task_qa:
+            assert qa_labels is None, "qa_labels given but the model has no QA head (build the store with num_answers > 0)"
+            return False
+        assert qa_labels is not None, "a task_qa model adds qa_loss in every branch: label_dict['qa_labels'] is required"
+        self.answer.labels.copy_(qa_labels.reshape(-1), non_blocking=True)
+        self.answer.fwd(self.pooled)
+        self.answer.ce_loss_fwd_bwd(True)
+        return True
+
+    def _cls_views(self, G):
+        B, L, d = self.B, self.L, self.d
+        return self.lang_final.view(B, L * d)[:, :d], G[:self.ML].view(B, L * d)[:, :d]
+
+    # Every branch of XLxmertForPretraining.forward (ref lxrt/modeling.py:154-308) as two phases: task_forward = encoder + heads
+    # + losses (and the loss gradients w.r.t. the head outputs: no parameter gradient is touched), task_backward = everything
+    # that accumulates into store.grad.  The trainer runs them back to back around one clear of the gradient buffer
+    # (*_forward_backward below); the nn.Module surface runs them from autograd's forward / backward.
+    def task_forward(self, task, word_labels=None, word_rows=None, matched_labels=None, qa_labels=None, feat_loss=True,
+                     want_grad=True):
+        """returns {name: 0-d/1-element device tensor} with the reference's out_dict keys (lm_loss / matched_loss / obj_loss,
+        feat_loss / qa_loss)."""
+        assert task in ("vis_mask", "word_mask", "matched", "qa"), task
+        lh = self.lang_heads
+        self._task_run = task
+        out = {}
+        if task == "vis_mask":
+            self.encoder_forward(want_pooled=self.task_qa)
+            use_rows = want_grad and self.compact_head and self.has_vmask and 0 < self.n_mrows < self.MV
+            self._hrows_step = (self.mrows, self.n_mrows) if use_rows else None
+            self._hrows = self._hrows_step
+            try:
+                self.head_forward()
+                losses = self.losses_forward_backward(want_grad, feat_loss)
+            finally:
+                self._hrows = None
+            out["obj_loss"] = losses[0:1]
+            if feat_loss:
+                out["feat_loss"] = losses[1:2]
+        elif task == "word_mask":
+            wl = word_labels.clone()
+            wl[wl < 0] = -100           # the reference's data code writes -1, its loss ignores -100: any negative = not masked
+            lh.word_labels.copy_(wl, non_blocking=True)
+            lh.set_rows(word_rows if want_grad else None)      # labelled positions (from the data loader): masked-row head
+            self.encoder_forward(want_pooled=self.task_qa)
+            lh.mlm_fwd(self.lang_final)
+            out["lm_loss"] = lh.mlm_loss()[0:1]
+        elif task == "matched":
+            lh.matched_labels.copy_(matched_labels, non_blocking=True)
+            self.encoder_forward(want_pooled=True)
+            lh.rel_fwd(self.pooled)
+            out["matched_loss"] = lh.rel_loss()[1:2]
+        else:
+            assert self.task_qa, "task 'qa' needs a model built with the QA head (num_answers > 0)"
+            self.encoder_forward(want_pooled=True)
+        if self._qa_forward(qa_labels):
+            out["qa_loss"] = self.answer.loss[0:1]
+        self._qa_run = "qa_loss" in out
+        return out
+
+    def task_backward(self):
+        """backward of the branch task_forward ran last; ACCUMULATES into store.grad."""
+        task, qa, lh, ans = self._task_run, self._qa_run, self.lang_heads, self.answer
+        self.begin_backward()
+        GA = self.GA
+        if task == "vis_mask":
+            self._hrows = self._hrows_step
+            try:
+                self.head_backward(GA[self.ML:], report=not qa)
+            finally:
+                self._hrows = None
+            if self.need_lang:          # the language side of the last cross layer exists: zero gradient ...
+                GA[:self.ML].zero_()
+            if qa:                      # ... unless the QA branch reads pooled_output
+                cls_rows, d_cls = self._cls_views(GA)
+                ans.bwd(self.pooled, cls_rows, d_cls)
+                self._ready_heads()
+            self.encoder_backward(self.need_lang)
+            return
+        GA.zero_()
+        cls_rows, d_cls = self._cls_views(GA)
+        if task == "word_mask":
+            lh.mlm_bwd(GA[:self.ML])
+            if qa:
+                ans.bwd(self.pooled, cls_rows, d_cls, accumulate=True)     # the MLM gradient of the [CLS] rows is there
+        elif task == "matched":
+            extra = None
+            if qa:
+                ans.bwd_to_pooled(self.pooled)
+                extra = ans.dpooled
+            lh.rel_bwd(self.pooled, cls_rows, d_cls, extra_dpooled=extra)
+        else:
+            ans.bwd(self.pooled, cls_rows, d_cls)
+        self._ready_heads()
+        self.encoder_backward(True)
+
+    def _task_step(self, task, **kw):
+        out = self.task_forward(task, **kw)
+        st = self.store
+        st.grad[st.n_mat:st.n_used].zero_()
+        self.task_backward()
+        return out
+
+    def qa_forward_backward(self, qa_labels):
+        """XLxmertForPretraining.forward(task='qa') + backward on a task_qa model (ref lxrt/modeling.py:154-210, 292-306):
+        un-masked codebook features in, total_loss = qa_loss.  Returns the device loss buffer [1]."""
+        return self._task_step("qa", qa_labels=qa_labels)["qa_loss"]
+
+    def word_mask_forward_backward(self, word_labels, word_rows=None, qa_labels=None):
         """XLxmertForPretraining.forward(task='word_mask') + backward (ref lxrt/modeling.py:211-219): un-masked codebook
         features in (set_inputs(cluster_ids=..., vis_mask=None)), MLM loss over `word_labels` (negative = ignored)."""
-        lh = self.lang_heads
-        wl = word_labels.clone()
-        wl[wl < 0] = -100               # the reference's data code writes -1, its loss ignores -100: any negative = not masked
-        lh.word_labels.copy_(wl, non_blocking=True)
-        lh.set_rows(word_rows)          # flat indices of the labelled positions (from the data loader): masked-row head
-        self.encoder_forward(want_pooled=False)
-        lh.mlm_fwd(self.lang_final)
-        self.zero_accumulated_grads()
-        self.GA.zero_()
-        loss = lh.mlm_loss_bwd(self.GA[:self.ML])
-        self._ready("cls.")
-        self.encoder_backward(True)
-        return loss[0:1]
+        return self._task_step("word_mask", word_labels=word_labels, word_rows=word_rows, qa_labels=qa_labels)["lm_loss"]
 
-    def matched_forward_backward(self, matched_labels):
+    def matched_forward_backward(self, matched_labels, qa_labels=None):
         """XLxmertForPretraining.forward(task='matched') + backward (ref lxrt/modeling.py:221-229)."""
-        lh = self.lang_heads
-        lh.matched_labels.copy_(matched_labels, non_blocking=True)
-        self.encoder_forward(want_pooled=True)
-        lh.rel_fwd(self.pooled)
-        self.zero_accumulated_grads()
-        self.GA.zero_()
-        cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
-        loss = lh.rel_loss_bwd(self.pooled, cls_rows, self.GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
-        self._ready("cls.")
-        self.encoder_backward(True)
-        return loss[1:2]
+        return self._task_step("matched", matched_labels=matched_labels, qa_labels=qa_labels)["matched_loss"]
 
     def vqa_forward(self):
         """VQAModel.forward (ref tasks/vqa_model.py:22-72): real grid features -> encoder -> pooled_output -> answer head."""
@@ -948,7 +1094,7 @@ class Engine:
         GA.zero_()                                   # only the [CLS] rows of the language output carry gradient
         cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
         ans.bwd(self.pooled, cls_rows, GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
-        self._ready("answer_head.")
+        self._ready_heads()
         self.encoder_backward(True)
         return loss
 
@@ -1025,8 +1171,9 @@ class Engine:
         self.defer_reductions(True)
         self._lane_lo = {"v": 0, "l": self.store.language_range()[0]}
 
-    def head_backward(self, d_vis):
-        """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis."""
+    def head_backward(self, d_vis, report=True):
+        """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis.  report=False: another
+        head's backward (QA branch) still follows before the head gradients are final."""
         ops, d, MV, F, K = self.ops, self.d, self.MV, self.F, self.K
         M = self._head_rows()
         hd = self.hd
@@ -1062,7 +1209,8 @@ class Engine:
             ops.gemm(dtp, hd["wt"][0], dvc, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
             d_vis.zero_()
             ops.scatter_rows(dvc, self._hrows[0], d_vis, M, d, d, d)
-        self._ready("obj_predict_head.")
+        if report:
+            self._ready_heads()
 
     def encoder_backward(self, have_lang_grad=False):
         """d(outputs) are expected in GA ([lang ; vis] rows; the language rows are ignored unless have_lang_grad)."""
@@ -1147,20 +1295,9 @@ class Engine:
             self._report("v", st.n_used, flush=True)
 
     # ------------------------------------------------------------ whole vis_mask step (forward + backward)
-    def vis_mask_forward_backward(self, feat_loss=True):
+    def vis_mask_forward_backward(self, feat_loss=True, qa_labels=None):
         """XLxmertForPretraining.forward(task='vis_mask') + loss.backward() (ref lxrt/modeling.py:154-308,
-        lxmert_pretrain.py:338).  Gradients land in store.grad; returns the device loss buffer."""
-        self.encoder_forward(want_pooled=False)
-        use_rows = self.compact_head and self.has_vmask and 0 < self.n_mrows < self.MV
-        self._hrows = (self.mrows, self.n_mrows) if use_rows else None
-        try:
-            self.head_forward()
-            self.zero_accumulated_grads()
-            losses = self.losses_forward_backward(True, feat_loss)
-            self.head_backward(self.GA[self.ML:])
-        finally:
-            self._hrows = None
-        if self.need_lang:              # multi-task engine: the language side of the last cross layer exists, with zero gradient
-            self.GA[:self.ML].zero_()
-        self.encoder_backward(self.need_lang)
-        return losses
+        lxmert_pretrain.py:338).  Gradients land in store.grad; returns the device loss buffer [obj_loss, feat_loss]
+        (a task_qa model's qa_loss is in self.answer.loss)."""
+        self._task_step("vis_mask", feat_loss=feat_loss, qa_labels=qa_labels)
+        return self.losses

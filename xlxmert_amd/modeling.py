@@ -197,51 +197,73 @@ class LxmertVisualObjHead(_Named):
         return output
 
 
-class _VisMaskStepFn(torch.autograd.Function):
-    """XLxmertForPretraining vis_mask branch as one fused forward+backward (what the trainer also runs)."""
+class _TaskStepFn(torch.autograd.Function):
+    """One branch of XLxmertForPretraining.forward as engine.task_forward (encoder, heads, losses) with engine.task_backward
+    as its backward; `losses` come back as one tensor in the order of `keys`."""
 
     @staticmethod
-    def forward(ctx, model, anchor, feat_loss):
+    def forward(ctx, model, anchor, task, kw, keys):
         eng = model.bert._engine
-        eng.encoder_forward(want_pooled=False)
-        eng.head_forward()
-        losses = eng.losses_forward_backward(True, feat_loss)
+        out = eng.task_forward(task, **kw)
+        keys.extend(out.keys())
         ctx.model = model
-        return losses[:2].clone()
+        return torch.cat([out[k].reshape(1) for k in keys]).clone()
 
     @staticmethod
     def backward(ctx, d_losses):
         eng = ctx.model.bert._engine
         s = d_losses.tolist()
-        if abs(s[0] - s[1]) > 1e-12 and eng.with_feat_loss:
-            raise NotImplementedError("obj_loss and feat_loss must be weighted equally (total_loss = obj + feat)")
+        if max(s) - min(s) > 1e-12 * max(1.0, abs(s[0])):
+            raise NotImplementedError("the branch's losses must be weighted equally (total_loss is their plain sum)")
         # gradients ACCUMULATE into the flat buffer (several forward/backward calls per update, --update > 1): clearing is
         # zero_grad()'s job, as with autograd; the deferred column reductions are switched on and off inside this backward
-        eng.begin_backward()
-        eng.head_backward(eng.GA[eng.ML:])
-        eng.encoder_backward(False)
-        if s[0] != 1.0:
-            st = ctx.model._store
-            st.grad[:st.n_used].mul_(s[0])
-        return None, None, None
+        st = ctx.model._store
+        if s[0] != 1.0:             # a scaled loss (gradient accumulation / loss scaling): scale what this call adds
+            keep = st.grad[:st.n_used].clone()
+            st.grad[:st.n_used].zero_()
+            eng.task_backward()
+            st.grad[:st.n_used].mul_(s[0]).add_(keep)
+        else:
+            eng.task_backward()
+        return None, None, None, None, None
+
+
+class LxmertPreTrainingHeads(_Named):
+    """HF:648-657 `cls`: predictions (LxmertLMPredictionHead, decoder tied to the word embeddings) + seq_relationship;
+    parameters are views of the flat buffer, compute runs in engine.LangHeads."""
+
+    def __init__(self, store):
+        super().__init__()
+        self._bind(store, "cls", [n for n in store.names() if n.startswith("cls.")])
 
 
 class XLxmertForPretraining(nn.Module):
-    """ref lxrt/modeling.py:56-308 (task == 'vis_mask'; the word_mask / matched / qa branches are scope-table row N3)."""
+    """ref lxrt/modeling.py:56-308: `.bert`, `.cls` (task_mask_lm or task_matched), `.obj_predict_head` (task_obj_predict),
+    `.answer_head` (task_qa), `.mask_feat`, `.vis_emb`; forward(task = 'vis_mask' | 'word_mask' | 'matched' | 'qa')."""
 
     def __init__(self, config: XLxmertConfig, num_clusters=None, device=None, dtype=torch.bfloat16):
         super().__init__()
         if num_clusters is not None:
             config.num_clusters = num_clusters
         self.config = config
+        self.task_mask_lm, self.task_matched = config.task_mask_lm, config.task_matched
+        self.task_obj_predict, self.task_qa = config.task_obj_predict, config.task_qa
+        self.num_qa_labels = config.num_qa_labels
         dev = torch.device(device if device is not None else "cuda")
-        self._store = ParamStore(config, dev, dtype, task="vis_mask")
+        multi = self.task_mask_lm or self.task_matched or self.task_qa
+        # one parameter set for every branch the model was built for; a model with only the codebook head keeps the
+        # dead-branch-free layout of the masked-visual-token step
+        self._store = ParamStore(config, dev, dtype, task="all" if multi else "vis_mask",
+                                 num_answers=self.num_qa_labels if self.task_qa else 0)
         self.bert = LxmertModel(config, store=self._store, device=dev)
+        if self.task_mask_lm or self.task_matched:
+            self.cls = LxmertPreTrainingHeads(self._store)
         self.obj_predict_head = LxmertVisualObjHead(config, self.bert)
+        if self.task_qa:
+            self.answer_head = LxmertVisualAnswerHead(self._store)
         self.mask_feat = nn.Parameter(self._store.view("mask_feat"))
         self.mask_feat.grad = self._store.gview("mask_feat")
         self.vis_emb = None
-        self.task_obj_predict = True
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         from .trainer import init_reference_weights
         init_reference_weights(self._store, seed=0)
@@ -281,33 +303,56 @@ class XLxmertForPretraining(nn.Module):
                 visual_attention_mask=None, cluster_ids=None, vis_mask=None, token_type_ids=None, inputs_embeds=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, label_dict=None,
                 task="vis_mask", **kwargs):
-        if task != "vis_mask":
-            raise NotImplementedError(f"task {task!r}: only the masked-visual-token branch is on the hot path (N3 next)")
+        if task not in ("vis_mask", "word_mask", "matched", "qa"):
+            raise ValueError(f"task must be one of 'word_mask', 'vis_mask', 'matched', 'qa' (got {task!r})")
         if self.vis_emb is None:
             raise RuntimeError("call set_visual_embedding(centroids) first (ref lxrt/modeling.py:185-186)")
+        if inputs_embeds is not None or visual_attention_mask is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("inputs_embeds / visual_attention_mask / attention maps / hidden states: None in every "
+                                      "reference caller of this model (ref lxmert_pretrain.py:201-223)")
+        label_dict = label_dict or {}
         B, L = input_ids.shape
         V = cluster_ids.shape[1]
         eng = self._step_engine(B, L, V)
-        labels = label_dict["obj_labels"]
-        # feature regression iff the caller supplies its targets: the reference trainer adds label_dict['feat_labels'] (the
-        # real grid features) exactly when 'feat' is in --visualLosses (lxmert_pretrain.py:177-179); the canonical recipe
-        # (scripts/pretrain.bash:15, --visualLosses obj) has no feature loss.  (The published model code keys the branch on
-        # visual_obj_loss and then fails on the missing label: SURVEY App. A item 10.)
-        feat_labels = label_dict.get("feat_labels")
-        eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, cluster_ids=cluster_ids, vis_mask=vis_mask,
-                       obj_labels=labels, feat_labels=feat_labels)
-        feat_loss = feat_labels is not None
-        if torch.is_grad_enabled():
-            losses = _VisMaskStepFn.apply(self, self._anchor, feat_loss)
+        kw = {}
+        if task == "vis_mask":
+            # feature regression iff the caller supplies its targets: the reference trainer adds label_dict['feat_labels']
+            # (the real grid features) exactly when 'feat' is in --visualLosses (lxmert_pretrain.py:177-179); the canonical
+            # recipe (scripts/pretrain.bash:15, --visualLosses obj) has no feature loss.  (The published model code keys the
+            # branch on visual_obj_loss and then fails on the missing label: SURVEY App. A item 10.)
+            feat_labels = label_dict.get("feat_labels")
+            eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, cluster_ids=cluster_ids, vis_mask=vis_mask,
+                           obj_labels=label_dict["obj_labels"], feat_labels=feat_labels)
+            kw["feat_loss"] = feat_labels is not None
         else:
-            eng.encoder_forward(want_pooled=False)
-            eng.head_forward()
-            losses = eng.losses_forward_backward(False, feat_loss)[:2].clone()
-        obj_loss, feat_l = losses[0], losses[1]
-        if not feat_loss:
-            return {"obj_loss": obj_loss.detach(), "vis_loss": obj_loss.detach(), "total_loss": obj_loss}
-        total = obj_loss + feat_l
-        return {"obj_loss": obj_loss.detach(), "feat_loss": feat_l.detach(), "vis_loss": total.detach(), "total_loss": total}
+            if task == "word_mask":
+                if not self.task_mask_lm:
+                    raise RuntimeError("task 'word_mask' on a model built without task_mask_lm (no `cls` head)")
+                kw["word_labels"] = label_dict["word_labels"]
+            elif task == "matched":
+                if not self.task_matched:
+                    raise RuntimeError("task 'matched' on a model built without task_matched (no `cls` head)")
+                kw["matched_labels"] = label_dict["matched_labels"]
+            # the [MASK]-feature substitution belongs to task == 'vis_mask' only (ref lxrt/modeling.py:190-193)
+            eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, cluster_ids=cluster_ids)
+        if self.task_qa:                    # `if self.task_qa:` -- on the MODEL, not the task argument (ref :292)
+            kw["qa_labels"] = label_dict["qa_labels"]
+        elif task == "qa":
+            return {"total_loss": torch.zeros((), device=input_ids.device)}         # the reference adds nothing either
+        keys = []
+        if torch.is_grad_enabled():
+            losses = _TaskStepFn.apply(self, self._anchor, task, kw, keys)
+        else:
+            out = eng.task_forward(task, want_grad=False, **kw)
+            keys = list(out.keys())
+            losses = torch.cat([out[k].reshape(1) for k in keys]).clone()
+        out_dict = {k: losses[i].detach() for i, k in enumerate(keys)}
+        if task == "vis_mask":
+            out_dict["vis_loss"] = sum(losses[i] for i, k in enumerate(keys) if k in ("obj_loss", "feat_loss")).detach()
+        if self.task_qa:
+            out_dict["qa_pred"] = eng.answer.row_argmax.long().clone()          # ref :300
+        out_dict["total_loss"] = losses.sum()
+        return out_dict
 
     @torch.no_grad()
     def sample_codes(self, input_ids, n_steps=4, grid_size=8):
@@ -338,8 +383,8 @@ class XLxmertForPretraining(nn.Module):
     def _step_engine(self, B, L, V):
         key = (B, L, V, self.training, "step")
         if self.bert._geom != key:
-            self.bert._engine = Engine(self.config, self._store, self.bert._ops, B, L, V, need_lang=False,
-                                       train_dropout=self.training)
+            self.bert._engine = Engine(self.config, self._store, self.bert._ops, B, L, V,
+                                       need_lang=self._store.task != "vis_mask", train_dropout=self.training)
             self.bert._geom = key
         self.bert._engine.sync_compute_weights()
         return self.bert._engine

@@ -52,13 +52,17 @@ def _decays(name):
 
 def build_units(cfg, task="vis_mask", num_answers=0):
     """task: "vis_mask" (masked-visual-token pretraining step) or "vqa" (VQA/GQA fine-tune: real features in, pooled output
-    -> LxmertVisualAnswerHead, ref tasks/vqa_model.py:7-72; the codebook head and mask_feat are not part of that model)."""
+    -> LxmertVisualAnswerHead, ref tasks/vqa_model.py:7-72; the codebook head and mask_feat are not part of that model).
+    Pretraining tasks ("vis_mask", "word_mask", "matched", "qa", "all") with num_answers > 0 describe a model built with
+    `task_qa` (ref lxrt/modeling.py:89-90): the answer head over pooled_output joins EVERY task's loss (ref :292-304), so the
+    pooler, the language side of the last cross layer and `answer_head.*` are live in every branch."""
     d, dff, F, P = cfg.hidden_size, cfg.intermediate_size, cfg.visual_feat_dim, cfg.visual_pos_dim
     units = []
     # which heads a step of this task reads (everything else gets no gradient in the reference and must stay untouched):
     #   "word_mask" / "matched": the language pretraining branches (ref lxrt/modeling.py:211-235) -- language output or
     #   pooled_output only; un-masked codebook features in.  "all": every head of the pretraining model is live.
     pretrain = task in ("vis_mask", "all")
+    qa = task != "vqa" and num_answers > 0
 
     def U(region, used, *members):
         units.append(Unit([Member(n, tuple(s)) for n, s in members], region, used))
@@ -103,16 +107,16 @@ def build_units(cfg, task="vis_mask", num_answers=0):
     for i in range(cfg.x_layers):
         p = f"bert.encoder.x_layers.{i}"
         # vis_mask never reads the language output of the LAST cross layer
-        lang_used = not (task == "vis_mask" and i == cfg.x_layers - 1)
+        lang_used = qa or not (task == "vis_mask" and i == cfg.x_layers - 1)
         # ... and the VQA step never reads the VISUAL output of the last cross layer (only pooled_output): its visual
         # self-attention / FFN get no gradient in the reference, so the optimizer must not touch them
-        vis_used = not (task in ("vqa", "word_mask", "matched") and i == cfg.x_layers - 1)
+        vis_used = not (task in ("vqa", "word_mask", "matched", "qa") and i == cfg.x_layers - 1)
         att(p + ".visual_attention", "att")
         att(p + ".lang_self_att", "self", lang_used)
         att(p + ".visn_self_att", "self", vis_used)
         ffn(p + ".lang_inter", p + ".lang_output", lang_used)
         ffn(p + ".visn_inter", p + ".visn_output", vis_used)
-    pooled_used = task in ("vqa", "matched", "all")
+    pooled_used = qa or task in ("vqa", "matched", "all")
     U("mat", pooled_used, ("bert.pooler.dense.weight", (d, d)))
     U("vec", pooled_used, ("bert.pooler.dense.bias", (d,)))
     h = "obj_predict_head"
@@ -134,7 +138,7 @@ def build_units(cfg, task="vis_mask", num_answers=0):
         rel = task in ("matched", "all")
         U("vec", rel, (f"{c}.seq_relationship.weight", (2, d)))
         U("vec", rel, (f"{c}.seq_relationship.bias", (2,)))
-    if task == "vqa":
+    if task == "vqa" or qa:
         a = "answer_head.logit_fc"                       # nn.Sequential indices of HF:606-611
         U("mat", True, (f"{a}.0.weight", (2 * d, d)))
         U("vec", True, (f"{a}.0.bias", (2 * d,)))
@@ -251,6 +255,10 @@ class ParamStore:
         lo = self.range_of("bert.encoder.layer.")[0]
         hi = self.range_of("bert.embeddings.")[1]
         return lo, hi
+
+    def heads_end(self):
+        """end of the block of head gradients (everything with _backward_rank 0: codebook head, cls.*, answer head, pooler)."""
+        return max(u.offset + u.padded for u in self.units if u.used and _backward_rank(self.cfg, u.members[0].name) == 0)
 
     def range_of(self, prefix):
         """[lo, hi) element range (incl. padding) covered by the units whose first member starts with `prefix`."""

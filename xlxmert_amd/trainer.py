@@ -158,13 +158,17 @@ class PretrainStep:
         cluster_ids, vis_mask, obj_labels (optional: derived from cluster_ids/vis_mask as the reference does)."""
         eng, st, ops = self.engine, self.store, self.ops
         run = self.task if self.task != "all" else task           # a multi-task step object is told which branch to run
-        assert run in ("vis_mask", "word_mask", "matched", "vqa"), "PretrainStep(task='all').step(batch, task=...)"
+        assert run in ("vis_mask", "word_mask", "matched", "qa", "vqa"), "PretrainStep(task='all').step(batch, task=...)"
+        # a model built with task_qa (ParamStore num_answers > 0 on a pretraining task): batch["qa_labels"] [B] (-100 = no
+        # answer; the caller applies the reference's matched-task flip mask, lxmert_pretrain.py:186-190) joins every branch;
+        # the qa loss of the step is self.engine.answer.loss
         self._step_task = run
         ids = batch["input_ids"]
         am = batch.get("attention_mask")
         if am is None:
             am = ids > 0                                       # ref lxmert_pretrain.py:206 / tasks/vqa.py:178
-        if run in ("word_mask", "matched"):
+        qa_labels = batch.get("qa_labels") if eng.task_qa else None
+        if run in ("word_mask", "matched", "qa"):
             # language pretraining branches (ref lxmert_pretrain.py:159-160,180-182,192-195): un-masked codebook features;
             # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels (+ optional word_rows:
             # word_rows_of(word_labels), the masked-row decoder) | matched_labels
@@ -173,8 +177,12 @@ class PretrainStep:
             if self.exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
-            loss = (eng.word_mask_forward_backward(batch["word_labels"], batch.get("word_rows")) if run == "word_mask"
-                    else eng.matched_forward_backward(batch["matched_labels"]))
+            if run == "word_mask":
+                loss = eng.word_mask_forward_backward(batch["word_labels"], batch.get("word_rows"), qa_labels=qa_labels)
+            elif run == "matched":
+                loss = eng.matched_forward_backward(batch["matched_labels"], qa_labels=qa_labels)
+            else:
+                loss = eng.qa_forward_backward(qa_labels)
             if self.exchange:
                 self._finish_exchange()
             self.optimizer_step()
@@ -202,7 +210,7 @@ class PretrainStep:
         if self.exchange:
             self._begin_exchange()
             eng.grad_ready = self._on_grad_ready
-        losses = eng.vis_mask_forward_backward(self.feat_loss)
+        losses = eng.vis_mask_forward_backward(self.feat_loss, qa_labels=qa_labels)
         if self.exchange:
             self._finish_exchange()
         self.optimizer_step()
