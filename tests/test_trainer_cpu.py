@@ -253,6 +253,97 @@ def test_data_parallel_world2_gloo(tmp_path):
         assert (r0[k] - p).abs().max().item() < 2e-5, k
 
 
+def _dp_worker_modes(rank, world, port, out_dir):
+    """bf16 gradient buckets; VQA step; task round-robin with the QA head; per-tensor replica verification."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    B, L, grid = 2, 8, 4
+    res = {}
+    # (1) masked-visual-token step with bf16 buckets
+    tr, sd = make_step(cfg, B, L, grid, lr=1e-2, bucket_mb=0.05, grad_comm_dtype=torch.bfloat16)
+    assert tr.comm_buf is not None and tr.comm_buf.dtype == torch.bfloat16
+    tr.step(synthetic_batch(cfg, B, L, grid, seed=500 + rank))
+    assert tr.verify_replicas() == []
+    res["bf16"] = {k: tr.store.view(k).clone() for k in tr.store.names()}
+    # (2) VQA fine-tune step
+    A = 29
+    store = ParamStore(cfg, "cpu", torch.float32, task="vqa", num_answers=A)
+    store.load_named(O.make_vqa_state_dict(oc, A, 5))
+    trv = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
+                       total_steps=10, lr=1e-2, task="vqa", num_answers=A, bucket_mb=0.05)
+    trv.step(O.make_vqa_inputs(oc, A, 600 + rank, B, L, grid))
+    assert trv.verify_replicas() == [] and len(trv._works) > 3
+    res["vqa"] = {k: trv.store.view(k).clone() for k in trv.store.names()}
+    # (3) task round-robin on one parameter set with the QA head riding on every branch
+    NQ = 11
+    store = ParamStore(cfg, "cpu", torch.float32, task="all", num_answers=NQ)
+    store.load_named(O.make_qa_state_dict(oc, NQ, 9))
+    tra = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
+                       total_steps=10, lr=1e-2, task="all", num_answers=NQ, bucket_mb=0.05, visual_losses="obj,feat")
+    for t, task in enumerate(["vis_mask", "word_mask", "matched", "qa"]):
+        batch = synthetic_batch(cfg, B, L, grid, seed=700 + 10 * t + rank)
+        wl, ml = O.make_lang_task_labels(oc, batch["input_ids"], 800 + 10 * t + rank)
+        batch.update(word_labels=wl, matched_labels=ml, qa_labels=O.make_qa_labels(NQ, B, 900 + 10 * t + rank))
+        tra.step(batch, task=task)
+        assert tra.verify_replicas() == [], (task, tra.verify_replicas()[:4])
+    res["all"] = {k: tra.store.view(k).clone() for k in tra.store.names()}
+    # (4) a diverged replica is caught, tensor by tensor
+    if rank == 1:
+        tra.store.view("bert.pooler.dense.bias")[3] += 1.0
+    bad = tra.verify_replicas()
+    assert bad == ["param:bert.pooler.dense.bias"], bad
+    torch.save(res, os.path.join(out_dir, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world2_gloo_bf16_buckets_vqa_and_round_robin(tmp_path):
+    """world 2 over gloo: (1) bf16 gradient buckets = one AdamW step on the mean of the per-rank gradients up to the bf16
+    rounding of the exchanged values; (2) VQA step and (3) task round-robin with the QA head keep the replicas bit-identical
+    and equal the oracle's mean-gradient update; (4) verify_replicas names a diverged tensor."""
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker_modes, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "m0.pt"), torch.load(tmp_path / "m1.pt")
+    for mode in ("bf16", "vqa"):
+        for k in r0[mode]:
+            assert torch.equal(r0[mode][k], r1[mode][k]), (mode, k)
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    # bf16 buckets against the exact mean-gradient update: first-step AdamW moves every element by ~lr * sign(g); a bf16-
+    # rounded gradient changes that by < 1 % of lr except where the mean gradient is within rounding of zero
+    sd = O.make_state_dict(oc, 3)
+    gs = [oracle_grads(cfg, sd, synthetic_batch(cfg, 2, 8, 4, seed=500 + r))[0] for r in range(world)]
+    names = sorted(gs[0])
+    mean = [(gs[0][k] + gs[1][k]) / 2 for k in names]
+    _, clipped = O.clip_grad_norm(mean, 1.0)
+    lr = 1e-2 * linear_schedule(0, 0, 10)
+    close = tot = 0
+    for k, g in zip(names, clipped):
+        p, _, _ = O.adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr)
+        d = (r0["bf16"][k] - p).abs()
+        close += (d < 2e-2 * lr).sum().item()
+        tot += d.numel()
+        assert d.max().item() <= 2.0 * lr + 1e-6, k
+    assert close / tot > 0.97, close / tot
+    # VQA: exact (fp32 exchange)
+    A = 29
+    sdv = O.make_vqa_state_dict(oc, A, 5)
+    grads = []
+    for r in range(world):
+        leaf = {k: v.clone().requires_grad_(True) for k, v in sdv.items()}
+        b = O.make_vqa_inputs(oc, A, 600 + r, 2, 8, 4)
+        O.vqa_forward(leaf, oc, b["input_ids"], b["visual_feats"], b["visual_pos"], targets=b["targets"])["loss"].backward()
+        grads.append({k: v.grad for k, v in leaf.items() if v.grad is not None})
+    names = sorted(grads[0])
+    _, clipped = O.clip_grad_norm([(grads[0][k] + grads[1][k]) / 2 for k in names], 1.0)
+    for k, g in zip(names, clipped):
+        p, _, _ = O.adamw_update(sdv[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr)
+        assert (r0["vqa"][k] - p).abs().max().item() < 2e-5, k
+
+
 def test_random_word_batch_statistics():
     from xlxmert_amd.trainer import random_word_batch
     g = torch.Generator().manual_seed(0)

@@ -295,8 +295,10 @@ class XLxmertForPretraining(nn.Module):
         missing = self._store.load_named(sd, strict=strict)
         if self.vis_emb is None and self._store.centroids is not None:
             self.set_visual_embedding(self._store.centroids)
-        unexpected = [k for k in sd if k not in self._store.index and k not in ("vis_emb.weight",
-                                                                               "obj_predict_head.out_cluster.weight")]
+        # aliases of tensors stored once: the frozen codebook (vis_emb == out_cluster.weight) and the MLM decoder, tied to the
+        # word embeddings (transformers 4.1.1 LxmertPreTrainingHeads(config, embedding_weight), ref lxrt/modeling.py:86)
+        alias = ("vis_emb.weight", "obj_predict_head.out_cluster.weight", "cls.predictions.decoder.weight")
+        unexpected = [k for k in sd if k not in self._store.index and k not in alias]
         return missing, unexpected
 
     def forward(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,

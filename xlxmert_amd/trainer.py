@@ -51,7 +51,7 @@ class PretrainStep:
     def __init__(self, cfg: XLxmertConfig, batch_size, text_len=20, n_grids=64, dtype=torch.bfloat16, device=None,
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
-                 bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj"):
+                 bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -61,7 +61,11 @@ class PretrainStep:
         visual_losses: the reference's --visualLosses ("obj" in scripts/pretrain.bash:15 = the canonical recipe and the
         default here; "obj,feat" adds the masked SmoothL1 feature regression onto batch["feat_labels"] -- the real grid
         features, ref lxmert_pretrain.py:177-179 -- or, when the batch carries none, onto the centroid of each position's
-        cluster id).  feat_loss=True/False overrides it (older call sites)."""
+        cluster id).  feat_loss=True/False overrides it (older call sites).
+        grad_comm_dtype: element type of the gradient exchange, torch.float32 (default; what DDP moves for the reference's
+        fp32 parameters) or torch.bfloat16 (half the bytes over xGMI: 405 MB instead of 810 MB per step; every finished
+        slice is cast into a bf16 bucket on the stream that produced it, summed by RCCL, and cast back into the fp32
+        gradient buffer before the norm / AdamW, which keep accumulating in fp32).  Env XL_GRAD_COMM=bf16|fp32 overrides."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -94,7 +98,17 @@ class PretrainStep:
         # memory a queued step still has to read
         self.lrs = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // 4)
+        env = os.environ.get("XL_GRAD_COMM")
+        if env:
+            grad_comm_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[env]
+        self.grad_comm_dtype = grad_comm_dtype or torch.float32
+        self.comm_buf, self._comm_ops = None, self.ops
+        if self.exchange and self.grad_comm_dtype == torch.bfloat16:
+            self.comm_buf = torch.zeros(self.store.n_used, dtype=torch.bfloat16, device=self.device)
+            if isinstance(self.ops, HipOps) and self.ops.dtype != torch.bfloat16:
+                self._comm_ops = HipOps(torch.bfloat16)
+        self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // (2 if self.comm_buf is not None else 4))
+        self.exposed_comm_ms = []              # per step: time the main stream waited for collectives after backward
         if self.world > 1:
             self.sync_replicas()
 
@@ -114,6 +128,27 @@ class PretrainStep:
         self.t = int(self.step_dev.item())
         self.engine.sync_compute_weights()
 
+    def verify_replicas(self):
+        """names of the tensors (parameters, Adam moments) whose per-tensor checksum differs between ranks -- [] when the
+        replicas agree.  One float64 sum per tensor and buffer, MIN / MAX all-reduced: cheap enough for every N-th step."""
+        st = self.store
+        names = [n for n in st.index if st.index[n].offset < st.n_used]
+        sums = []
+        for buf in (st.master, st.exp_avg, st.exp_avg_sq):
+            for n in names:
+                m = st.index[n]
+                k = 1
+                for d in m.shape:
+                    k *= d
+                sums.append(buf[m.offset:m.offset + k].double().sum())
+        v = torch.stack(sums)
+        lo, hi = v.clone(), v.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        bad = (lo != hi).nonzero().reshape(-1).tolist()
+        kinds = ("param", "exp_avg", "exp_avg_sq")
+        return [f"{kinds[i // len(names)]}:{names[i % len(names)]}" for i in bad]
+
     def set_centroids(self, centroids):
         self.store.set_centroids(centroids)
 
@@ -127,7 +162,11 @@ class PretrainStep:
         self._lanes, self._works, self._slices = {}, [], []
 
     def _send(self, lo, hi):
-        self._works.append(dist.all_reduce(self.store.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        buf = self.store.grad
+        if self.comm_buf is not None:           # bf16 bucket, filled on the stream that just finished the slice
+            self._comm_ops.cast_from_f32(self.store.grad[lo:hi], self.comm_buf[lo:hi], hi - lo)
+            buf = self.comm_buf
+        self._works.append(dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self._slices.append((lo, hi))
 
     def _on_grad_ready(self, lo, hi, flush=False, lane="v"):
@@ -150,8 +189,25 @@ class PretrainStep:
             assert lo == pos, (lo, pos)
             pos = hi
         assert pos == self.store.n_used, (pos, self.store.n_used)
+        timed = self.device.type == "cuda"
+        if timed:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
         for w in self._works:
             w.wait()
+        if timed:
+            t1.record()
+            self.exposed_comm_ms.append((t0, t1))
+            del self.exposed_comm_ms[:-64]
+        if self.comm_buf is not None:           # summed bf16 buckets back into the fp32 gradient buffer (norm + AdamW read it)
+            n = self.store.n_used
+            self._comm_ops.cast_to_f32(self.comm_buf[:n], self.store.grad[:n], n)
+
+    def exposed_comm(self):
+        """mean time (ms) the compute stream spent waiting for gradient collectives at the end of backward (last <= 64 steps;
+        call after a synchronize)."""
+        ts = [a.elapsed_time(b) for a, b in self.exposed_comm_ms]
+        return sum(ts) / len(ts) if ts else 0.0
 
     def step(self, batch, task=None):
         """batch: dict with input_ids, attention_mask (optional), token_type_ids (optional), visual_pos,
