@@ -64,7 +64,7 @@ def test_step_gradients_fp32_match_reference_fixture():
 
 def test_step_gradients_bf16_close_to_reference_fixture():
     """bf16 operands / fp32 accumulate: stated tolerance = loss within 2e-2, every gradient tensor within 6% of its
-    norm (relative L2) of the fp32 reference gradient."""
+    norm (relative L2) of the fp32 reference gradient (3x the measured worst tensor, 2.1 %)."""
     g = load_golden("tiny_222")
     eng, oc, sd, inp = build(g, torch.bfloat16, False)
     losses = eng.vis_mask_forward_backward()
@@ -108,7 +108,8 @@ def test_config1_logits_fp32_within_1e3():
 
 def test_config1_logits_bf16_stated_tolerance():
     """bf16 throughput mode against the same fixture.  Stated tolerance (logit std ~ 16): max abs err < 1.5,
-    mean abs err < 0.25, argmax agreement >= 90 %."""
+    mean abs err < 0.25, argmax agreement >= 90 % (measured 0.58 / 0.10 / 96.1 %; the reference's own bf16 autocast: 0.76 /
+    0.115 / 97.7 %)."""
     g = load_golden("config1")
     eng, oc, sd, inp = build(g, torch.bfloat16, True)
     eng.encoder_forward()
@@ -175,7 +176,7 @@ def test_full_width_fp32_matches_reference_fixture():
     assert abs(losses[1].item() - g["feat_loss"].item()) < 1e-4
     wn, ws, med = _grad_report(eng, g)
     print("full_955 fp32 worst gradient-norm error", wn, "worst sample error", ws, "median", med)
-    assert wn[1] < 1e-3 and ws[1] < 2e-3, (wn, ws)
+    assert wn[1] < 1e-4 and ws[1] < 2e-4, (wn, ws)              # measured 3.5e-6 / 1.1e-5
 
 
 @pytest.mark.parametrize("pingpong", [2, 1])
@@ -204,10 +205,10 @@ def test_full_width_bf16_benchmark_configuration_close_to_reference(pingpong):
     print(f"full_955 bf16 (pingpong={pingpong}): loss rel err {rel_loss:.4f}, worst gradient-norm error {wn}, worst sample error {ws}, "
           f"median sample error {med:.4f}")
     assert rel_loss < 5e-3 and abs(losses[1].item() - g["feat_loss"].item()) < 2e-3
-    assert wn[1] < 4.5e-2 and ws[1] < 0.154 and med < 3e-2, (wn, ws, med)
+    assert wn[1] < 4.5e-2 and ws[1] < 0.154 and med < 4e-2, (wn, ws, med)      # measured 2.2 % / 9.2 % / 2.9 %
 
 
-@pytest.mark.parametrize("dtype,tn,ts", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 3e-2, 6e-2)])
+@pytest.mark.parametrize("dtype,tn,ts", [(torch.float32, 1e-4, 1e-4), (torch.bfloat16, 1e-2, 3e-2)])     # measured: 1e-6 / 3e-6; 0.3 % / 1.0 %
 def test_config1_gradients_match_reference_fixture(dtype, tn, ts):
     """BASELINE config 1 (1+1+1 layers at d=768): the norm of all 79 reference gradients (`gnorm:*`) and the stored ones."""
     g = load_golden("config1")
@@ -504,7 +505,7 @@ def test_vqa_full_size_step_properties_bf16(B):
         torch.cuda.synchronize()
         d = (logit_big - logit_small).abs().max().item()
         print("vqa bs512 vs bs64 logits max abs diff:", d, "logit scale", logit_small.abs().max().item())
-        assert d < 2e-2 * max(1.0, logit_small.abs().max().item())
+        assert d < 1e-3 * max(1.0, logit_small.abs().max().item())          # measured 2.4e-7
 
 
 # ---------------------------------------------------------------- on-device iterative sampler
@@ -720,4 +721,4 @@ def test_qa_branch_steps_bf16_stated_tolerance(task):
         if ref_n > 1e-4:
             worst = max(worst, abs(got_n - ref_n) / ref_n)
     print(f"qa fixture bf16 {task}: worst gradient-norm error {worst:.4f}")
-    assert worst < 5e-2
+    assert worst < 3e-2                 # measured 0.9 %
