@@ -37,7 +37,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, bs, budget_s=20.0):
+def cpu_baseline(cfg, bs, budget_s=20.0, big_bs=256):
     """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores: fwd + bwd + clip + AdamW."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import lxmert_oracle as O
@@ -56,6 +56,7 @@ def cpu_baseline(cfg, bs, budget_s=20.0):
     batch = synthetic_batch(cfg, bs, 20, 8, seed=9595)
 
     def one(t):
+        nonlocal batch
         for p in params:
             p.grad = None
         out = O.xlxmert_vis_mask_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
@@ -77,8 +78,16 @@ def cpu_baseline(cfg, bs, budget_s=20.0):
         times.append(time.time() - s)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(bs / med, 3), "unit": "examples/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} full steps (fwd+bwd+clip+AdamW, fp32 torch-CPU oracle) at bs={bs}, median {med:.2f} s/step"}
+    res = {"value": round(bs / med, 3), "unit": "examples/s", "cores": cores, "kind": "port",
+           "sample": f"{len(times)} full steps (fwd+bwd+clip+AdamW, fp32 torch-CPU oracle) at bs={bs}, median {med:.2f} s/step"}
+    if big_bs and time.time() - t0 < 2.5 * budget_s:      # SURVEY 8d also asks for the metric's own batch size: ONE step
+        batch = synthetic_batch(cfg, big_bs, 20, 8, seed=9595)
+        s = time.time()
+        one(len(times) + 2)
+        dt = time.time() - s
+        res["value_bs%d" % big_bs] = round(big_bs / dt, 3)
+        res["sample"] += f"; 1 step at bs={big_bs}: {dt:.1f} s"
+    return res
 
 
 class GemmTimer:
@@ -93,14 +102,21 @@ class GemmTimer:
             s.record()
             self.orig(A, B, C, bias, residual, aux, M, N, K, *a, **kw)
             e.record()
-            self.rec.append((s, e, 2.0 * M * N * K, (M, N, K, kw.get("a_kmajor", 1), kw.get("b_kmajor", 1), kw.get("epilogue", 0))))
+            eb = 2 if A.dtype == torch.bfloat16 else 4
+            nbytes = eb * (M * K + N * K) + C.element_size() * M * N + (eb * M * N if residual is not None else 0) + \
+                (eb * M * N if aux is not None else 0)
+            self.rec.append((s, e, 2.0 * M * N * K, (M, N, K, kw.get("a_kmajor", 1), kw.get("b_kmajor", 1), kw.get("epilogue", 0)),
+                             nbytes, getattr(self.ops, "block", "")))
         def timed_group(problems):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             self.orig_group(problems)
             e.record()
+            eb = problems[0][0].element_size()
+            nbytes = sum(eb * pr[5] * (pr[3] + pr[4]) + 2 * 4 * pr[3] * pr[4] for pr in problems)      # operands + fp32 read-modify-write
             self.rec.append((s, e, sum(2.0 * pr[3] * pr[4] * pr[5] for pr in problems),
-                             ("group", len(problems), problems[0][5], sum(pr[3] * pr[4] for pr in problems) // 65536, 0, 0)))
+                             ("group", len(problems), problems[0][5], sum(pr[3] * pr[4] for pr in problems) // 65536, 0, 0),
+                             nbytes, getattr(self.ops, "block", "")))
         self.ops.gemm = timed
         self.ops.gemm_wgrad_group = timed_group
         return self
@@ -111,7 +127,23 @@ class GemmTimer:
         torch.cuda.synchronize()
         self.total_ms = sum(r[0].elapsed_time(r[1]) for r in self.rec)
         self.flops = sum(r[2] for r in self.rec)
+        self.bytes = sum(r[4] for r in self.rec)
         self.launches = len(self.rec)
+
+    def by_block(self, peak_tflops):
+        """GEMM time / FLOPs per group of model blocks (labels set by the engine): language stack, visual stack, the five
+        cross-modality layers (their Q/KV/out projections + the self-attention and FFN sub-blocks = row A7), head."""
+        groups = {"cross_modality_layers": lambda t: t.startswith("x"), "cross_attention_blocks_only": lambda t: t.startswith("x") and t[1:].isdigit(),
+                  "language_layers": lambda t: t.startswith("l"), "visual_layers": lambda t: t.startswith("r"),
+                  "codebook_head_and_feature_encoder": lambda t: t in ("head", "visn_fc")}
+        out = {}
+        for name, pred in groups.items():
+            rs = [r for r in self.rec if pred(r[5])]
+            if rs:
+                ms = sum(r[0].elapsed_time(r[1]) for r in rs)
+                tf = sum(r[2] for r in rs) / (ms * 1e-3) / 1e12
+                out[name] = {"launches": len(rs), "gemm_ms": round(ms, 3), "achieved": round(tf, 1), "frac": round(tf / peak_tflops, 4)}
+        return out
 
 
 def main():
@@ -196,14 +228,15 @@ def main():
     with GemmTimer(tr.ops) as gt:
         tr.step(batches[0])
     tr.engine.side = side
-    traffic = None
+    traffic, traffic_src = None, None
     try:        # HBM bytes per GEMM launch from the committed PMC profile of this build (cannot be collected live)
-        traffic = round(json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic.json")))["bytes_per_launch"])
+        tj = json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic.json")))
+        traffic, traffic_src = round(tj["bytes_per_launch"]), tj.get("source")
     except Exception:
         pass
     if rank == 0 and args.gemm_table:
         agg = {}
-        for s_, e_, f_, key in gt.rec:
+        for s_, e_, f_, key, _b, _t in gt.rec:
             a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += s_.elapsed_time(e_); a[2] += f_
         for key, (c, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print(f"  {str(key):44s} x{c:3d} {t:8.3f} ms  {t / c * 1e3:8.1f} us  {f / t / 1e9:7.1f} TF/s", file=sys.stderr)
@@ -221,6 +254,9 @@ def main():
                        "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}",
                        "dropout": "off (eval-parity mode)" if args.no_dropout else "0.1 hidden + 0.1 attention (training mode, 94 sites)",
                        "loss": round(loss_val, 4),
+                       "visual_losses": "obj,feat" if tr.feat_loss else "obj (scripts/pretrain.bash:15)",
+                       "inputs": "4 synthetic minibatches per rank resident in HBM before the timed region: no H2D inside it "
+                                 "(a batch is ~0.5 MB of int64 ids; SURVEY 8d counts its upload, 0.5 MB over PCIe ~ 10 us)",
                        "vis_mask": "--vis_mask_predict masks, n ~ U{1..64} per image (ref lxmert_data.py:414-419)",
                        "head_rows": "codebook head + both losses on the masked rows only (exact: the reference's losses read "
                                     "nothing else); all rows with XL_COMPACT_HEAD=0"},
@@ -230,12 +266,22 @@ def main():
             "step_mfma_frac": round(gt.flops / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel + gemm_bf16_mfma_kernel (all dense contractions of one step, grouped weight gradients included)",
                          "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(gt.bytes / gt.launches),
+                         "algorithmic_bytes_per_step": int(gt.bytes),
+                         "blocks": gt.by_block(PEAK_BF16_TFLOPS),
                          "launches_per_step": gt.launches, "avg_launch_us": round(gt.total_ms * 1e3 / gt.launches, 2),
                          "gemm_ms_per_step": round(gt.total_ms, 3),
                          "algorithmic_gflop_per_step": round(gt.flops / 1e9, 1),
                          "contract_gflop_per_step": round(GFLOP_PER_EXAMPLE * B, 1)},
         }
+        if world > 1 or grouped:
+            out["config"]["gradient_exchange"] = {
+                "collective": "RCCL all-reduce (sum; 1/N folded into AdamW) per finished slice of the flat gradient buffer",
+                "element_type": "bf16" if tr.comm_buf is not None else "fp32",
+                "bucket_mb": round(tr.bucket_elems * (2 if tr.comm_buf is not None else 4) / (1 << 20), 1),
+                "bytes_per_step": int(tr.store.n_used * (2 if tr.comm_buf is not None else 4)),
+                "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3)}
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -50,6 +50,10 @@ int  xl_set_lds_transpose_read(int enable);
 /* GEMM kernel choice for bf16 operands: 0 = 128x128 kernel only, 1 = by shape (default), 2 = the 256x256 ping-pong
  * kernel whenever the operands allow it (tuning / test switch; env XL_GEMM_PP sets the initial value) */
 int  xl_set_gemm_pingpong(int mode);
+/* 256x192 output tiles of the ping-pong kernel (forward / dX layouts, N a multiple of 192, M of 256, bf16 output): 0 = never,
+ * 1 = when they shorten the launch (default: N = 768 gives 192 tiles of 256x256 on 256 CUs but 256 of 256x192), 2 = whenever
+ * eligible (test switch; env XL_GEMM_BN192 sets the initial value) */
+int  xl_set_gemm_tile192(int mode);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */
 int  xl_gemm_trace(void* buffer);

@@ -144,6 +144,43 @@ def test_gemm_pingpong_pipeline_depths(M, N, K, layout):
         ops.set_gemm_pingpong(1)
 
 
+@pytest.mark.parametrize("bk", [1, 0])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 768, 128), (768, 384, 200), (256, 2304, 1000), (1024, 768, 1536)])
+def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
+    """the 256x192 variant of the ping-pong kernel (waves 4 x 2, wave tile 64 x 96, B staged in three 8 KiB parts) forced for
+    every eligible launch: 1 / 2 / 4 (ragged) / 16 (ragged) / 24 K tiles, forward and dX operand layouts, all four fast
+    epilogues.  Integer-valued operands: the fp32 accumulation is exact, so the plain result must equal the host product bit
+    for bit and the epilogue variants must equal the host restatement to bf16 rounding of identical pre-epilogue values."""
+    g = torch.Generator().manual_seed(M + N + K + epi * 3 + bk)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+    B = torch.randint(-3, 4, ((N, K) if bk else (K, N)), generator=g).to(torch.bfloat16)
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    res = torch.randint(-8, 9, (M, N), generator=g).to(torch.bfloat16)
+    aux = (torch.randint(-8, 9, (M, N), generator=g).float() * 0.25).to(torch.bfloat16)
+    alpha = 2.0 ** -6 if epi in (1, 3) else 1.0            # keep GELU / dGELU arguments in a sensible range
+    ops = hip(torch.bfloat16)
+    ops.set_gemm_pingpong(2)
+    ops.set_gemm_tile192(2)
+    try:
+        for rep in range(2):
+            C = torch.full((M, N), 7.0, dtype=torch.bfloat16)
+            X = aux.clone()
+            cpu, gpu = run_both(torch.bfloat16, "gemm", [A, B, C, bias, res if epi == 2 else None, X if epi in (1, 3) else None,
+                                                         M, N, K, K, (K if bk else N), N],
+                                dict(ldr=N, ldx=N, b_kmajor=bk, epilogue=epi, alpha=alpha))
+            if epi in (0, 2):
+                # exact integers up to bf16 rounding of the final value: both sides round the same fp32 number
+                assert torch.equal(gpu[2], cpu[2]), f"rep {rep}: max abs diff {(gpu[2].float() - cpu[2].float()).abs().max().item()}"
+            else:
+                close(gpu[2], cpu[2], torch.bfloat16, f"256x192 epilogue {epi}", bf16_tol=1e-2)
+            if epi == 1:
+                assert torch.equal(gpu[5], cpu[5]), "saved pre-activation"
+    finally:
+        ops.set_gemm_pingpong(1)
+        ops.set_gemm_tile192(1)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N", [(512, 256), (256, 512), (200, 136)])
 def test_gemm_fused_column_sums(M, N, dtype, pingpong):

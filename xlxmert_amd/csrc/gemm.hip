@@ -230,6 +230,7 @@ static int env_int(const char* name, int dflt) {
 
 unsigned long long* g_gemm_trace = nullptr;   // xl_gemm_trace
 int g_gemm_pp = -1;      // 0 / 1 / 2, see xl_set_gemm_pingpong; -1 = read XL_GEMM_PP (default 1)
+int g_gemm_bn192 = -1;   // 0 / 1 / 2, see xl_set_gemm_tile192; -1 = read XL_GEMM_BN192 (default 1)
 
 }  // namespace xl
 
@@ -244,6 +245,12 @@ extern "C" int xl_gemm_trace(void* buffer) {
 extern "C" int xl_set_gemm_pingpong(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_pingpong: mode %d", mode);
     g_gemm_pp = mode;
+    return XL_OK;
+}
+
+extern "C" int xl_set_gemm_tile192(int mode) {
+    XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_tile192: mode %d", mode);
+    g_gemm_bn192 = mode;
     return XL_OK;
 }
 
@@ -298,7 +305,20 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     const bool use_pp = pp_ok && (pp_mode == 2 || (pp_mode == 1 && pp_blocks >= pp_min_tiles));
     const int tile = use_pp ? 256 : mfma_ok ? 128 : 64;
     p.tiles_m = (M + tile - 1) / tile;
-    p.tiles_n = (N + tile - 1) / tile;
+    // 256x192 tiles (forward / dX layouts with a fast epilogue, every tile interior): taken when they shorten the launch,
+    // estimated as rounds over the 256 CUs x relative tile cost (a 256x192 tile does 3/4 of the MFMA work plus the same
+    // fixed prologue / epilogue latency: ~0.8).  N = 768: 64 row tiles give 192 tiles of 256x256 (a quarter of the chip
+    // idle) or 256 of 256x192; N = 2304: 576 (2.25 rounds) or 768 (3 rounds of 0.8); N = 3072 stays at 256x256.
+    if (g_gemm_bn192 < 0) g_gemm_bn192 = env_int("XL_GEMM_BN192", 1);     // 0 never, 1 by cost, 2 whenever eligible
+    const int bn192_mode = g_gemm_bn192;
+    int bn = 256;
+    if (use_pp && bn192_mode && a_kmajor && M % 256 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate &&
+        colsum_out == nullptr && epilogue != XL_EPI_TANH) {
+        const long t256 = (long)p.tiles_m * ((N + 255) / 256), t192 = (long)p.tiles_m * (N / 192);
+        const double c256 = (double)((t256 + 255) / 256), c192 = 0.8 * (double)((t192 + 255) / 256);
+        if (bn192_mode == 2 || c192 < c256) bn = 192;
+    }
+    p.tiles_n = bn == 192 ? N / 192 : (N + tile - 1) / tile;
     const int tiles = p.tiles_m * p.tiles_n;
     // split-K only for the weight-gradient shape (fp32 out, plain epilogue): few output tiles, deep K
     int splitk = 1;
@@ -319,7 +339,6 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: memset failed: %s", hipGetErrorString(e));
     }
-    const int nblk = tiles * splitk;
     // 16-byte epilogue accesses need 8-element (bf16) / 4-element (fp32) aligned rows of C / residual / aux
     p.vec_epi = aligned16(C) && (out_dtype == XL_F32 ? ldc % 4 == 0 : ldc % 8 == 0);
     if (epilogue == XL_EPI_RESIDUAL) p.vec_epi = p.vec_epi && aligned16(residual) && ldr % 8 == 0;
@@ -327,12 +346,17 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // fast (templated) epilogue: aligned rows, a kind that has one, plain stores
     int epik = -1;
     if (p.vec_epi && !p.atomic_out && epilogue != XL_EPI_TANH && (bias == nullptr || aligned16(bias))) epik = epilogue;
+    if (bn == 192 && epik < 0) {          // the 256x192 tile has the fast epilogue only: back to 256x256
+        bn = 256;
+        p.tiles_n = (N + tile - 1) / tile;
+    }
     // column sums of C ride in the fast epilogue when every tile takes it; otherwise a separate pass over C follows
     const bool colsum_fused = colsum_out != nullptr && mfma_ok && epik >= 0 && splitk == 1 && a_kmajor && M % tile == 0 &&
                               N % tile == 0;
     if (colsum_fused) p.colsum_ws = colsum_ws;
+    const int nblk = p.tiles_m * p.tiles_n * splitk;
     if (use_pp) {
-        hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, nblk, st);
+        hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     } else if (mfma_ok) {
         if (a_kmajor && b_kmajor) launch_mfma<true, true>(p, epik, nblk, st);

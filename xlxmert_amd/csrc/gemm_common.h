@@ -88,20 +88,25 @@ __device__ __forceinline__ bf16x4_t lds_tr_read(const uint8_t* ptr) {
 
 // Operand tile of ROWS x 64(k) bf16 in LDS.
 //   K-major: [row][k], row pitch 128 B, 16-byte chunk c of row r stored at chunk c ^ ((r>>1)&7).
-//   M-major: [k][row], k-row pitch ROWS*2 B, byte b of k-row kr stored at b ^ ((kr&3)<<6).
+//   M-major: [k][row], k-row pitch ROWS*2 B, byte b of k-row kr stored at b ^ swz(kr): a transpose read takes 64 bytes
+//            of each of four consecutive k-rows at once, which must fall into the four quarters of the 256-byte bank
+//            period -- ROWS = 128 (pitch 256 B: every k-row starts a period): (kr&3)<<6; ROWS = 64 (pitch 128 B: k-rows
+//            kr and kr+2 alias): ((kr>>1)&1)<<6.
 template <bool KMAJ, int ROWS>
 struct OpTile {
+    static_assert(ROWS == 128 || ROWS == 64, "operand tile of 64 or 128 rows");
     static constexpr int BYTES = ROWS * BK * 2;
     static constexpr int RP = ROWS * 2;               // M-major k-row pitch (bytes)
+    __device__ static __forceinline__ int swz(int kr) { return ROWS == 128 ? ((kr & 3) << 6) : (((kr >> 1) & 1) << 6); }
 
     // (strided index, contiguous chunk) of the 16 bytes stored at LDS byte offset o of the tile
     __device__ static __forceinline__ void decode(int o, int& rs, int& c) {
         if (KMAJ) { rs = o >> 7; c = ((o >> 4) & 7) ^ ((rs >> 1) & 7); }
-        else { rs = o / RP; c = ((o % RP) ^ ((rs & 3) << 6)) >> 4; }
+        else { rs = o / RP; c = ((o % RP) ^ swz(rs)) >> 4; }
     }
     __device__ static __forceinline__ int encode(int rs, int c) {
         if (KMAJ) return rs * 128 + ((c ^ ((rs >> 1) & 7)) << 4);
-        return rs * RP + ((c << 4) ^ ((rs & 3) << 6));
+        return rs * RP + ((c << 4) ^ swz(rs));
     }
     // MFMA operand fragment: rows [r0, r0+32) (lane -> row l&31), k-slots s*16 + (l>>5)*8 + 0..7
     template <bool TR>
@@ -115,8 +120,8 @@ struct OpTile {
             const int t = lane & 15;
             const int mb = (r0 + ((lane >> 4) & 1) * 16 + (t & 3) * 4) * 2;
             const int k0r = s * 16 + (lane >> 5) * 8 + (t >> 2), k1r = k0r + 4;
-            bf16x4_t lo = lds_tr_read(tile + k0r * RP + (mb ^ ((k0r & 3) << 6)));
-            bf16x4_t hi = lds_tr_read(tile + k1r * RP + (mb ^ ((k1r & 3) << 6)));
+            bf16x4_t lo = lds_tr_read(tile + k0r * RP + (mb ^ swz(k0r)));
+            bf16x4_t hi = lds_tr_read(tile + k1r * RP + (mb ^ swz(k1r)));
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         } else {
             const int m = r0 + (lane & 31);
@@ -124,7 +129,7 @@ struct OpTile {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = s * 16 + (lane >> 5) * 8 + j;
-                f[j] = *reinterpret_cast<const short*>(tile + k * RP + ((m * 2) ^ ((k & 3) << 6)));
+                f[j] = *reinterpret_cast<const short*>(tile + k * RP + ((m * 2) ^ swz(k)));
             }
             return f;
         }
@@ -262,6 +267,51 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, float* wbuf, 
 // BEFORE the LDS transpose and nothing waits on a store: branch-free, one load latency per quad instead of eight.
 struct QuadOperand { uint4 row[8]; };      // residual (RESIDUAL) or saved pre-activation (DGELU): 8 rows x 8 bf16 per lane
 
+// ---- the same pieces for a sub-tile of 64 rows x W columns (W = 64: the quad above; W = 32: the third accumulator column of
+// the 256x192 kernel's 64x96 wave tile): W/8 lanes share a row, 512/W rows per pass, W/8 passes.
+// 64 rows x 32 columns (two accumulators stacked in M) -> wave-private LDS, row pitch 32 floats
+__device__ __forceinline__ void half_to_lds(float* wbuf, int lane, const f32x16_t& a0, const f32x16_t& a1) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f32x16_t& a = i == 0 ? a0 : a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            wbuf[row * 32 + (lane & 31)] = a[r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+template <int W>
+__device__ __forceinline__ void sub_row_from_lds(const float* wbuf, int row, int c8, float (&v)[8]) {
+    const float4 lo = *reinterpret_cast<const float4*>(wbuf + row * W + c8 * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(wbuf + row * W + c8 * 8 + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
+template <int EPI, int W>
+__device__ __forceinline__ void sub_operand_load(const GemmParams& p, int lane, int mq, int nq, QuadOperand& op) {
+    if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU) {
+        constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = 64 / RPP;
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(EPI == XL_EPI_RESIDUAL ? p.residual : p.aux);
+        const int ld = EPI == XL_EPI_RESIDUAL ? p.ldr : p.ldx;
+        const bf16_t* s0 = src + (size_t)(mq + lane / LPR) * ld + nq + (lane % LPR) * 8;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) op.row[ps] = *reinterpret_cast<const uint4*>(s0 + (size_t)(ps * RPP) * ld);
+    }
+}
+template <int W>
+__device__ __forceinline__ void sub_load_bias8(const GemmParams& p, int lane, bool first, int nq, float (&bv)[8]) {
+    const int n = nq + (lane % (W / 8)) * 8;
+    if (first && p.bias != nullptr) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    }
+}
+
 template <int EPI>
 __device__ __forceinline__ void quad_operand_load(const GemmParams& p, int lane, int mq, int nq, QuadOperand& op) {
     if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU) {
@@ -368,6 +418,52 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
     }
 }
 
+// rows of a 64 x W sub-tile already in LDS (sub_to_lds) -> epilogue math -> 16-byte stores (no fused column sums)
+template <int EPI, int W>
+__device__ __forceinline__ void sub_rows_fast(const GemmParams& p, const float* wbuf, int lane, int mq, int nq,
+                                              const QuadOperand& op, const float (&bv)[8]) {
+    constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = 64 / RPP;
+    const int c8 = lane % LPR, rr = lane / LPR;
+    const int n = nq + c8 * 8;
+    const bool drop = p.p_drop > 0.0f;
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+        const int row = ps * RPP + rr;
+        const size_t m = (size_t)(mq + row);
+        float v[8];
+        sub_row_from_lds<W>(wbuf, row, c8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bv[e];
+        if constexpr (EPI == XL_EPI_GELU) {
+            stvec(reinterpret_cast<bf16_t*>(p.aux) + m * p.ldx + n, v);
+            gelu_fast8(v);
+        } else if constexpr (EPI == XL_EPI_RESIDUAL) {
+            float rv[8];
+            unpack8(op.row[ps], rv);
+            if (drop) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(p.seed, (uint32_t)m, (uint32_t)(n + e), p.p_drop, p.inv_keep);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        } else if constexpr (EPI == XL_EPI_DGELU) {
+            float av[8];
+            unpack8(op.row[ps], av);
+            gelu_grad_mul8(v, av);
+        }
+        if (p.out_f32) {
+            float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            uint4 t;
+            t.x = pack2bf(v[0], v[1]); t.y = pack2bf(v[2], v[3]); t.z = pack2bf(v[4], v[5]); t.w = pack2bf(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_quad_fast(const GemmParams& p, float* wbuf, int lane, bool first, int mq, int nq,
                                                    const QuadOperand& op, const f32x16_t& a00, const f32x16_t& a01,
@@ -393,6 +489,7 @@ hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st);
 
 // EPIK: -1 = generic epilogue (runtime kind, ragged edges); XL_EPI_NONE / GELU / RESIDUAL / DGELU = fast epilogue, used by
 // the host for launches whose C / residual / aux rows are 16-byte aligned (interior tiles take it, edge tiles fall back)
-hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int nblk, hipStream_t st);
+// bn: 256 (256x256 tile) or 192 (256x192 tile: N a multiple of 192, every tile interior, fast epilogue, no fused column sums)
+hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int bn, int nblk, hipStream_t st);
 
 }  // namespace xl

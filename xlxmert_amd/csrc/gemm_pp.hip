@@ -21,53 +21,75 @@ __device__ __forceinline__ void hard_barrier() {
 }
 template <int V> using ic = std::integral_constant<int, V>;
 
-template <bool AK, bool BKM, int EPIK>
-__device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int z) {
+// Geometry of the two tile shapes (8 waves each):
+//   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64: A half = 2 row fragments, B in 2 parts of one column fragment
+//   BN = 192: waves 4 (M) x 2 (N), wave tile  64 x 96: A half = 1 row fragment,  B in 3 parts of one column fragment
+// (N = 768 = 3 x 256 = 4 x 192: 64 row tiles give 192 tiles of 256x256 -- a quarter of the 256 CUs idle for the whole launch --
+// or 256 tiles of 256x192; N = 2304 likewise 576 -> 768 = 3 full rounds.)  The A half-tiles are 128 rows x 64 k (16 KiB,
+// 2 DMA pieces per wave) in both; a B part is (waves in N) x 32 columns: 128 rows / 16 KiB / 2 pieces or 64 rows / 8 KiB / 1 piece.
+template <int BN> struct PPGeo;
+template <> struct PPGeo<256> { static constexpr int WR = 2, WC = 4, AF = 2, NB = 2; };
+template <> struct PPGeo<192> { static constexpr int WR = 4, WC = 2, AF = 1, NB = 3; };
+
+template <bool AK, bool BKM, int EPIK, int BN = 256>
+__device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int kbeg, int kend, bool first) {
+    using G = PPGeo<BN>;
+    constexpr int WR = G::WR, WC = G::WC, AF = G::AF, NB = G::NB;
+    constexpr int WTM = 256 / WR, WTN = BN / WC, HR = AF * 32;         // wave tile; rows of a wave in one A half
+    constexpr int BROWS = WC * 32;                                     // columns (tile rows) of one B part
     using TA = OpTile<AK, 128>;
-    using TB = OpTile<BKM, 128>;
-    constexpr int HT = 16384, BUF = 4 * HT;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];            // [2 buffers][A0 | B0 | B1 | A1]
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int kbeg = z * p.kper, kend = min(p.K, kbeg + p.kper);
+    using TB = OpTile<BKM, BROWS>;
+    constexpr int HT = 16384, BPB = TB::BYTES, PB = BPB / 8192;        // bytes of a B part, DMA pieces per wave and part
+    constexpr int BUF = 2 * HT + NB * BPB;                             // [A0 | B parts | A1]
+    constexpr int NA = 2, NBP = NB * PB;                               // DMA instructions per wave: A half, all of B
+    constexpr int WAIT = 2 * NA + NBP;                                 // steady-state vmcnt (see the phase comment)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // [2 buffers][A0 | B parts | A1]
+    const int m0 = tm * 256, n0 = tn * BN;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WC, wc = wave % WC;
+    const int grp = wave >> 2;                     // waves 4-7 run one barrier behind waves 0-3 (one wave of each group per SIMD)
 
-    f32x16_t acc[4][2];
+    f32x16_t acc[2 * AF][NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * AF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // per-lane sources of this wave's two 1 KiB pieces of each half-tile (BYTE offsets, k0 excluded), and the k
+    // per-lane sources of this wave's 1 KiB pieces of each half-tile / part (BYTE offsets, k0 excluded), and the k
     // coordinate of the lane's 16 bytes inside the K tile (ragged last tile: lanes past kend read zeros instead)
-    uint32_t src[4][2];
-    int kk[2][2];
+    uint32_t srca[2][NA], srcb[NB][PB];
+    int kka[NA], kkb[PB];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const int o = (wave * 2 + pt) * 1024 + lane * 16;
+    for (int pt = 0; pt < NA; ++pt) {
+        const int o = (wave * NA + pt) * 1024 + lane * 16;
         int rs, c;
         TA::decode(o, rs, c);
-        kk[0][pt] = AK ? c * 8 : rs;
+        kka[pt] = AK ? c * 8 : rs;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int lr = AK ? rs : c * 8;                                   // local row (first of 8 when M-major)
-            const int gr = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
-            src[h == 0 ? 0 : 3][pt] = 2u * (AK ? (uint32_t)min(gr, p.M - 1) * (uint32_t)p.lda + c * 8
-                                              : (uint32_t)rs * (uint32_t)p.lda + min(gr, p.lda - 8));
+            const int gr = m0 + (lr / HR) * WTM + h * HR + (lr % HR);
+            srca[h][pt] = 2u * (AK ? (uint32_t)min(gr, p.M - 1) * (uint32_t)p.lda + c * 8
+                                   : (uint32_t)rs * (uint32_t)p.lda + min(gr, p.lda - 8));
         }
-        TB::decode(o, rs, c);
-        kk[1][pt] = BKM ? c * 8 : rs;
+    }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+    for (int pt = 0; pt < PB; ++pt) {
+        const int o = (wave * PB + pt) * 1024 + lane * 16;
+        int rs, c;
+        TB::decode(o, rs, c);
+        kkb[pt] = BKM ? c * 8 : rs;
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
             const int lr = BKM ? rs : c * 8;
-            const int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
-            src[1 + h][pt] = 2u * (BKM ? (uint32_t)min(gn, p.N - 1) * (uint32_t)p.ldb + c * 8
-                                       : (uint32_t)rs * (uint32_t)p.ldb + min(gn, p.ldb - 8));
+            const int gn = n0 + (lr >> 5) * WTN + h * 32 + (lr & 31);
+            srcb[h][pt] = 2u * (BKM ? (uint32_t)min(gn, p.N - 1) * (uint32_t)p.ldb + c * 8
+                                    : (uint32_t)rs * (uint32_t)p.ldb + min(gn, p.ldb - 8));
         }
     }
     // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane part of the address is a constant
@@ -82,93 +104,110 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     };
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(A, (uint32_t)(((size_t)((AK ? p.M : p.K) - 1) * p.lda + (AK ? p.K : p.M)) * 2));
     const __amdgpu_buffer_rsrc_t rb = rsrc_of(B, (uint32_t)(((size_t)((BKM ? p.N : p.K) - 1) * p.ldb + (BKM ? p.K : p.N)) * 2));
-    auto stage = [&](auto SUB, int kt) {
-        constexpr int sub = decltype(SUB)::value;
-        constexpr bool isA = (sub == 0 || sub == 3);
+    auto stage_a = [&](auto H, int kt) {
+        constexpr int h = decltype(H)::value;
         const int k0 = kbeg + kt * BK;
         const int krem = kend - k0;
-        uint8_t* dst = smem + (kt & 1) * BUF + sub * HT + wave * 2048;
-        const uint32_t soff = isA ? (uint32_t)(AK ? k0 : k0 * p.lda) * 2u : (uint32_t)(BKM ? k0 : k0 * p.ldb) * 2u;
+        uint8_t* dst = smem + (kt & 1) * BUF + (h == 0 ? 0 : HT + NB * BPB) + wave * (NA * 1024);
+        const uint32_t soff = (uint32_t)(AK ? k0 : k0 * p.lda) * 2u;
         if (krem >= BK) {                                 // whole K tile in range (wave-uniform): no per-lane work at all
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
-                                                         (int)src[sub][pt], (int)soff, 0, 0);
+            for (int pt = 0; pt < NA; ++pt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
+                                                         (int)srca[h][pt], (int)soff, 0, 0);
         } else {
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                uint32_t voff = src[sub][pt];
-                if (kk[isA ? 0 : 1][pt] >= krem) voff = 0x7FFFFFF0u;         // out of range -> zeros
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
+            for (int pt = 0; pt < NA; ++pt) {
+                uint32_t voff = srca[h][pt];
+                if (kka[pt] >= krem) voff = 0x7FFFFFF0u;                      // out of range -> zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(dst + pt * 1024), 16,
                                                          (int)voff, (int)soff, 0, 0);
             }
         }
     };
-    bf16x8_t fa[2][4], fb[2][4];          // A: 2 row fragments x 4 k-steps of the current A half; B: both halves
+    auto stage_b = [&](int kt) {
+        const int k0 = kbeg + kt * BK;
+        const int krem = kend - k0;
+        const uint32_t soff = (uint32_t)(BKM ? k0 : k0 * p.ldb) * 2u;
+        uint8_t* dst0 = smem + (kt & 1) * BUF + HT + wave * (PB * 1024);
+        if (krem >= BK) {
+#pragma unroll
+            for (int h = 0; h < NB; ++h)
+#pragma unroll
+                for (int pt = 0; pt < PB; ++pt)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dst0 + h * BPB + pt * 1024),
+                                                             16, (int)srcb[h][pt], (int)soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < NB; ++h)
+#pragma unroll
+                for (int pt = 0; pt < PB; ++pt) {
+                    uint32_t voff = srcb[h][pt];
+                    if (kkb[pt] >= krem) voff = 0x7FFFFFF0u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dst0 + h * BPB + pt * 1024),
+                                                             16, (int)voff, (int)soff, 0, 0);
+                }
+        }
+    };
+    bf16x8_t fa[AF][4], fb[NB][4];        // A: row fragments x 4 k-steps of the current A half; B: all parts
     auto read_a = [&](const uint8_t* buf, auto H) {
-        const uint8_t* t = buf + (decltype(H)::value == 0 ? 0 : 3 * HT);
+        const uint8_t* t = buf + (decltype(H)::value == 0 ? 0 : HT + NB * BPB);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i][s] = TA::template frag<true>(t, wr * 64 + i * 32, s, lane);
+            for (int i = 0; i < AF; ++i) fa[i][s] = TA::template frag<true>(t, wr * HR + i * 32, s, lane);
     };
-    auto read_b = [&](const uint8_t* buf, auto H) {
-        constexpr int h = decltype(H)::value;
-        const uint8_t* t = buf + (1 + h) * HT;
+    auto read_b = [&](const uint8_t* buf) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fb[h][s] = TB::template frag<true>(t, wc * 32, s, lane);
+        for (int h = 0; h < NB; ++h) {
+            const uint8_t* t = buf + HT + h * BPB;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fb[h][s] = TB::template frag<true>(t, wc * 32, s, lane);
+        }
     };
-    auto mma = [&](auto AH, auto BH) {
-        constexpr int ah = decltype(AH)::value, bh = decltype(BH)::value;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[ah * 2 + i][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(v8bf16_t, fa[i][s]), __builtin_bit_cast(v8bf16_t, fb[bh][s]), acc[ah * 2 + i][bh], 0, 0, 0);
-    };
-    auto mma2 = [&](auto AH) {            // 16 MFMAs over 4 independent accumulators
+    auto mma2 = [&](auto AH) {            // 16 (12) MFMAs over 4 (3) independent accumulators
         constexpr int ah = decltype(AH)::value;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int bh = 0; bh < 2; ++bh)
+            for (int bh = 0; bh < NB; ++bh)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[ah * 2 + i][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(v8bf16_t, fa[i][s]), __builtin_bit_cast(v8bf16_t, fb[bh][s]), acc[ah * 2 + i][bh], 0, 0, 0);
+                for (int i = 0; i < AF; ++i)
+                    acc[ah * AF + i][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(v8bf16_t, fa[i][s]), __builtin_bit_cast(v8bf16_t, fb[bh][s]), acc[ah * AF + i][bh], 0, 0, 0);
     };
-    // Two phases per K tile, 16 MFMAs each: P0 = rows A0 x (B0 | B1), P1 = rows A1 x (B1 | B0).
-    //   P0(t) reads B0, B1, A0 of tile t and issues A1(t+1);  P1(t) reads A1 of tile t and issues A0, B0, B1 of tile t+2.
+    // Two phases per K tile: P0 = rows A0 x all of B, P1 = rows A1 x all of B.
+    //   P0(t) reads B, A0 of tile t and issues A1(t+1);  P1(t) reads A1 of tile t and issues A0, B of tile t+2.
     // Every half-tile is issued two phases before the phase that waits for it (vmcnt) and three before its first read;
     // a slot is rewritten one phase after its last read, which is safe because the fragment reads are retired
-    // (lgkmcnt(0)) BEFORE the barrier that ends the reading section.
+    // (lgkmcnt(0)) BEFORE the barrier that ends the reading section.  After either phase's issue the DMAs that may still
+    // be in flight are one A half and one (A half + B): WAIT = 2 NA + NBP instructions.
 #ifdef XL_PP_PROFILE      // debug build: cycles of the sections of wave 0 / wave 4 of every workgroup (tools/gemm_trace.py --sections)
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};       // L(P0), L(P1), barrier-1 wait, M, barrier-2 wait, phases
 #define XL_T() __builtin_readcyclecounter()
 #else
 #define XL_T() 0ull
 #endif
-    auto phase = [&](auto X, auto WAIT, auto ISSUE, int kt) {
+    auto phase = [&](auto X, auto WAITC, auto ISSUE, int kt) {
         constexpr int x = decltype(X)::value;
         const uint8_t* buf = smem + (kt & 1) * BUF;
         [[maybe_unused]] const unsigned long long t0 = XL_T();
         if constexpr (x == 0) {
-            read_b(buf, ic<0>{}); read_b(buf, ic<1>{});
+            read_b(buf);
             read_a(buf, ic<0>{});
         } else {
             read_a(buf, ic<1>{});
         }
         if constexpr (decltype(ISSUE)::value != 0) {
             if constexpr (x == 0) {
-                stage(ic<3>{}, kt + 1);
+                stage_a(ic<1>{}, kt + 1);
             } else {
-                stage(ic<0>{}, kt + 2); stage(ic<1>{}, kt + 2); stage(ic<2>{}, kt + 2);
+                stage_a(ic<0>{}, kt + 2); stage_b(kt + 2);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         [[maybe_unused]] const unsigned long long t1 = XL_T();
-        wait_vmcnt<decltype(WAIT)::value>();
+        wait_vmcnt<decltype(WAITC)::value>();
         [[maybe_unused]] const unsigned long long t1b = XL_T();
         hard_barrier();
         [[maybe_unused]] const unsigned long long t2 = XL_T();
@@ -191,27 +230,31 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     // the epilogue's bias segment is requested before the first DMA: older than every counted load, so the K loop's vmcnt
     // arithmetic is unchanged, and its latency (a full miss after 15 us of streaming operands) is off the epilogue's front
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] float bias8b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // BN = 192: third column fragment
     if constexpr (EPIK >= 0) {
-        if (n0 + wc * 64 + 64 <= p.N) load_bias8(p, lane, z == 0, n0 + wc * 64, bias8);
+        if (n0 + wc * WTN + WTN <= p.N) {
+            load_bias8(p, lane, first, n0 + wc * WTN, bias8);
+            if constexpr (BN == 192) sub_load_bias8<32>(p, lane, first, n0 + wc * WTN + 64, bias8b);
+        }
     }
     const int nkt = (kend - kbeg + BK - 1) / BK;
-    // prologue: tile 0 complete, plus A0 | B0 | B1 of tile 1; A0, B0, B1 of tile 0 must have landed before P0(0)
-    stage(ic<0>{}, 0); stage(ic<1>{}, 0); stage(ic<2>{}, 0); stage(ic<3>{}, 0);
-    if (nkt >= 2) { stage(ic<0>{}, 1); stage(ic<1>{}, 1); stage(ic<2>{}, 1); wait_vmcnt<8>(); } else { wait_vmcnt<2>(); }
+    // prologue: tile 0 complete, plus A0 | B of tile 1; A0, B of tile 0 must have landed before P0(0)
+    stage_a(ic<0>{}, 0); stage_b(0); stage_a(ic<1>{}, 0);
+    if (nkt >= 2) { stage_a(ic<0>{}, 1); stage_b(1); wait_vmcnt<WAIT>(); } else { wait_vmcnt<NA>(); }
     hard_barrier();
     stamp(1);
-    if (wr == 1) hard_barrier();                  // waves 4-7 run one barrier behind waves 0-3
+    if (grp == 1) hard_barrier();                 // waves 4-7 run one barrier behind waves 0-3
     for (int kt = 0; kt < nkt - 2; ++kt) {
-        phase(ic<0>{}, ic<8>{}, ic<1>{}, kt);
-        phase(ic<1>{}, ic<8>{}, ic<1>{}, kt);
+        phase(ic<0>{}, ic<WAIT>{}, ic<1>{}, kt);
+        phase(ic<1>{}, ic<WAIT>{}, ic<1>{}, kt);
     }
     if (nkt >= 2) {
-        phase(ic<0>{}, ic<8>{}, ic<1>{}, nkt - 2);
-        phase(ic<1>{}, ic<2>{}, ic<0>{}, nkt - 2);
+        phase(ic<0>{}, ic<WAIT>{}, ic<1>{}, nkt - 2);
+        phase(ic<1>{}, ic<NA>{}, ic<0>{}, nkt - 2);
     }
     phase(ic<0>{}, ic<0>{}, ic<0>{}, nkt - 1);
     phase(ic<1>{}, ic<0>{}, ic<0>{}, nkt - 1);
-    if (wr == 0) hard_barrier();
+    if (grp == 0) hard_barrier();
     stamp(2);
 #ifdef XL_PP_PROFILE
     if (p.trace != nullptr && lane == 0 && (wave == 0 || wave == 4)) {
@@ -221,48 +264,69 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
 #endif
     if (p.ablate & 4) return;
     // ---- epilogue (all fragment reads of the staging LDS are behind the last barrier)
-    const bool first = (z == 0);
-    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    const int mw = m0 + wr * WTM, nw = n0 + wc * WTN;
     if (p.atomic_out) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2 * AF; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) epilogue_atomic_frag(p, lane, first, mw + i * 32, nw + j * 32, acc[i][j]);
+            for (int j = 0; j < NB; ++j) epilogue_atomic_frag(p, lane, first, mw + i * 32, nw + j * 32, acc[i][j]);
         return;
     }
     float* wbuf = reinterpret_cast<float*>(smem + wave * 16384);
-    if constexpr (EPIK >= 0) {
-        if (mw + 128 <= p.M && nw + 64 <= p.N) {
-            // the first quad's operand rows are requested before its transpose, the second quad's as soon as the first
-            // quad's accumulators are in LDS (their registers are free from then on)
-            QuadOperand op0, op1;
-            quad_operand_load<EPIK>(p, lane, mw, nw, op0);
-            __builtin_amdgcn_sched_barrier(0);
-            quad_to_lds(wbuf, lane, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            quad_operand_load<EPIK>(p, lane, mw + 64, nw, op1);
-            __builtin_amdgcn_sched_barrier(0);
-            float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8);
-            __builtin_amdgcn_sched_barrier(0);
-            quad_to_lds(wbuf, lane, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1, cs, bias8);
-            if (p.colsum_ws != nullptr) colsum_flush(p, lane, mw >> 7, nw, cs);      // one slab per 128 rows
-            if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
-            return;
+    if constexpr (BN == 192) {
+        // 64 x 96 wave tile = one 64x64 quad + one 64x32 half quad; the host sends only launches here whose tiles are all
+        // interior and take the fast epilogue
+        static_assert(EPIK >= 0, "the 256x192 tile has the fast epilogue only");
+        QuadOperand op0, op1;
+        quad_operand_load<EPIK>(p, lane, mw, nw, op0);
+        __builtin_amdgcn_sched_barrier(0);
+        quad_to_lds(wbuf, lane, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        sub_operand_load<EPIK, 32>(p, lane, mw, nw + 64, op1);
+        __builtin_amdgcn_sched_barrier(0);
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8);
+        __builtin_amdgcn_sched_barrier(0);
+        half_to_lds(wbuf, lane, acc[0][2], acc[1][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        sub_rows_fast<EPIK, 32>(p, wbuf, lane, mw, nw + 64, op1, bias8b);
+        if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+        return;
+    } else {
+        if constexpr (EPIK >= 0) {
+            if (mw + 128 <= p.M && nw + 64 <= p.N) {
+                // the first quad's operand rows are requested before its transpose, the second quad's as soon as the first
+                // quad's accumulators are in LDS (their registers are free from then on)
+                QuadOperand op0, op1;
+                quad_operand_load<EPIK>(p, lane, mw, nw, op0);
+                __builtin_amdgcn_sched_barrier(0);
+                quad_to_lds(wbuf, lane, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                quad_operand_load<EPIK>(p, lane, mw + 64, nw, op1);
+                __builtin_amdgcn_sched_barrier(0);
+                float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8);
+                __builtin_amdgcn_sched_barrier(0);
+                quad_to_lds(wbuf, lane, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1, cs, bias8);
+                if (p.colsum_ws != nullptr) colsum_flush(p, lane, mw >> 7, nw, cs);      // one slab per 128 rows
+                if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+                return;
+            }
         }
+        epilogue_quad(p, wbuf, lane, first, mw, nw, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+        epilogue_quad(p, wbuf, lane, first, mw + 64, nw, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+        if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
     }
-    epilogue_quad(p, wbuf, lane, first, mw, nw, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
-    epilogue_quad(p, wbuf, lane, first, mw + 64, nw, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
-    if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
 }
 
-template <bool AK, bool BKM, int EPIK>
+template <bool AK, bool BKM, int EPIK, int BN>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
     int tm, tn, z;
     tile_coords(p, tm, tn, z);
-    pp_tile<AK, BKM, EPIK>(p, tm, tn, z);
+    const int kbeg = z * p.kper;
+    pp_tile<AK, BKM, EPIK, BN>(p, tm, tn, kbeg, min(p.K, kbeg + p.kper), z == 0);
 }
 
 // Grouped weight gradients: the output tiles of up to 8 problems C_i[M_i,N_i] += A_i^T B_i (M-major operands, fp32
@@ -287,7 +351,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr; p.colsum_ws = nullptr;
     if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
     const int tl = t - g.tile_start[i];
-    pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, z);
+    const int kbeg = z * pr.kper;
+    pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, kbeg, min(pr.K, kbeg + pr.kper), z == 0);
 }
 
 hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st) {
@@ -299,11 +364,11 @@ hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st) {
     return e;
 }
 
-template <bool AK, bool BKM, int EPIK>
+template <bool AK, bool BKM, int EPIK, int BN = 256>
 static hipError_t launch_pp_one(const GemmParams& p, int nblk, hipStream_t st) {
     constexpr int lds = 131072;
     hipError_t e = hipSuccess;
-    auto k = gemm_bf16_pp_kernel<AK, BKM, EPIK>;
+    auto k = gemm_bf16_pp_kernel<AK, BKM, EPIK, BN>;
     static bool attr = false;
     if (!attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     hipLaunchKernelGGL(k, dim3(nblk), dim3(512), lds, st, p);
@@ -311,8 +376,17 @@ static hipError_t launch_pp_one(const GemmParams& p, int nblk, hipStream_t st) {
 }
 
 template <bool AK, bool BKM>
-static hipError_t launch_pp_layout(const GemmParams& p, int epik, int nblk, hipStream_t st) {
+static hipError_t launch_pp_layout(const GemmParams& p, int epik, int bn, int nblk, hipStream_t st) {
     if constexpr (AK) {
+        if (bn == 192) {
+            switch (epik) {
+                case XL_EPI_NONE: return launch_pp_one<AK, BKM, XL_EPI_NONE, 192>(p, nblk, st);
+                case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU, 192>(p, nblk, st);
+                case XL_EPI_RESIDUAL: return launch_pp_one<AK, BKM, XL_EPI_RESIDUAL, 192>(p, nblk, st);
+                case XL_EPI_DGELU: return launch_pp_one<AK, BKM, XL_EPI_DGELU, 192>(p, nblk, st);
+                default: return hipErrorInvalidValue;
+            }
+        }
         switch (epik) {
             case XL_EPI_NONE: return launch_pp_one<AK, BKM, XL_EPI_NONE>(p, nblk, st);
             case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU>(p, nblk, st);
@@ -324,11 +398,12 @@ static hipError_t launch_pp_layout(const GemmParams& p, int epik, int nblk, hipS
     return launch_pp_one<AK, BKM, -1>(p, nblk, st);
 }
 
-hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int nblk, hipStream_t st) {
-    if (a_kmajor && b_kmajor) return launch_pp_layout<true, true>(p, epik, nblk, st);
-    if (a_kmajor && !b_kmajor) return launch_pp_layout<true, false>(p, epik, nblk, st);
-    if (!a_kmajor && b_kmajor) return launch_pp_layout<false, true>(p, epik, nblk, st);
-    return launch_pp_layout<false, false>(p, epik, nblk, st);
+hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int bn, int nblk, hipStream_t st) {
+    if (bn == 192 && !a_kmajor) return hipErrorInvalidValue;
+    if (a_kmajor && b_kmajor) return launch_pp_layout<true, true>(p, epik, bn, nblk, st);
+    if (a_kmajor && !b_kmajor) return launch_pp_layout<true, false>(p, epik, bn, nblk, st);
+    if (!a_kmajor && b_kmajor) return launch_pp_layout<false, true>(p, epik, bn, nblk, st);
+    return launch_pp_layout<false, false>(p, epik, bn, nblk, st);
 }
 
 }  // namespace xl

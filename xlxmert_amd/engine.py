@@ -77,6 +77,7 @@ class SelfAttBlock:
     def fwd(self, x, y):
         e, p, d, M = self.e, self.p, self.e.d, self.M
         ops = e.ops
+        ops.block = self.tag
         ops.gemm(x, p.wqkv, self.qkv, p.bqkv, None, None, M, 3 * d, d, d, d, 3 * d)
         km = e.kmask if self.masked else None
         ops.sdpa_fwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, self.ctx, self.lse, e.B, e.H, self.n, self.n,
@@ -89,6 +90,7 @@ class SelfAttBlock:
     def bwd(self, dy, dx):
         e, p, d, M = self.e, self.p, self.e.d, self.M
         ops = e.ops
+        ops.block = self.tag
         e.wgrad_sync()                  # the previous block's weight-gradient GEMMs still read the shared scratch
         dz = e.tmp("dz", M, d)
         dzm = e.ln_bwd_dense(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo, M, d, self.site + 1)
@@ -128,6 +130,7 @@ class FFNBlock:
     def fwd(self, x, y):
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
         ops = e.ops
+        ops.block = self.tag
         ops.gemm(x, self.w1, self.h, self.b1, None, self.pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU)
         ops.gemm(self.h, self.w2, self.z, self.b2, x, None, M, d, dff, dff, dff, d, ldr=d, epilogue=EPI_RESIDUAL,
                  p_drop=e.p_hid, seed=e.seed(self.site))
@@ -137,6 +140,7 @@ class FFNBlock:
     def bwd(self, dy, dx):
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
         ops = e.ops
+        ops.block = self.tag
         e.wgrad_sync()
         # own scratch names: the two weight gradients registered here are launched together with the attention block's
         # (which runs next on this stream and flushes), so dz / dzm / dpre must outlive that block's scratch use
@@ -176,6 +180,7 @@ class CrossAttBlock:
     def fwd(self, X, Y):
         e, p, d = self.e, self.p, self.e.d
         ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
+        ops.block = self.tag
         qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
         if not self.need_vis:
             ops.gemm(X[:ML], p.wqkv, qkv_l, p.bqkv, None, None, ML, d, d, d, d, 3 * d)                    # Q of language rows
@@ -207,6 +212,7 @@ class CrossAttBlock:
     def bwd(self, dY, dX):
         e, p, d = self.e, self.p, self.e.d
         ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
+        ops.block = self.tag
         e.wgrad_sync()
         if not self.need_vis:
             return self._bwd_lang_only(dY, dX)
@@ -532,6 +538,7 @@ class Engine:
         self._seed = 0
         self._tmp = {}
         self._pending = {"v": [], "l": []}
+        self._pending_block = {"v": "", "l": ""}
         self.act_bytes = 0
         st, d = store, self.d
         # ---- blocks
@@ -706,6 +713,7 @@ class Engine:
     def wgrad_defer(self, dY, X, dW, M, N, K, lda, ldb, ldc):
         """register dW[M,N] += dY[K,M]^T X[K,N]; launched with the block's other weight gradients by wgrad_flush()."""
         self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc))
+        self._pending_block[self._tag] = getattr(self.ops, "block", "")
 
     def wgrad_flush(self):
         """queue the registered weight gradients as ONE grouped launch on the companion stream of the current stream
@@ -715,6 +723,7 @@ class Engine:
         if not probs:
             return
         self._pending[self._tag] = []
+        self.ops.block = self._pending_block[self._tag]
         if self._dw is None or self.side is None:
             return self.ops.gemm_wgrad_group(probs)
         dw = self._dw[self._tag]
@@ -861,6 +870,7 @@ class Engine:
             ops.codebook_gather(self.cid, self.vmask if self.has_vmask else None, st.centroids_c, st.view("mask_feat"),
                                 self.feats, MV, self.F)
         v = "bert.encoder.visn_fc"
+        ops.block = "visn_fc"
         ops.gemm(self.feats, st.cview(v + ".visn_fc.weight"), self.xv, st.view(v + ".visn_fc.bias"), None, None,
                  MV, d, self.F, self.F, self.F, d)
         ops.visn_ln_fwd(self.xv, self.pos, st.view(v + ".box_fc.weight"), st.view(v + ".box_fc.bias"),
@@ -907,6 +917,7 @@ class Engine:
     def head_forward(self, want_logits=True):
         """LxmertVisualObjHead.forward (ref lxrt/modeling.py:38-53): returns (feat, logits)."""
         ops, d, F, K = self.ops, self.d, self.F, self.K
+        ops.block = "head"
         M = self._head_rows()
         hd = self.hd
         vis = self.vis_final
@@ -1175,6 +1186,7 @@ class Engine:
         """consumes dlogits/dfeat from losses_forward_backward; writes d(vision_output) into d_vis.  report=False: another
         head's backward (QA branch) still follows before the head gradients are final."""
         ops, d, MV, F, K = self.ops, self.d, self.MV, self.F, self.K
+        ops.block = "head"
         M = self._head_rows()
         hd = self.hd
         ops.colsum(self.dlogits, hd["bc"][1], M, self.Kp, self.Kp, ws=self.ws)      # pad columns are zero; the bias unit is padded
@@ -1265,6 +1277,7 @@ class Engine:
             self._ready(f"bert.encoder.r_layers.{i}.")
         # ---- visual feature encoder (HF:468-476) + codebook input
         v = "bert.encoder.visn_fc"
+        ops.block = "visn_fc"
         dxv = self.tmp("dctx", MV, d)
         if self.p_hid > 0:
             ops.dropout(GA[ML:], GA[ML:], MV, d, d, d, self.p_hid, self.seed(1))

@@ -30,6 +30,7 @@ class HipOps:
         self.lib = get_lib()
         self.dtype = dtype
         self.dt = xl_dtype(dtype)
+        self.block = ""              # label of the model block issuing the current calls (set by the engine; bench.py's per-block table)
 
     # -- plumbing
     @staticmethod
@@ -50,6 +51,10 @@ class HipOps:
     def set_gemm_pingpong(self, mode):
         """0: 128x128 GEMM kernel only; 1: by shape (default); 2: 256x256 ping-pong kernel whenever eligible."""
         self.lib.call("xl_set_gemm_pingpong", int(mode))
+
+    def set_gemm_tile192(self, mode):
+        """0: 256x256 tiles only; 1: 256x192 where it shortens the launch (default); 2: whenever eligible."""
+        self.lib.call("xl_set_gemm_tile192", int(mode))
 
     def set_deferred_reduce(self, on):
         self.lib.call("xl_set_deferred_reduce", int(on))
