@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="eval-parity mode (the reference trains with p=0.1)")
     ap.add_argument("--single-stream", action="store_true", help="no language/visual stream overlap (profiling)")
     ap.add_argument("--gemm-table", action="store_true", help="print the instrumented step's GEMM time by shape (stderr)")
+    ap.add_argument("--eager", action="store_true", help="enqueue every step from Python instead of replaying the recorded launch plan")
     args = ap.parse_args()
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 during the run (RCCL's
     # version banner at communicator creation, library warnings) is sent to stderr, the JSON goes to the saved descriptor
@@ -193,7 +194,8 @@ def main():
     B = args.batch
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595,
                       total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout,
-                      bucket_mb=float(os.environ.get("XL_BUCKET_MB", "64")))
+                      bucket_mb=float(os.environ.get("XL_BUCKET_MB", "64")),
+                      plan=(world == 1 and not grouped and not args.eager and not args.single_stream))
     if args.single_stream:
         tr.engine.side = None
     g = torch.Generator().manual_seed(9595)
@@ -224,10 +226,21 @@ def main():
     # one extra, instrumented step (not in the timed region).  It runs single-stream so that every GEMM launch is
     # timed alone (in the timed region language-stream kernels overlap visual-stream kernels on a second stream,
     # which lengthens individual kernels while shortening the step).
+    # host time to enqueue ONE step on an empty queue (the timed loop above runs the host into the runtime's queue
+    # back-pressure: its per-step enqueue time says how far ahead of the GPU the host got, not what a step costs it)
+    host_ms = []
+    for i in range(6):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        tr.step(batches[i % 4])
+        host_ms.append((time.perf_counter() - h0) * 1e3)
+    torch.cuda.synchronize()
+    host_ms = sorted(host_ms)[len(host_ms) // 2]
     side, tr.engine.side = tr.engine.side, None
+    planned, tr.plan_mode = tr.plan_mode, False
     with GemmTimer(tr.ops) as gt:
         tr.step(batches[0])
-    tr.engine.side = side
+    tr.engine.side, tr.plan_mode = side, planned
     traffic, traffic_src = None, None
     try:        # HBM bytes per GEMM launch from the committed PMC profile of this build (cannot be collected live)
         tj = json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic.json")))
@@ -254,13 +267,19 @@ def main():
                        "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}",
                        "dropout": "off (eval-parity mode)" if args.no_dropout else "0.1 hidden + 0.1 attention (training mode, 94 sites)",
                        "loss": round(loss_val, 4),
+                       "step_launch": (f"launch plan: one xl_plan_run per step replays the step's recorded C-ABI calls "
+                                       f"({len(tr._plans)} masked-row geometries, {max(p.n_calls for p in tr._plans.values())} calls each)"
+                                       if tr.plan_mode and tr._plans else "eager (every launch enqueued from Python)"),
                        "visual_losses": "obj,feat" if tr.feat_loss else "obj (scripts/pretrain.bash:15)",
                        "inputs": "4 synthetic minibatches per rank resident in HBM before the timed region: no H2D inside it "
                                  "(a batch is ~0.5 MB of int64 ids; SURVEY 8d counts its upload, 0.5 MB over PCIe ~ 10 us)",
                        "vis_mask": "--vis_mask_predict masks, n ~ U{1..64} per image (ref lxmert_data.py:414-419)",
                        "head_rows": "codebook head + both losses on the masked rows only (exact: the reference's losses read "
                                     "nothing else); all rows with XL_COMPACT_HEAD=0"},
-            "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(host_ms, 3),
+            "host_enqueue_note": "median host time of tr.step() on an empty queue (6 steps after the timed region, device "
+                                 "synchronised before each); inside the timed loop the host ran "
+                                 f"{round(t_enqueue / args.steps * 1e3, 2)} ms per step, i.e. up to the runtime's queue back-pressure",
             # whole-step MFMA utilisation from the dense-contraction FLOPs actually EXECUTED in a step (the head runs on the
             # masked rows only, so this is below the contract figure 50.782 GFLOP/example x batch)
             "step_mfma_frac": round(gt.flops / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),

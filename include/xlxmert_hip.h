@@ -47,6 +47,12 @@ const char* xl_last_error(void);
 int  xl_version(void);
 /* 1: GEMM/SDPA transposed operands use ds_read_b64_tr_b16; 0: 16-bit LDS gathers (debug switch) */
 int  xl_set_lds_transpose_read(int enable);
+/* Step part of every dropout seed, in DEVICE memory: with a non-null pointer registered, each dropout site (xl_gemm
+ * XL_EPI_RESIDUAL, xl_layernorm_bwd dx_dropped, xl_sdpa_fwd/bwd, xl_dropout) draws its mask from
+ *     seed argument + 1000003 * *step_seed        (read by the kernel when it runs)
+ * so a captured launch sequence (hipGraph replay of a whole training step) gets fresh masks after one 8-byte update of
+ * *step_seed.  NULL (default): the seed argument alone.  The pointer is sampled when a launch is issued. */
+int  xl_set_step_seed_ptr(const uint64_t* step_seed);
 /* GEMM kernel choice for bf16 operands: 0 = 128x128 kernel only, 1 = by shape (default), 2 = the 256x256 ping-pong
  * kernel whenever the operands allow it (tuning / test switch; env XL_GEMM_PP sets the initial value) */
 int  xl_set_gemm_pingpong(int mode);
@@ -90,6 +96,16 @@ int xl_gemm(const void* A, const void* B, void* C, const float* bias,
 int  xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const* C,
                          const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
                          int count, int dtype, void* stream);
+
+/* Split-K without atomics on the output: a per-stream workspace (caller-owned device memory, 16-byte aligned) for the
+ * ping-pong kernel's partial tiles.  With one registered for `stream`, split-K launches on that stream (xl_gemm weight-
+ * gradient shapes, xl_gemm_wgrad_group) let the splits of an output tile meet in memory -- the last workgroup to arrive
+ * sums the partial tiles and makes ONE read-modify-write pass over C -- instead of one pass of fp32 atomics per split.
+ * xl_gemm_workspace_bytes(slabs): bytes for `slabs` = output tiles x K splits of the largest launch (256 covers every
+ * chip-filling launch; a launch that needs more falls back to atomics).  ws = NULL unregisters.  The workspace must not be
+ * shared by streams that run concurrently; results are identical up to fp32 summation order. */
+int64_t xl_gemm_workspace_bytes(int slabs);
+int  xl_gemm_set_workspace(void* ws, int64_t bytes, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm (eps inside sqrt, HF:188 et al.)
  * y = (x-mean)*rstd*gamma+beta over the last dim N; saves mean,rstd (fp32 [M]).  */
@@ -227,6 +243,11 @@ int xl_featloss_fwd_bwd(const void* pred, const void* centroids, const int64_t* 
  * pred / dpred with one row per entry of `rows`. */
 int xl_gather_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype, void* stream);
 int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype, void* stream);
+/* A row list may be PADDED with negative entries (the caller rounds its length up so that launch sizes do not depend on the
+ * batch: a captured step replays unchanged): xl_gather_rows writes a zero row for them, xl_scatter_rows skips them,
+ * xl_featloss_fwd_bwd gives them no loss and a zero gradient row, and xl_gather_labels hands the cross-entropy the ignore
+ * label:  out[r] = rows[r] >= 0 ? labels[rows[r]] : -100. */
+int xl_gather_labels(const int64_t* labels, const int* rows, int64_t* out, int n_rows, void* stream);
 
 /* ---------------------------------------------------------------- optimizer side (ref lxmert_pretrain.py:343-364)
  * sumsq[0] += sum g^2 over n fp32 elements */
@@ -253,6 +274,28 @@ int xl_adamw(float* p, const float* g, float* m, float* v, void* p_compute,
 int xl_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
 /* dst (fp32) = src (`dtype`) */
 int xl_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- launch plans (csrc/plan.hip)
+ * The host language records one training step as the list of C-ABI calls it made (function + argument words) and replays
+ * it with ONE call per step: same kernels, streams and events as the eager sequence, no interpreter in between.  What a
+ * step varies must live in device memory: inputs (caller's static buffers), the dropout step seed (xl_set_step_seed_ptr),
+ * schedule scalars (xl_schedule_step), row lists padded to a fixed length (xl_gather_labels).
+ *   xl_memset / xl_stream_fork: the two stream operations a step needs besides kernels, as plan-able calls
+ *     (xl_stream_fork = hipEventRecord(event, from) + hipStreamWaitEvent(to, event): `to` continues after everything queued
+ *     on `from` so far; events come from xl_event_create, one per fork site is enough).
+ *   xl_plan_fn_id(name): index of a plan-able entry point (negative: it cannot be part of a plan); xl_plan_fn_nargs.
+ *   xl_plan_create(n_calls, fn_ids, n_args, words): words = the calls' arguments back to back, one 64-bit word each
+ *     (pointers / integers by value, floats as their 32-bit pattern; host arrays, as xl_gemm_wgrad_group takes them, must
+ *     outlive the plan).  Returns a handle (0 on error).  xl_plan_run(handle) replays; xl_plan_destroy frees. */
+int  xl_memset(void* dst, int value, int64_t bytes, void* stream);
+int64_t xl_event_create(void);
+int  xl_event_destroy(int64_t event);
+int  xl_stream_fork(void* event, void* from_stream, void* to_stream);
+int  xl_plan_fn_id(const char* name);
+int  xl_plan_fn_nargs(int fn_id);
+int64_t xl_plan_create(int n_calls, const int* fn_ids, const int* n_args, const uint64_t* words);
+int  xl_plan_run(int64_t plan);
+int  xl_plan_destroy(int64_t plan);
 
 #ifdef __cplusplus
 }

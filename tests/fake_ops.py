@@ -48,6 +48,20 @@ class FakeOps:
     def __init__(self, dtype):
         self.dtype = dtype
         self.calls = []
+        self.step_seed = None
+
+    def zero(self, t):
+        t.zero_()
+
+    def stream_fork(self, from_stream, to_stream):
+        pass
+
+    def set_step_seed_ptr(self, step_seed):
+        """xl_set_step_seed_ptr: the kernels add 1000003 * *step_seed to every dropout seed while the pointer is set"""
+        self.step_seed = step_seed
+
+    def _seed(self, seed):
+        return seed if self.step_seed is None else seed + int(self.step_seed.item()) * 1000003
 
     def set_lds_transpose_read(self, enable):
         pass
@@ -65,7 +79,7 @@ class FakeOps:
             acc = torch.nn.functional.gelu(acc)
         elif epilogue == EPI_RESIDUAL:
             if p_drop > 0:
-                acc = acc * keep_scale(seed, torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop)
+                acc = acc * keep_scale(self._seed(seed), torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop)
             acc = acc + v2(residual, M, N, ldr).float()
         elif epilogue == EPI_DGELU:
             acc = acc * gelu_grad(v2(aux, M, N, ldx).float())
@@ -123,7 +137,7 @@ class FakeOps:
         dgamma.add_(dg)
         dbeta.add_(db)
         if dx_dropped is not None and p_drop > 0:
-            d = d * keep_scale(seed, torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop)                         # the kernel masks the fp32 value, then rounds
+            d = d * keep_scale(self._seed(seed), torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop)                         # the kernel masks the fp32 value, then rounds
             v2(dx_dropped, M, N, N).copy_(d)
         if dbias_prev is not None:
             dbias_prev.add_(d.sum(0))
@@ -179,7 +193,7 @@ class FakeOps:
         torch.as_strided(out, (N,), (1,)).add_(v2(x, M, N, ldx).float().sum(0))
 
     def dropout(self, x, y, M, N, ldx, ldy, p_drop, seed):
-        v2(y, M, N, ldy).copy_(v2(x, M, N, ldx).float() * keep_scale(seed, torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop))
+        v2(y, M, N, ldy).copy_(v2(x, M, N, ldx).float() * keep_scale(self._seed(seed), torch.arange(M)[:, None], torch.arange(N)[None, :], p_drop))
 
     def gelu_bwd(self, dy, pre, dx, n):
         dx.view(-1)[:n].copy_(dy.reshape(-1)[:n].float() * gelu_grad(pre.reshape(-1)[:n].float()))
@@ -237,7 +251,7 @@ class FakeOps:
         if key_mask is not None:
             s = s.masked_fill(key_mask.view(B, 1, 1, nk) == 0, float("-inf"))
         lse.view(B, H, nq).copy_(torch.logsumexp(s, -1))
-        self._heads(o, B, nq, H, dh, ldo).copy_((torch.softmax(s, -1) * self._pmask(B, H, nq, nk, p_drop, seed)) @ V_)
+        self._heads(o, B, nq, H, dh, ldo).copy_((torch.softmax(s, -1) * self._pmask(B, H, nq, nk, p_drop, self._seed(seed))) @ V_)
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
                  lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None):
@@ -247,7 +261,7 @@ class FakeOps:
         p = torch.exp(s - lse.view(B, H, nq, 1))
         if key_mask is not None:
             p = p.masked_fill(key_mask.view(B, 1, 1, nk) == 0, 0.0)
-        msk = self._pmask(B, H, nq, nk, p_drop, seed)
+        msk = self._pmask(B, H, nq, nk, p_drop, self._seed(seed))
         dp = (dO @ V_.transpose(-1, -2)) * msk
         delta = (p * dp).sum(-1, keepdim=True)
         ds = p * (dp - delta) * scale
@@ -292,12 +306,15 @@ class FakeOps:
     def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F, grad_scale=1.0,
                          rows=None, n_rows=0, targets=None):
         g = torch.arange(B * V) if rows is None else rows.view(-1)[:n_rows].long()
+        pad = g < 0                      # padding entries of the row list: no loss, zero gradient row
+        g = g.clamp(min=0)
         M = g.numel()
         p = v2(pred, M, F, F).float()
         t = (centroids[cluster_ids.view(-1)[g]] if targets is None else targets.view(B * V, F)[g]).float()
         d = p - t
         sl1 = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5).mean(1)
         w = ((vis_mask.view(-1) != 0).float() / (nmask.clamp(min=1).repeat_interleave(V) * B))[g]
+        w = torch.where(pad, torch.zeros_like(w), w)
         if loss_out is not None:
             loss_out[0] += (w * sl1).sum()
         if dpred is not None:
@@ -305,11 +322,18 @@ class FakeOps:
 
     def gather_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
         g = rows.view(-1)[:n_rows].long()
-        v2(dst, n_rows, N, ld_dst).copy_(torch.as_strided(src, (int(g.max()) + 1, N), (ld_src, 1))[g])
+        out = torch.as_strided(src, (int(g.max()) + 1, N), (ld_src, 1))[g.clamp(min=0)].clone()
+        out[g < 0] = 0                   # padding entries: zero rows
+        v2(dst, n_rows, N, ld_dst).copy_(out)
 
     def scatter_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
         g = rows.view(-1)[:n_rows].long()
-        torch.as_strided(dst, (int(g.max()) + 1, N), (ld_dst, 1))[g] = v2(src, n_rows, N, ld_src)
+        keep = g >= 0                    # padding entries are skipped
+        torch.as_strided(dst, (int(g.max()) + 1, N), (ld_dst, 1))[g[keep]] = v2(src, n_rows, N, ld_src)[keep]
+
+    def gather_labels(self, labels, rows, out, n_rows):
+        g = rows.view(-1)[:n_rows].long()
+        out.view(-1)[:n_rows].copy_(torch.where(g >= 0, labels.view(-1)[g.clamp(min=0)], torch.full_like(g, -100)))
 
     def sumsq(self, g, out, n):
         out[0] += (g[:n].double() ** 2).sum().float()

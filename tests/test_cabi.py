@@ -48,3 +48,30 @@ def test_product_package_does_not_import_oracle():
                 ls = line.strip()
                 if ls.startswith("import ") or ls.startswith("from "):
                     assert "oracle" not in ls and "fake_ops" not in ls and "transformers" not in ls, (fn, ls)
+
+
+def test_launch_plan_records_and_replays_host_side():
+    """plan machinery without a GPU: calls are recorded with their argument words (pointers, ints, floats, uint64), replayed
+    in order by xl_plan_run, a failing call stops the replay with its own error text, and only plan-able entry points are
+    accepted (csrc/plan.hip)."""
+    from xlxmert_amd._lib import XlError, get_lib
+    lib = get_lib()
+    with lib.record() as calls:
+        lib.call("xl_set_deferred_reduce", 1)
+        lib.call("xl_set_step_seed_ptr", None)
+        lib.call("xl_set_deferred_reduce", 0)
+    assert [c[0] for c in calls] == ["xl_set_deferred_reduce", "xl_set_step_seed_ptr", "xl_set_deferred_reduce"]
+    assert lib.recorder is None
+    plan = lib.make_plan(calls)
+    assert plan.n_calls == 3
+    plan.run()
+    plan.run()
+    # argument marshalling: xl_gemm validates on the host before any launch -- the words must arrive in their slots
+    bad_shape = ("xl_gemm", (16, 16, 16, None, None, None, 0, 4, 4, 4, 4, 4, 0, 0, 1, 1, 1, 1, 0, 1.0, 0, 0.0, 0, None, None, None))
+    with pytest.raises(XlError, match="bad shape M=0 N=4 K=4"):
+        lib.make_plan([calls[0], bad_shape]).run()
+    bad_drop = ("xl_gemm", (16, 16, 16, None, None, None, 8, 4, 4, 4, 4, 4, 0, 0, 1, 1, 1, 1, 0, 1.0, 0, 1.5, 7, None, None, None))
+    with pytest.raises(XlError, match="p_drop 1.5"):
+        lib.make_plan([bad_drop]).run()
+    with pytest.raises(XlError, match="cannot be part of a launch plan"):
+        lib.make_plan([("xl_gemm_trace", (None,))])

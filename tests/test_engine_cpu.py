@@ -11,7 +11,7 @@ from xlxmert_amd.engine import Engine
 from xlxmert_amd.params import ParamStore
 
 
-def make_engine(g, need_lang, dtype=torch.float32):
+def make_engine(g, need_lang, dtype=torch.float32, row_pad=None):
     oc = golden_cfg(g)
     cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
                                                       "intermediate_size", "max_position_embeddings", "type_vocab_size",
@@ -24,6 +24,8 @@ def make_engine(g, need_lang, dtype=torch.float32):
     store = ParamStore(cfg, "cpu", dtype, task="vis_mask" if not need_lang else "all")
     store.load_named(sd)
     eng = Engine(cfg, store, FakeOps(dtype), B, L, V, need_lang=need_lang)
+    if row_pad is not None:
+        eng.ROW_PAD = row_pad
     eng.sync_compute_weights()
     eng.set_inputs(inp["input_ids"], inp["attention_mask"], inp["token_type_ids"], inp["visual_pos"],
                    cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], obj_labels=inp["obj_labels"])
@@ -48,9 +50,17 @@ def test_forward_matches_golden(name):
     assert abs(losses[1].item() - g["feat_loss"].item()) < 2e-5
 
 
-def test_vis_mask_step_gradients():
+@pytest.mark.parametrize("row_pad", [None, 1, 8])
+def test_vis_mask_step_gradients(row_pad):
+    """row_pad: granule of the masked-row head's row list (default 256 = every row at this size; 1 = the exact list;
+    8 = a list padded with -1 entries, which must change nothing)"""
     g = load_golden("tiny_222")
-    eng, oc, sd, inp = make_engine(g, need_lang=False)
+    eng, oc, sd, inp = make_engine(g, need_lang=False, row_pad=row_pad)
+    n_masked = int((inp["vis_mask"].reshape(-1) != 0).sum())
+    if row_pad is not None:
+        assert eng.n_mrows == (n_masked + row_pad - 1) // row_pad * row_pad < eng.MV
+        if row_pad == 8:
+            assert eng.n_mrows > n_masked and (eng.mrows[n_masked:eng.n_mrows] == -1).all()
     losses = eng.vis_mask_forward_backward()
     assert abs(losses[0].item() - g["obj_loss"].item()) < 2e-5
     assert abs(losses[1].item() - g["feat_loss"].item()) < 2e-5

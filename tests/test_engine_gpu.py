@@ -381,8 +381,10 @@ def test_full_size_step_properties_bf16():
     torch.cuda.synchronize()
     unmasked = (batch["obj_labels"].reshape(-1) == -100)
     if eng.compact_head:            # the training step runs the head on the masked rows only: unmasked rows never exist
-        assert eng.n_mrows == int((~unmasked).sum().item())
-        assert torch.equal(eng.mrows[:eng.n_mrows].long().cpu(), (~unmasked).nonzero().reshape(-1).cpu())
+        n = int((~unmasked).sum().item())
+        assert eng.n_mrows == (n + 255) // 256 * 256            # row list padded to the GEMM row tile with -1 entries
+        assert torch.equal(eng.mrows[:n].long().cpu(), (~unmasked).nonzero().reshape(-1).cpu())
+        assert (eng.mrows[n:eng.n_mrows] == -1).all()
     else:
         assert eng.dlogits[unmasked].abs().max().item() == 0.0
     assert torch.isfinite(losses).all() and 5.0 < losses[0].item() < 200.0
@@ -692,6 +694,51 @@ def test_training_reduces_the_loss_full_size_bf16():
     assert first > 8.0, first                        # ~ ln(10000) = 9.2 at initialisation
     assert last < 0.6 * first, (first, last)
     assert torch.isfinite(tr.store.master).all()
+
+
+def test_plan_replay_equals_eager_steps_bf16():
+    """The planned step (PretrainStep(plan=True): one recorded launch plan per masked-row geometry, replayed by one C call;
+    dropout step seed / schedule scalars / inputs in device memory) against the same step enqueued from Python, full
+    architecture, bf16, dropout on: 9 steps over 3 batches, so plans are recorded (steps 1-3), replayed (4-8) and re-used with
+    fresh dropout masks.  Every step starts from the SAME state in both trainers (the eager trainer's parameters and Adam
+    moments are copied over after each step: bf16 training amplifies the fp32-atomic summation order of the weight
+    gradients chaotically over steps, which is not what is under test) and must give the same loss, gradient norm and
+    gradients up to that summation order."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig()
+    B = 64
+    g = torch.Generator().manual_seed(1)
+    mask_feat = torch.randn(cfg.visual_feat_dim, generator=g).relu() * 0.1
+    cent = torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu()
+    batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=50 + i).items()} for i in range(3)]
+    trs = []
+    for plan in (False, True):
+        tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=3, lr=1e-4, total_steps=100,
+                          train_dropout=True, plan=plan)
+        assert tr.plan_mode == plan
+        tr.store.view("mask_feat").copy_(mask_feat)
+        tr.set_centroids(cent)
+        trs.append(tr)
+    te, tp = trs
+    replayed, losses_p = 0, []
+    for t in range(9):
+        n_plans = len(tp._plans)
+        le = te.step(batches[t % 3])[0:1].clone()
+        lp = tp.step(batches[t % 3])[0:1].clone()
+        torch.cuda.synchronize()
+        replayed += int(len(tp._plans) == n_plans and t > 0)
+        losses_p.append(lp.item())
+        assert abs(le.item() - lp.item()) <= 2e-5 * abs(le.item()), (t, le.item(), lp.item())
+        assert abs(te.grad_norm() - tp.grad_norm()) <= 2e-4 * te.grad_norm(), (t, te.grad_norm(), tp.grad_norm())
+        n = te.store.n_used
+        ge, gp = te.store.grad[:n], tp.store.grad[:n]
+        assert (ge - gp).norm().item() <= 1e-3 * ge.norm().item(), (t, (ge - gp).norm().item(), ge.norm().item())
+        for name in ("master", "exp_avg", "exp_avg_sq", "compute"):        # same starting point for the next step
+            getattr(tp.store, name).copy_(getattr(te.store, name))
+    assert replayed >= 5 and len(tp._plans) == 3 and tp.t == 9 and int(tp.step_dev.item()) == 9
+    # replays of one plan draw fresh dropout masks: steps 4 and 7 replay the same plan on the same batch
+    assert losses_p[4] != losses_p[7]
 
 
 # ---------------------------------------------------------------- SURVEY 8f N3: QA branch (task_qa model)

@@ -202,9 +202,65 @@ def test_gemm_fused_column_sums(M, N, dtype, pingpong):
     assert (out - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), (out - ref).abs().max().item()
 
 
+@pytest.fixture(params=[0, 1], ids=["atomics", "slabs"])
+def slab_ws(request):
+    """split-K weight gradients once through fp32 atomics and once through the slab workspace of the current stream"""
+    ops = hip(torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    ops.lib.call("xl_gemm_set_workspace", None, 0, st)
+    ws = None
+    if request.param:
+        nbytes = int(ops.lib.raw("xl_gemm_workspace_bytes")(256))
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+        ops.lib.call("xl_gemm_set_workspace", ws.data_ptr(), nbytes, st)
+    yield request.param
+    torch.cuda.synchronize()
+    ops.lib.call("xl_gemm_set_workspace", None, 0, st)
+
+
+@pytest.mark.parametrize("K", [4096, 1000])
+def test_gemm_wgrad_group_deep_split_exact(K, slab_ws):
+    """two d x d / 3d x d weight gradients (36 interior tiles, K split 7 / 1): every launch of a loop gives the exact integer
+    result ON TOP of the previous one (the tickets return to zero; the last arriver's read-modify-write sees every split)"""
+    g = torch.Generator().manual_seed(K)
+    ops = hip(torch.bfloat16)
+    probs, refs = [], []
+    for m, n in ((768, 768), (2304, 768)):
+        dY = torch.randint(-2, 3, (K, m), generator=g).to(torch.bfloat16)
+        X = torch.randint(-2, 3, (K, n), generator=g).to(torch.bfloat16)
+        refs.append(dY.float().t() @ X.float())
+        probs.append((dY.cuda(), X.cuda(), torch.zeros(m, n, device="cuda"), m, n, K, m, n, n))
+    for rep in range(1, 4):
+        ops.gemm_wgrad_group(probs)
+        torch.cuda.synchronize()
+        for pr, ref in zip(probs, refs):
+            assert torch.equal(pr[2].cpu(), ref * rep), f"rep {rep}: max abs diff {(pr[2].cpu() - ref * rep).abs().max().item()}"
+
+
+def test_gemm_wgrad_single_problem_slabs_exact(slab_ws):
+    """xl_gemm weight-gradient shape (fp32 out, split-K): overwrite and accumulate, exact integers"""
+    g = torch.Generator().manual_seed(77)
+    ops = hip(torch.bfloat16)
+    ops.set_gemm_pingpong(2)
+    try:
+        K, m, n = 8192, 768, 512
+        dY = torch.randint(-2, 3, (K, m), generator=g).to(torch.bfloat16)
+        X = torch.randint(-2, 3, (K, n), generator=g).to(torch.bfloat16)
+        ref = dY.float().t() @ X.float()
+        C = torch.full((m, n), 5.0, device="cuda")
+        ops.gemm(dY.cuda(), X.cuda(), C, None, None, None, m, n, K, m, n, n, a_kmajor=0, b_kmajor=0, out_f32=True)
+        torch.cuda.synchronize()
+        assert torch.equal(C.cpu(), ref)
+        ops.gemm(dY.cuda(), X.cuda(), C, None, None, None, m, n, K, m, n, n, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+        torch.cuda.synchronize()
+        assert torch.equal(C.cpu(), 2 * ref)
+    finally:
+        ops.set_gemm_pingpong(1)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows", [(2048, 2048, 2048), (1536, 640, 1536)])
-def test_gemm_wgrad_group(rows, dtype):
+def test_gemm_wgrad_group(rows, dtype, slab_ws):
     """three weight gradients of different shapes (and contraction lengths) accumulated by one grouped launch"""
     g = torch.Generator().manual_seed(rows[1])
     shapes = [(768, 256), (200, 520), (256, 256)]

@@ -58,14 +58,87 @@ class Lib:
 
     def call(self, name, *args):
         """status-returning entry points: 0 = ok, negative = XL_ERR_* (the error convention of include/xlxmert_hip.h).
-        Value-returning ones (xl_version, xl_workspace_floats, xl_last_error) go through raw()."""
+        Value-returning ones (xl_version, xl_workspace_floats, xl_last_error) go through raw().
+        While a recorder is installed (record()), the call is executed AND appended to it."""
         rc = getattr(self._dll, name)(*args)
         if rc < 0:
             raise XlError(f"{name} failed ({rc}): {self._dll.xl_last_error().decode()}")
+        if self.recorder is not None:
+            self.recorder.append((name, args))
         return rc
 
     def raw(self, name):
         return getattr(self._dll, name)
+
+    # ---- launch plans (csrc/plan.hip): record the C-ABI calls of one step, replay them with one call
+    recorder = None
+
+    def record(self):
+        """context manager: every call() inside is executed and recorded; returns the list of (name, args)."""
+        lib = self
+
+        class _Rec:
+            def __enter__(self):
+                assert lib.recorder is None, "nested recording"
+                lib.recorder = []
+                return lib.recorder
+
+            def __exit__(self, *a):
+                lib.recorder = None
+
+        return _Rec()
+
+    def make_plan(self, calls):
+        """[(name, args)] -> LaunchPlan.  Arguments become 64-bit words: pointers / integers by value, floats as their bit
+        pattern; ctypes arrays (host arrays a call reads at launch) are kept alive by the plan."""
+        return LaunchPlan(self, calls)
+
+
+class LaunchPlan:
+    def __init__(self, lib, calls):
+        import struct
+        self.lib, self.keep = lib, []
+        ids, nargs, words = [], [], []
+        for name, args in calls:
+            fid = lib._dll.xl_plan_fn_id(name.encode())
+            if fid < 0:
+                raise XlError(f"{name} cannot be part of a launch plan: {lib._dll.xl_last_error().decode()}")
+            types = [t for t, _ in lib.protos[name][1]]
+            if len(types) != len(args):
+                raise XlError(f"{name}: {len(args)} arguments recorded, prototype has {len(types)}")
+            for t, a in zip(types, args):
+                if "*" in t:
+                    if a is None:
+                        w = 0
+                    elif isinstance(a, int):
+                        w = a
+                    else:                       # ctypes array (host memory read at launch): keep it alive with the plan
+                        self.keep.append(a)
+                        w = ctypes.addressof(a)
+                elif t.replace("const", "").strip() == "float":
+                    w = struct.unpack("<I", struct.pack("<f", float(a)))[0]
+                else:
+                    w = int(a) & 0xFFFFFFFFFFFFFFFF
+                words.append(w)
+            ids.append(fid)
+            nargs.append(len(args))
+        self.n_calls = len(ids)
+        IA, WA = ctypes.c_int * len(ids), ctypes.c_uint64 * max(1, len(words))
+        self.handle = lib._dll.xl_plan_create(len(ids), IA(*ids), IA(*nargs), WA(*words))
+        if not self.handle:
+            raise XlError(f"xl_plan_create failed: {lib._dll.xl_last_error().decode()}")
+        self._run = lib._dll.xl_plan_run
+
+    def run(self):
+        rc = self._run(self.handle)
+        if rc < 0:
+            raise XlError(f"xl_plan_run failed ({rc}): {self.lib._dll.xl_last_error().decode()}")
+
+    def __del__(self):
+        try:
+            self.lib._dll.xl_plan_destroy(self.handle)
+        except Exception:
+            pass
 
 
 _LIB = None

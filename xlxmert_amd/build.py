@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxlxmert_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "rowops.hip", "sdpa.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

@@ -192,6 +192,14 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t row, uint
     return dropout_draw16(dropout_seed_mix(seed), row, col) >= thr ? inv_keep : 0.0f;
 }
 
+// Step seed in DEVICE memory (xl_set_step_seed_ptr): every dropout site's seed is  site_seed + 1000003 * *step  -- the site part
+// is a launch argument, the step part is read by the kernel, so a captured launch sequence (hipGraph) draws fresh masks on
+// every replay after one 8-byte update.  Null pointer: the site seed alone.
+__device__ __forceinline__ uint64_t with_step_seed(uint64_t site_seed, const uint64_t* __restrict__ step) {
+    return step != nullptr ? site_seed + *step * 1000003ull : site_seed;
+}
+extern const uint64_t* g_step_seed;
+
 extern int g_use_tr_read;   // set by xl_set_lds_transpose_read
 // out[n] += sum_g ws[g*N + n] (second stage of the two-stage column reductions; rowops.hip)
 void launch_colsum_reduce(const float* ws, int G, int N, float* out, hipStream_t st);

@@ -17,6 +17,8 @@
 //       path (XL_F32: parity configuration) and the fallback for operands the MFMA loader cannot
 //       take (leading dimension not a multiple of 8 elements).
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include "gemm_common.h"
 
 namespace xl {
@@ -232,10 +234,41 @@ unsigned long long* g_gemm_trace = nullptr;   // xl_gemm_trace
 int g_gemm_pp = -1;      // 0 / 1 / 2, see xl_set_gemm_pingpong; -1 = read XL_GEMM_PP (default 1)
 int g_gemm_bn192 = -1;   // 0 / 1 / 2, see xl_set_gemm_tile192; -1 = read XL_GEMM_BN192 (default 1)
 
+// split-K slab workspaces, one per stream (xl_gemm_set_workspace): caller-owned memory, [16 KiB of tickets | slabs]
+struct SlabWs { uint8_t* ptr; size_t bytes; };
+static std::mutex g_slab_mu;
+static std::unordered_map<hipStream_t, SlabWs> g_slab_ws;
+// -> true and the pointers when the stream has a workspace for `slabs` partial tiles
+static bool slab_workspace(hipStream_t st, long tiles, long slabs, float** slab, int** tickets) {
+    std::lock_guard<std::mutex> lk(g_slab_mu);
+    auto it = g_slab_ws.find(st);
+    if (it == g_slab_ws.end() || tiles * (long)sizeof(int) > (long)SLAB_TICKET_BYTES ||
+        SLAB_TICKET_BYTES + (size_t)slabs * SLAB_FLOATS * sizeof(float) > it->second.bytes) return false;
+    *tickets = reinterpret_cast<int*>(it->second.ptr);
+    *slab = reinterpret_cast<float*>(it->second.ptr + SLAB_TICKET_BYTES);
+    return true;
+}
+
 }  // namespace xl
 
 
 using namespace xl;
+
+extern "C" int64_t xl_gemm_workspace_bytes(int slabs) {
+    return (int64_t)SLAB_TICKET_BYTES + (int64_t)std::max(slabs, 0) * (int64_t)(SLAB_FLOATS * sizeof(float));
+}
+
+extern "C" int xl_gemm_set_workspace(void* ws, int64_t bytes, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(g_slab_mu);
+    if (ws == nullptr || bytes <= 0) { g_slab_ws.erase(st); return XL_OK; }
+    XL_CHECK_ARG(aligned16(ws) && bytes >= (int64_t)SLAB_TICKET_BYTES, XL_ERR_BAD_ARG,
+                 "xl_gemm_set_workspace: workspace must be 16-byte aligned and hold the 16 KiB ticket block");
+    hipError_t e = hipMemsetAsync(ws, 0, SLAB_TICKET_BYTES, st);          // tickets are zero between launches
+    XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm_set_workspace: memset failed: %s", hipGetErrorString(e));
+    g_slab_ws[st] = SlabWs{reinterpret_cast<uint8_t*>(ws), (size_t)bytes};
+    return XL_OK;
+}
 
 extern "C" int xl_gemm_trace(void* buffer) {
     g_gemm_trace = reinterpret_cast<unsigned long long*>(buffer);
@@ -280,9 +313,10 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux = aux;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldx = ldx;
     p.epilogue = epilogue; p.out_f32 = (out_dtype == XL_F32); p.alpha = alpha;
-    p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.ablate = ablate;
+    p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.step_seed = g_step_seed; p.ablate = ablate;
     p.trace = g_gemm_trace;
     p.colsum_ws = nullptr;
+    p.slab = nullptr; p.tickets = nullptr;
     if (colsum_out != nullptr)
         XL_CHECK_ARG(colsum_ws != nullptr && !accumulate && (long)((M + 63) / 64) * N <= xl_workspace_floats(N), XL_ERR_BAD_ARG,
                      "xl_gemm: colsum_out needs a workspace (xl_workspace_floats), accumulate = 0 and M <= 262144");
@@ -335,6 +369,9 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     splitk = (K + kper - 1) / kper;
     p.splitk = splitk; p.kper = kper;
     p.atomic_out = (accumulate || splitk > 1) ? 1 : 0;
+    // split-K of the ping-pong kernel meets in slabs when the stream has a workspace (xl_gemm_set_workspace): one
+    // read-modify-write pass over C by the last arriver of every tile instead of a pass of fp32 atomics per split
+    if (use_pp && splitk > 1) slab_workspace(st, tiles, (long)tiles * splitk, &p.slab, &p.tickets);
     if (splitk > 1 && !accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: memset failed: %s", hipGetErrorString(e));
@@ -411,12 +448,25 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
     }
     GroupParams g;
     g.count = count; g.splitk = splitk;
+    g.slab = nullptr; g.tickets = nullptr;
+    // slabs + vector read-modify-write of C need one writer per output element: no two problems may share any of C
+    bool disjoint = true;
+    for (int i = 0; i < count && disjoint; ++i)
+        for (int j = i + 1; j < count; ++j) {
+            const char* a0 = reinterpret_cast<const char*>(C[i]);
+            const char* b0 = reinterpret_cast<const char*>(C[j]);
+            const char* a1 = a0 + ((size_t)(M[i] - 1) * ldc[i] + N[i]) * sizeof(float);
+            const char* b1 = b0 + ((size_t)(M[j] - 1) * ldc[j] + N[j]) * sizeof(float);
+            if (a0 < b1 && b0 < a1) { disjoint = false; break; }
+        }
+    if (disjoint) slab_workspace(st, total, total * splitk, &g.slab, &g.tickets);
     int acc = 0;
     for (int i = 0; i < count; ++i) {
         GroupProblem& pr = g.prob[i];
         pr.A = A[i]; pr.B = B[i]; pr.C = C[i]; pr.M = M[i]; pr.N = N[i]; pr.K = K[i];
         pr.lda = lda[i]; pr.ldb = ldb[i]; pr.ldc = ldc[i];
         pr.tiles_m = (M[i] + 255) / 256; pr.tiles_n = (N[i] + 255) / 256;
+        pr.vec = aligned16(C[i]) && ldc[i] % 4 == 0;
         int kper = (K[i] + splitk - 1) / splitk;
         pr.kper = (kper + 63) / 64 * 64;
         g.tile_start[i] = acc;

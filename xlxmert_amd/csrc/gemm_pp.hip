@@ -32,7 +32,8 @@ template <> struct PPGeo<256> { static constexpr int WR = 2, WC = 4, AF = 2, NB 
 template <> struct PPGeo<192> { static constexpr int WR = 4, WC = 2, AF = 1, NB = 3; };
 
 template <bool AK, bool BKM, int EPIK, int BN = 256>
-__device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int kbeg, int kend, bool first) {
+__device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int kbeg, int kend, bool first,
+                                        int slab_tile = -1, int z = 0, int nz = 1) {
     using G = PPGeo<BN>;
     constexpr int WR = G::WR, WC = G::WC, AF = G::AF, NB = G::NB;
     constexpr int WTM = 256 / WR, WTN = BN / WC, HR = AF * 32;         // wave tile; rows of a wave in one A half
@@ -263,9 +264,24 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     }
 #endif
     if (p.ablate & 4) return;
+    // ---- split-K through slabs: only the last arriver of this output tile goes on, with the whole sum in its registers
+    const bool slabbed = slab_tile >= 0 && nz > 1;
+    if (slabbed) {
+        if (!slab_exchange(p, smem, tid, slab_tile, z, nz, acc)) return;
+        first = true;
+    }
     // ---- epilogue (all fragment reads of the staging LDS are behind the last barrier)
     const int mw = m0 + wr * WTM, nw = n0 + wc * WTN;
     if (p.atomic_out) {
+        if constexpr (BN == 256) {
+            // one writer per tile (no split, or the slab path's last arriver), interior tile, aligned rows: vector accumulate
+            if ((slab_tile >= 0) && p.vec_epi && mw + 128 <= p.M && nw + 64 <= p.N) {
+                float* wb = reinterpret_cast<float*>(smem + wave * 16384);
+                epilogue_quad_accum(p, wb, lane, mw, nw, true, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+                epilogue_quad_accum(p, wb, lane, mw + 64, nw, true, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2 * AF; ++i)
 #pragma unroll
@@ -326,7 +342,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
     int tm, tn, z;
     tile_coords(p, tm, tn, z);
     const int kbeg = z * p.kper;
-    pp_tile<AK, BKM, EPIK, BN>(p, tm, tn, kbeg, min(p.K, kbeg + p.kper), z == 0);
+    pp_tile<AK, BKM, EPIK, BN>(p, tm, tn, kbeg, min(p.K, kbeg + p.kper), z == 0,
+                               p.slab != nullptr ? tn * p.tiles_m + tm : -1, z, p.splitk);
 }
 
 // Grouped weight gradients: the output tiles of up to 8 problems C_i[M_i,N_i] += A_i^T B_i (M-major operands, fp32
@@ -347,12 +364,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     p.A = pr.A; p.B = pr.B; p.C = pr.C; p.bias = nullptr; p.residual = nullptr; p.aux = nullptr;
     p.M = pr.M; p.N = pr.N; p.K = pr.K; p.lda = pr.lda; p.ldb = pr.ldb; p.ldc = pr.ldc; p.ldr = 0; p.ldx = 0;
     p.epilogue = XL_EPI_NONE; p.out_f32 = 1; p.atomic_out = 1; p.splitk = g.splitk; p.kper = pr.kper; p.vec_epi = 0;
-    p.alpha = 1.0f; p.p_drop = 0.f; p.inv_keep = 1.f; p.seed = 0;
+    p.alpha = 1.0f; p.p_drop = 0.f; p.inv_keep = 1.f; p.seed = 0; p.step_seed = nullptr;
     p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr; p.colsum_ws = nullptr;
+    p.slab = g.slab; p.tickets = g.tickets; p.vec_epi = pr.vec;
     if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
     const int tl = t - g.tile_start[i];
     const int kbeg = z * pr.kper;
-    pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, kbeg, min(pr.K, kbeg + pr.kper), z == 0);
+    pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, kbeg, min(pr.K, kbeg + pr.kper), z == 0,
+                              g.slab != nullptr ? t : -1, z, (pr.K + pr.kper - 1) / pr.kper);
 }
 
 hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st) {

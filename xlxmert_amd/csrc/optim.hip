@@ -7,6 +7,7 @@ namespace xl {
 
 static thread_local char g_err[512] = "";
 int g_use_tr_read = 1;
+const uint64_t* g_step_seed = nullptr;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -123,6 +124,7 @@ using namespace xl;
 extern "C" const char* xl_last_error(void) { return g_err; }
 extern "C" int xl_version(void) { return 1; }
 extern "C" int xl_set_lds_transpose_read(int enable) { g_use_tr_read = enable ? 1 : 0; return XL_OK; }
+extern "C" int xl_set_step_seed_ptr(const uint64_t* step_seed) { g_step_seed = step_seed; return XL_OK; }
 
 extern "C" int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, int total_steps, float beta1, float beta2,
                                 float* lr_and_steps, void* stream) {

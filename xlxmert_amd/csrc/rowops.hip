@@ -139,8 +139,10 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, T* __restrict__ dx,
                                                      float* dgamma, float* dbeta, float* dbias_prev, int M, int N, float* ws,
-                                                     T* __restrict__ dx_drop, float p_drop, float inv_keep, uint64_t seed) {
+                                                     T* __restrict__ dx_drop, float p_drop, float inv_keep, uint64_t seed,
+                                                     const uint64_t* __restrict__ step_seed) {
     constexpr int VEC = Elem<T>::VEC;
+    seed = with_step_seed(seed, step_seed);
     __shared__ float red[W * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NIT][VEC] = {}, ab[NIT][VEC] = {}, ax[NIT][VEC] = {};
@@ -702,8 +704,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy,
 
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int M, int N, int ldx, int ldy,
-                                                      float p_drop, float inv_keep, uint64_t seed) {
+                                                      float p_drop, float inv_keep, uint64_t seed,
+                                                      const uint64_t* __restrict__ step_seed) {
     constexpr int VEC = Elem<T>::VEC;
+    seed = with_step_seed(seed, step_seed);
     const int cpr = N / VEC;                                   // chunks per row
     const int64_t total = (int64_t)M * cpr;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -944,6 +948,13 @@ __global__ __launch_bounds__(256) void featloss_kernel(const T* __restrict__ pre
     float acc = 0.f;                                             // this wave's share of the loss: ONE atomic per block at the
     for (int row = blockIdx.x * WPB + wave; row < n_rows; row += gridDim.x * WPB) {      // end (8k same-address atomics: 120 us)
         const int gr = rows ? rows[row] : row;                   // (example, grid position) the row of pred / dpred belongs to
+        if (gr < 0) {                                            // padding entry of the row list: no loss, zero gradient
+            if (dpred) {
+                const float z[VEC] = {};
+                for (int col = lane * VEC; col < F; col += 64 * VEC) stvec(dpred + (size_t)row * F + col, z);
+            }
+            continue;
+        }
         const int b = gr / V;
         const float w = mask[gr] ? 1.0f / (fmaxf(nmask[b], 1.0f) * (float)B) : 0.f;
         // regression target: the caller's feat_labels row (ref lxrt/modeling.py:275: label_dict['feat_labels'], the real grid
@@ -1052,9 +1063,21 @@ __global__ __launch_bounds__(256) void move_rows_kernel(const T* __restrict__ sr
     const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (r >= n_rows) return;
     const int g = rows[r];
+    if (g < 0) {                      // padding entry of the row list: a zero row on the way in, nothing on the way out
+        if (!SCATTER)
+            for (int col = lane * VEC; col < N; col += 64 * VEC) *reinterpret_cast<uint4*>(dst + (size_t)r * ldd + col) = make_uint4(0, 0, 0, 0);
+        return;
+    }
     const T* s = src + (size_t)(SCATTER ? r : g) * lds;
     T* d = dst + (size_t)(SCATTER ? g : r) * ldd;
     for (int col = lane * VEC; col < N; col += 64 * VEC) *reinterpret_cast<uint4*>(d + col) = *reinterpret_cast<const uint4*>(s + col);
+}
+
+// out[r] = rows[r] >= 0 ? labels[rows[r]] : -100   (labels of a compacted row list; padding entries are ignored by the loss)
+__global__ __launch_bounds__(256) void gather_labels_kernel(const int64_t* __restrict__ labels, const int* __restrict__ rows,
+                                                            int64_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = rows[i] >= 0 ? labels[rows[i]] : -100;
 }
 
 // Autoregressive sampler step (ref tasks/imggen_model.py:140-153): one position per image takes its prediction and is
@@ -1223,7 +1246,7 @@ extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamm
     DISPATCH_T(dtype, DISPATCH_NIT(T, N,
         hipLaunchKernelGGL((ln_bwd_kernel<T, NIT, LNB_W>), dim3(grid), dim3(LNB_W * 64), 0, st,
                            (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace,
-                           (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed);));
+                           (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed, xl::g_step_seed);));
     XL_CHECK_LAUNCH();
     if (workspace) {
         ReduceOuts o = {};
@@ -1435,7 +1458,7 @@ extern "C" int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy
     if (grid > 4096) grid = 4096;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((dropout_kernel<T>), dim3((int)grid), dim3(256), 0, st, (const T*)x, (T*)y, M, N, ldx, ldy, p_drop,
-                           1.0f / (1.0f - p_drop), seed););
+                           1.0f / (1.0f - p_drop), seed, xl::g_step_seed););
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
@@ -1508,6 +1531,13 @@ extern "C" int xl_gather_rows(const void* src, const int* rows, void* dst, int n
 extern "C" int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int N, int ld_src, int ld_dst, int dtype,
                                void* stream) {
     return move_rows(src, rows, dst, n_rows, N, ld_src, ld_dst, dtype, stream, true);
+}
+
+extern "C" int xl_gather_labels(const int64_t* labels, const int* rows, int64_t* out, int n_rows, void* stream) {
+    XL_CHECK_ARG(labels && rows && out && n_rows > 0, XL_ERR_BAD_ARG, "xl_gather_labels: bad args (n_rows=%d)", n_rows);
+    hipLaunchKernelGGL(gather_labels_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, labels, rows, out, n_rows);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
 }
 
 extern "C" int xl_sampler_ar_update(const float* prob, const int* pred_ids, void* visited, void* vis_mask, int64_t* code_ids,

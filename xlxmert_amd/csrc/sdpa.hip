@@ -22,7 +22,9 @@ __global__ __launch_bounds__(64) void sdpa_fwd_generic(const T* __restrict__ q, 
                                                        const uint8_t* __restrict__ key_mask, T* __restrict__ o,
                                                        float* __restrict__ lse, int H, int nq, int nk, int dh,
                                                        int ldq, int ldk, int ldv, int ldo, float scale,
-                                                       float p_drop, float inv_keep, uint64_t seed) {
+                                                       float p_drop, float inv_keep, uint64_t seed,
+                                                       const uint64_t* __restrict__ step_seed) {
+    seed = with_step_seed(seed, step_seed);
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int qi = threadIdx.x;
     if (qi >= nq) return;
@@ -60,7 +62,9 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
                                                        const float* __restrict__ lse, T* __restrict__ dq, T* __restrict__ dk,
                                                        T* __restrict__ dv, int H, int nq, int nk, int dh,
                                                        int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                                                       float scale, float p_drop, float inv_keep, uint64_t seed) {
+                                                       float scale, float p_drop, float inv_keep, uint64_t seed,
+                                                       const uint64_t* __restrict__ step_seed) {
+    seed = with_step_seed(seed, step_seed);
     __shared__ float sdk[MAXN * MAXN];
     __shared__ float sdv[MAXN * MAXN];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -217,7 +221,9 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     bf16_t* __restrict__ o, float* __restrict__ lse, int H, int nq, int nk,
                                                     int ldq, int ldk, int ldv, int ldo, float scale,
-                                                    float p_drop, float inv_keep, uint64_t seed) {
+                                                    float p_drop, float inv_keep, uint64_t seed,
+                                                    const uint64_t* __restrict__ step_seed) {
+    if (DROP) seed = with_step_seed(seed, step_seed);
     // one wave per 32-query fragment (NQF waves share the staged V tile of the (batch, head) problem)
     __shared__ __attribute__((aligned(16))) uint8_t vt[NKF * 32 * Tile<DH>::PITCH];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -289,7 +295,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
                                                     bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                     int H, int nq, int nk, int ldq, int ldk, int ldv, int ldo,
                                                     int lddq, int lddk, int lddv, float scale,
-                                                    float p_drop, float inv_keep, uint64_t seed, float* __restrict__ cs_ws) {
+                                                    float p_drop, float inv_keep, uint64_t seed, float* __restrict__ cs_ws,
+                                                    const uint64_t* __restrict__ step_seed) {
+    if (DROP) seed = with_step_seed(seed, step_seed);
     __shared__ __attribute__((aligned(16))) uint8_t tk[NKF * 32 * Tile<DH>::PITCH];     // K   [key][d]
     __shared__ __attribute__((aligned(16))) uint8_t tq[NQF * 32 * Tile<DH>::PITCH];     // Q   [q][d]
     __shared__ __attribute__((aligned(16))) uint8_t tdo[NQF * 32 * Tile<DH>::PITCH];    // dO  [q][d]
@@ -472,7 +480,7 @@ template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_fwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(NQF * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk,
-                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed);
+                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed, g_step_seed);
 }
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
@@ -480,7 +488,7 @@ static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP, NW>), dim3(a.B * a.H), dim3(NW * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq,
                        (bf16_t*)a.dk, (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv,
-                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws);
+                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws, g_step_seed);
 }
 template <int DH, int NQF, int NKF>
 static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
@@ -550,11 +558,11 @@ extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const ui
     } else if (dtype == XL_BF16) {
         hipLaunchKernelGGL((sdpa_fwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, key_mask, (bf16_t*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
-                           a.inv_keep, seed);
+                           a.inv_keep, seed, g_step_seed);
     } else {
         hipLaunchKernelGGL((sdpa_fwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, key_mask, (float*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
-                           a.inv_keep, seed);
+                           a.inv_keep, seed, g_step_seed);
     }
     XL_CHECK_LAUNCH();
     return XL_OK;
@@ -592,11 +600,11 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
     } else if (dtype == XL_BF16) {
         hipLaunchKernelGGL((sdpa_bwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, key_mask, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, H, nq,
-                           nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed);
+                           nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, g_step_seed);
     } else {
         hipLaunchKernelGGL((sdpa_bwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, key_mask, (const float*)dout, lse, (float*)dq, (float*)dk, (float*)dv, H, nq, nk,
-                           dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed);
+                           dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, g_step_seed);
     }
     XL_CHECK_LAUNCH();
     if (bias_grad != nullptr) {          // no fused partials on this path: column sums of the stored gradients

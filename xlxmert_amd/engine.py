@@ -15,6 +15,7 @@ Layout decisions (MI355X-first):
     (vis_mask task) -- its parameters sit outside the optimizer range.
 """
 import math
+import os
 
 import torch
 
@@ -310,7 +311,7 @@ class AnswerHead:
 
     def loss_fwd_bwd(self, want_grad=True):
         B, A = self.e.B, self.A
-        self.loss.zero_()
+        self.e.ops.zero(self.loss)
         self.e.ops.bce_logits_fwd_bwd(self.logit, self.targets, self.dlogit if want_grad else None, self.loss, B, A, A, A, self.Ap)
         return self.loss
 
@@ -319,10 +320,10 @@ class AnswerHead:
         d(logit); also records qa_pred = argmax (ref :300)."""
         B, A = self.e.B, self.A
         ops = self.e.ops
-        self.loss.zero_()
+        ops.zero(self.loss)
         ops.mask_counts(self.labels, self._ones, self.counts, self._nm, B, 1)          # counts[0] = #labels != -100
         if want_grad and self.Ap > A:
-            self.dlogit.zero_()                                                        # pad columns
+            ops.zero(self.dlogit)                                                      # pad columns
         ops.ce_fwd_bwd(self.logit, self.labels, self.counts, self.dlogit if want_grad else None, self.loss, self.row_lse,
                        self.row_argmax, self.row_maxprob, B, A, A, self.Ap, 1.0)
         return self.loss
@@ -382,7 +383,6 @@ class LangHeads:
             # masked-row mode (training step, row list from the data loader): the 30522-way decoder, its loss and their
             # backward run on the labelled rows only - exact, the loss reads nothing else (same idea as Engine._hrows)
             self.rows = torch.zeros(ML, dtype=torch.int32, device=eng.dev)
-            self.rows_long = torch.zeros(ML, dtype=torch.int64, device=eng.dev)
             self.labels_c = torch.zeros(ML, dtype=torch.int64, device=eng.dev)
             self.n_rows = 0
         if self.has_rel:
@@ -403,9 +403,8 @@ class LangHeads:
         self.n_rows = 0
         if word_rows is not None and 0 < len(word_rows) < self.e.ML:
             idx = torch.as_tensor(word_rows, dtype=torch.int64)
-            self.n_rows = int(idx.numel())
-            self.rows_long[:self.n_rows].copy_(idx, non_blocking=True)
-            self.rows[:self.n_rows].copy_(idx, non_blocking=True)
+            n = int(idx.numel())
+            self.n_rows = self.e.pad_rows(self.rows, idx, n, self.e.ML)
 
     def mlm_fwd(self, lang):
         e, d = self.e, self.e.d
@@ -433,12 +432,12 @@ class LangHeads:
         e, Vn, Vp = self.e, self.Vn, self.Vp
         ops = e.ops
         M = self.n_rows if self.n_rows else e.ML
-        self.loss[0:1].zero_()
+        ops.zero(self.loss[0:1])
         ops.mask_counts(self.word_labels, e.kmask, self.counts, self.dummy, e.B, e.L)
         labels = self.word_labels
         if self.n_rows:
             labels = self.labels_c[:M]
-            torch.index_select(self.word_labels.view(-1), 0, self.rows_long[:M], out=labels)
+            ops.gather_labels(self.word_labels, self.rows, labels, M)
         ops.ce_fwd_bwd(self.scores, labels, self.counts, self.dscores, self.loss[0:], None, None, None,
                        M, Vn, Vp, Vp, 1.0)
         return self.loss
@@ -479,7 +478,7 @@ class LangHeads:
 
     def rel_loss(self):
         e, B = self.e, self.e.B
-        self.loss[1:2].zero_()
+        e.ops.zero(self.loss[1:2])
         self.rel_counts.fill_(float(B))                                 # every example carries a matched label
         e.ops.ce_fwd_bwd(self.rel, self.matched_labels, self.rel_counts, self.drel, self.loss[1:], None, None, None, B, 2, 8, 8, 1.0)
         return self.loss
@@ -536,6 +535,7 @@ class Engine:
         self._lane_lo = None
         self._n_sites = 2               # sites 0 / 1: embedding and visual-feature-encoder output dropout
         self._seed = 0
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)       # step part of the dropout seeds
         self._tmp = {}
         self._pending = {"v": [], "l": []}
         self._pending_block = {"v": "", "l": ""}
@@ -589,7 +589,6 @@ class Engine:
         self.labels = torch.full((B, V), -100, dtype=torch.int64, device=self.dev)
         self._hrows, self._hvis = None, None
         self.feat_tgt, self._feat_tgt_buf = None, None
-        import os
         self.compact_head = os.environ.get("XL_COMPACT_HEAD", "1") != "0"   # training step: codebook head on the masked rows only
         self.task = getattr(store, "task", "vis_mask")
         # answer head on pooled_output: the VQA/GQA fine-tune model, or a pretraining model built with task_qa (then its CE
@@ -619,7 +618,6 @@ class Engine:
         self.row_lse, self.row_maxprob = self.f32(self.MV), self.f32(self.MV)
         self.row_argmax = torch.zeros(self.MV, dtype=torch.int32, device=self.dev)
         self.mrows = torch.zeros(self.MV, dtype=torch.int32, device=self.dev)         # ids b*V+v of the masked positions
-        self._hrows_long = torch.zeros(self.MV, dtype=torch.int64, device=self.dev)
         self.labels_c = torch.zeros(self.MV, dtype=torch.int64, device=self.dev)
         self.n_mrows = 0
         self.mf_tmp = self.f32(d)
@@ -640,9 +638,19 @@ class Engine:
         # Weight-gradient GEMMs (dW = dY^T X) are off the dX dependency chain: each stream gets a companion stream for
         # them, so they co-run with the chain's next kernels (and their epilogue bursts interleave).
         self.side, self._dw = None, None
+        self._dw_busy = {"v": False, "l": False}
         if two_streams and self.dev.type == "cuda":
             self.side, dwv, dwl = reserve_streams(self.dev)
             self._dw = {"v": dwv, "l": dwl}
+        # split-K slab workspaces of the streams that launch weight gradients (ops.gemm_workspace): no fp32 atomics on the
+        # gradient buffer and a fixed summation order (deterministic weight gradients).  Opt-in (XL_GEMM_SLABS=1): measured 1-3 % slower
+        # than the atomics -- L2 atomics are fire-and-forget, the slabs add a write + read of every partial tile.
+        self._slab_ws = []
+        if self.dev.type == "cuda" and hasattr(ops, "gemm_workspace") and os.environ.get("XL_GEMM_SLABS", "0") != "0":
+            streams = list(self._dw.values()) if self._dw is not None else []
+            streams += [torch.cuda.current_stream()] + ([self.side] if self.side is not None else [])
+            for s_ in streams:
+                self._slab_ws.append(ops.gemm_workspace(256, s_))
 
     # ------------------------------------------------------------ memory helpers
     def act(self, *shape):
@@ -703,12 +711,12 @@ class Engine:
     def fork(self):
         """language stream waits for everything queued so far on the main (visual) stream."""
         if self.side is not None:
-            self.side.wait_event(torch.cuda.current_stream().record_event())
+            self.ops.stream_fork(torch.cuda.current_stream(), self.side)
 
     def join(self):
         """main stream waits for everything queued so far on the language stream."""
         if self.side is not None:
-            torch.cuda.current_stream().wait_event(self.side.record_event())
+            self.ops.stream_fork(self.side, torch.cuda.current_stream())
 
     def wgrad_defer(self, dY, X, dW, M, N, K, lda, ldb, ldc):
         """register dW[M,N] += dY[K,M]^T X[K,N]; launched with the block's other weight gradients by wgrad_flush()."""
@@ -724,17 +732,20 @@ class Engine:
             return
         self._pending[self._tag] = []
         self.ops.block = self._pending_block[self._tag]
-        if self._dw is None or self.side is None:
+        dw = self._dw.get(self._tag) if (self._dw is not None and self.side is not None) else None
+        if dw is None:
             return self.ops.gemm_wgrad_group(probs)
-        dw = self._dw[self._tag]
-        dw.wait_event(torch.cuda.current_stream().record_event())
+        self.ops.stream_fork(torch.cuda.current_stream(), dw)
         with torch.cuda.stream(dw):
             self.ops.gemm_wgrad_group(probs)
+        self._dw_busy[self._tag] = True
 
     def wgrad_sync(self):
-        """current stream waits for the weight-gradient GEMMs queued so far by this stream."""
-        if self._dw is not None and self.side is not None:
-            torch.cuda.current_stream().wait_event(self._dw[self._tag].record_event())
+        """current stream waits for the weight-gradient GEMMs queued so far by this stream (nothing to wait for when none
+        was queued since the last wait: an event of a stream that has not joined a stream capture must not be waited on)."""
+        if self._dw_busy[self._tag]:
+            self.ops.stream_fork(self._dw[self._tag], torch.cuda.current_stream())
+            self._dw_busy[self._tag] = False
 
     def tmp(self, name, M, N):
         """backward scratch, shared by all blocks of one stream (sized for the largest user)."""
@@ -743,16 +754,47 @@ class Engine:
             self._tmp[key] = torch.zeros(self.MX, N, dtype=self.cdtype, device=self.dev)
         return self._tmp[key][:M]
 
+    ROW_PAD = 256
+
+    def pad_rows(self, buf, idx, n, cap):
+        """row list of a masked-row head -> device buffer `buf` (int32), its length rounded up to ROW_PAD (the GEMM row tile)
+        with -1 entries: the kernels treat those as zero rows / skip them (include/xlxmert_hip.h xl_gather_labels), so the
+        launch sizes of a step take few distinct values and a captured step (hipGraph) can be replayed.  Returns the padded
+        length (0 for an empty list; `cap` = all rows when the padding would reach it)."""
+        if n == 0:
+            return 0
+        npad = min(cap, (n + self.ROW_PAD - 1) // self.ROW_PAD * self.ROW_PAD)
+        buf[:n].copy_(idx, non_blocking=True)
+        if npad > n:
+            buf[n:npad].fill_(-1)
+        return npad
+
     def new_site(self, n):
         s = self._n_sites
         self._n_sites += n
         return s
 
+    # Dropout seeds: mask(site, row, col) = hash(site_seed + 1000003 * step_seed, row, col).  The site part is a launch
+    # argument; the step part lives in DEVICE memory (self.seed_dev) and is read by the kernels, so a captured step (hipGraph)
+    # draws fresh masks on every replay.  The library samples the pointer when a launch is issued: it is set for the duration
+    # of this engine's forward / backward only (direct users of the ops keep plain seeds).
     def seed(self, site):
-        return (self._seed * 1000003 + site * 7919 + 12345) & 0x7FFFFFFFFFFFFFFF
+        return site * 7919 + 12345
 
     def set_step_seed(self, seed):
-        self._seed = int(seed)
+        """step part of the dropout seeds (the trainer passes step * world + rank); a tiny fill on the current stream."""
+        self._seed = int(seed) & 0x7FFFFFFFFFFF
+        self.seed_dev.fill_(self._seed)
+
+    class _Seeded:
+        def __init__(self, eng):
+            self.e = eng
+
+        def __enter__(self):
+            self.e.ops.set_step_seed_ptr(self.e.seed_dev)
+
+        def __exit__(self, *a):
+            self.e.ops.set_step_seed_ptr(None)
 
     def ln_bwd_dense(self, dy, z, g, mean, rstd, dz, gg, gb, gbias, M, N, site, tmp_name="dzm"):
         """LayerNorm backward of a `LN(dropout(dense(.)) + residual)` block: returns the gradient entering the dense layer
@@ -830,10 +872,7 @@ class Engine:
                 if self.compact_head and self.task in ("vis_mask", "all"):
                     # the only host <-> device round trip of a step: how many positions are masked (sizes the head's launches)
                     idx = masked_rows.reshape(-1) if masked_rows is not None else (vis_mask.reshape(-1) != 0).nonzero().reshape(-1)
-                    self.n_mrows = int(idx.numel())
-                    if self.n_mrows:
-                        self._hrows_long[:self.n_mrows].copy_(idx, non_blocking=True)
-                        self.mrows[:self.n_mrows].copy_(idx, non_blocking=True)
+                    self.n_mrows = self.pad_rows(self.mrows, idx, int(idx.numel()), self.MV)
         else:
             self.feats.copy_(visual_feats.reshape(self.MV, self.F), non_blocking=True)
         if obj_labels is not None:
@@ -847,6 +886,10 @@ class Engine:
 
     # ------------------------------------------------------------ forward
     def encoder_forward(self, want_pooled=True):
+        with Engine._Seeded(self):
+            return self._encoder_forward(want_pooled)
+
+    def _encoder_forward(self, want_pooled=True):
         cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
         ML, MV = self.ML, self.MV
         X0 = self.X[0]
@@ -937,14 +980,14 @@ class Engine:
         [obj_loss, feat_loss] (device, fp32)."""
         ops, F, K = self.ops, self.F, self.K
         M = self._head_rows()
-        self.losses.zero_()
+        ops.zero(self.losses)
         ops.mask_counts(self.labels, self.vmask, self.counts, self.nmask, self.B, self.V)
         labels = self.labels
         rows = None
         if self._hrows is not None:
             rows = self._hrows[0]
             labels = self.labels_c[:M]
-            torch.index_select(self.labels.view(-1), 0, self._hrows_long[:M], out=labels)
+            ops.gather_labels(self.labels, rows, labels, M)
         ops.ce_fwd_bwd(self.logits, labels, self.counts, self.dlogits if want_grad else None, self.losses[0:],
                        None, None, None, M, K, K, self.Kp, 1.0)
         self.with_feat_loss = feat_loss
@@ -1043,14 +1086,14 @@ class Engine:
             finally:
                 self._hrows = None
             if self.need_lang:          # the language side of the last cross layer exists: zero gradient ...
-                GA[:self.ML].zero_()
+                self.ops.zero(GA[:self.ML])
             if qa:                      # ... unless the QA branch reads pooled_output
                 cls_rows, d_cls = self._cls_views(GA)
                 ans.bwd(self.pooled, cls_rows, d_cls)
                 self._ready_heads()
             self.encoder_backward(self.need_lang)
             return
-        GA.zero_()
+        self.ops.zero(GA)
         cls_rows, d_cls = self._cls_views(GA)
         if task == "word_mask":
             lh.mlm_bwd(GA[:self.ML])
@@ -1070,7 +1113,7 @@ class Engine:
     def _task_step(self, task, **kw):
         out = self.task_forward(task, **kw)
         st = self.store
-        st.grad[st.n_mat:st.n_used].zero_()
+        self.ops.zero(st.grad[st.n_mat:st.n_used])
         self.task_backward()
         return out
 
@@ -1102,7 +1145,7 @@ class Engine:
         self.zero_accumulated_grads()
         loss = ans.loss_fwd_bwd(True)
         GA = self.GA
-        GA.zero_()                                   # only the [CLS] rows of the language output carry gradient
+        self.ops.zero(GA)                            # only the [CLS] rows of the language output carry gradient
         cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
         ans.bwd(self.pooled, cls_rows, GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
         self._ready_heads()
@@ -1173,7 +1216,7 @@ class Engine:
     def zero_accumulated_grads(self):
         """start of a training step's backward: clear the gradient buffer, defer the column reductions' second stages."""
         st = self.store
-        st.grad[st.n_mat:st.n_used].zero_()
+        self.ops.zero(st.grad[st.n_mat:st.n_used])
         self.begin_backward()
 
     def begin_backward(self):
@@ -1200,7 +1243,7 @@ class Engine:
         # weight gradients contract over the rows: round a compacted row count up to the K tile with zero gradient rows
         Mk = min(MV, (M + 63) // 64 * 64)
         if Mk > M:
-            dfeat[M:Mk].zero_()
+            ops.zero(dfeat[M:Mk])
         self.wgrad_defer(dfeat, self.t_y, hd["wf"][1], F, d, Mk, F, d, d)
         dty = self.tmp("dz", MV, d)
         ops.gemm(dfeat, hd["wf"][0], dty, None, None, None, M, d, F, F, d, d, a_kmajor=1, b_kmajor=0)
@@ -1210,7 +1253,7 @@ class Engine:
         ops.gelu_bwd(dth, self.t_pre, dtp, M * d)
         ops.colsum(dtp, hd["bt"][1], M, d, d, ws=self.ws)
         if Mk > M:
-            dtp[M:Mk].zero_()
+            ops.zero(dtp[M:Mk])
         hv = self._hvis if self._hrows is None else self.tmp("vis_c", MV, d)
         self.wgrad_defer(dtp, hv, hd["wt"][1], d, d, Mk, d, d, d)
         self.wgrad_flush()
@@ -1219,13 +1262,17 @@ class Engine:
         else:                       # gradient of the masked rows, scattered into an otherwise zero d(vision_output)
             dvc = self.tmp("dvis_c", MV, d)
             ops.gemm(dtp, hd["wt"][0], dvc, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
-            d_vis.zero_()
+            ops.zero(d_vis)
             ops.scatter_rows(dvc, self._hrows[0], d_vis, M, d, d, d)
         if report:
             self._ready_heads()
 
     def encoder_backward(self, have_lang_grad=False):
         """d(outputs) are expected in GA ([lang ; vis] rows; the language rows are ignored unless have_lang_grad)."""
+        with Engine._Seeded(self):
+            self._encoder_backward(have_lang_grad)
+
+    def _encoder_backward(self, have_lang_grad=False):
         cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
         ML, MV = self.ML, self.MV
         GA, GB = self.GA, self.GB
@@ -1291,7 +1338,7 @@ class Engine:
                  a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
         if self.use_codebook and self.has_vmask:
             # d(mask_feat) = (sum over masked rows of d(xv)) W_visn   (ref lxrt/modeling.py:190-193: mask_feat is a Parameter)
-            self.mf_tmp.zero_()
+            ops.zero(self.mf_tmp)
             ops.masked_colsum(dxv, self.vmask, self.mf_tmp, MV, d, d, ws=self.ws)
             self.flush_reductions()              # consumed right away
             ops.cast_from_f32(self.mf_tmp, self.mf_tmp_c, d)

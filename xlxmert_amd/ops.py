@@ -13,6 +13,7 @@ XL_F32, XL_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH = 0, 1, 2, 3, 4
 
 TORCH_DTYPE = {XL_F32: torch.float32, XL_BF16: torch.bfloat16}
+_SLAB_WS = {}
 
 
 def xl_dtype(torch_dtype):
@@ -56,6 +57,32 @@ class HipOps:
         """0: 256x256 tiles only; 1: 256x192 where it shortens the launch (default); 2: whenever eligible."""
         self.lib.call("xl_set_gemm_tile192", int(mode))
 
+    # -- stream plumbing of a step as C-ABI calls (so that a recorded launch plan contains them: _lib.LaunchPlan)
+    def zero(self, t):
+        """t.zero_() on the current stream (t contiguous)."""
+        assert t.is_contiguous()
+        self.lib.call("xl_memset", self._p(t), 0, t.numel() * t.element_size(), self._stream())
+
+    _events, _ev_next = [], 0
+
+    def stream_fork(self, from_stream, to_stream):
+        """`to_stream` continues after everything queued on `from_stream` so far (event record + stream wait).  Events come
+        from a process-wide ring: a wait refers to the record that precedes it at enqueue time, so re-recording is safe."""
+        cls = HipOps
+        if len(cls._events) < 512:
+            ev = int(self.lib.raw("xl_event_create")())
+            if not ev:
+                raise XlError("xl_event_create failed")
+            cls._events.append(ev)
+        else:
+            ev = cls._events[cls._ev_next % 512]
+        cls._ev_next += 1
+        self.lib.call("xl_stream_fork", ev, from_stream.cuda_stream, to_stream.cuda_stream)
+
+    def set_step_seed_ptr(self, step_seed):
+        """device tensor (one int64 >= 0) holding the step part of every dropout seed, or None (xl_set_step_seed_ptr)."""
+        self.lib.call("xl_set_step_seed_ptr", self._p(step_seed))
+
     def set_deferred_reduce(self, on):
         self.lib.call("xl_set_deferred_reduce", int(on))
 
@@ -80,6 +107,19 @@ class HipOps:
         ptrs = [vp(*[self._p(t) for t in cols[j]]) for j in range(3)]
         ints = [ia(*[int(v) for v in cols[j]]) for j in range(3, 9)]
         self.lib.call("xl_gemm_wgrad_group", *ptrs, *ints, n, self.dt, self._stream())
+
+    def gemm_workspace(self, slabs=256, stream=None):
+        """allocate and register the split-K slab workspace of `stream` (default: the current one): weight-gradient launches
+        on that stream then combine their K splits in memory instead of through fp32 atomics on the gradient buffer.
+        Returns the tensor (the caller keeps it alive)."""
+        st = stream if stream is not None else torch.cuda.current_stream()
+        key = (st.device_index, st.cuda_stream, int(slabs))
+        if key not in _SLAB_WS:               # one per stream for the life of the process: the library keeps the pointer
+            nbytes = int(self.lib.raw("xl_gemm_workspace_bytes")(int(slabs)))
+            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=torch.device("cuda", st.device_index))
+            self.lib.call("xl_gemm_set_workspace", ws.data_ptr(), nbytes, st.cuda_stream)
+            _SLAB_WS[key] = ws
+        return _SLAB_WS[key]
 
     # -- LayerNorm family
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, N, eps):
@@ -188,6 +228,9 @@ class HipOps:
 
     def scatter_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
         self.lib.call("xl_scatter_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
+
+    def gather_labels(self, labels, rows, out, n_rows):
+        self.lib.call("xl_gather_labels", self._p(labels), self._p(rows), self._p(out), n_rows, self._stream())
 
     def sumsq(self, g, out, n):
         self.lib.call("xl_sumsq", self._p(g), self._p(out), n, self._stream())

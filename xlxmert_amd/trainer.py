@@ -51,7 +51,8 @@ class PretrainStep:
     def __init__(self, cfg: XLxmertConfig, batch_size, text_len=20, n_grids=64, dtype=torch.bfloat16, device=None,
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
-                 bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None):
+                 bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None,
+                 plan=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -65,7 +66,14 @@ class PretrainStep:
         grad_comm_dtype: element type of the gradient exchange, torch.float32 (default; what DDP moves for the reference's
         fp32 parameters) or torch.bfloat16 (half the bytes over xGMI: 405 MB instead of 810 MB per step; every finished
         slice is cast into a bf16 bucket on the stream that produced it, summed by RCCL, and cast back into the fp32
-        gradient buffer before the norm / AdamW, which keep accumulating in fp32).  Env XL_GRAD_COMM=bf16|fp32 overrides."""
+        gradient buffer before the norm / AdamW, which keep accumulating in fp32).  Env XL_GRAD_COMM=bf16|fp32 overrides.
+        plan: replay the masked-visual-token step (forward, backward, norm, AdamW: ~560 launches and ~150 stream hand-offs
+        on four streams) as ONE C call per step -- a launch plan recorded from the step's own C-ABI calls (csrc/plan.hip,
+        _lib.LaunchPlan), one per launch geometry -- instead of enqueueing it from Python (13 ms of host time per step).
+        Everything a step varies lives in device memory: inputs in the engine's static buffers, the dropout step seed
+        (engine.seed_dev), the schedule scalars (xl_schedule_step), the masked-row list padded to the GEMM row tile.
+        Single-process runs only (a gradient exchange keeps the eager path); default off, env XL_PLAN=1|0 overrides.
+        (A hipGraph of the same step was measured and rejected: see csrc/plan.hip.)"""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -109,6 +117,10 @@ class PretrainStep:
                 self._comm_ops = HipOps(torch.bfloat16)
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // (2 if self.comm_buf is not None else 4))
         self.exposed_comm_ms = []              # per step: time the main stream waited for collectives after backward
+        env = os.environ.get("XL_PLAN")
+        self.plan_mode = bool(int(env)) if env else bool(plan)
+        self.plan_mode = self.plan_mode and isinstance(self.ops, HipOps) and not self.exchange and task == "vis_mask"
+        self._plans, self._plan_warm = {}, False
         if self.world > 1:
             self.sync_replicas()
 
@@ -263,6 +275,8 @@ class PretrainStep:
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                        vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"),
                        feat_labels=batch.get("feat_labels") if self.feat_loss else None)
+        if self.plan_mode and qa_labels is None:
+            return self._planned_step()
         if self.exchange:
             self._begin_exchange()
             eng.grad_ready = self._on_grad_ready
@@ -272,14 +286,41 @@ class PretrainStep:
         self.optimizer_step()
         return losses
 
+    def _planned_step(self):
+        """forward + backward + optimizer of the batch set_inputs has just staged, replayed from a launch plan.  One plan per
+        launch geometry = (padded number of masked rows, losses): with n ~ U{1..64} masks per image the padded count takes a
+        handful of values at bs 256.  The very first step only runs (it allocates the backward scratch); a geometry's first
+        use runs AND records; from then on the step is one xl_plan_run."""
+        eng = self.engine
+        use_rows = eng.compact_head and eng.has_vmask and 0 < eng.n_mrows < eng.MV
+        key = (eng.n_mrows if use_rows else -1, bool(self.feat_loss), eng.feat_tgt is not None, eng.has_vmask, eng.use_codebook)
+        plan = self._plans.get(key)
+        if plan is not None:
+            plan.run()
+            self.t += 1
+            return eng.losses
+        if not self._plan_warm:
+            self._plan_warm = True
+            losses = eng.vis_mask_forward_backward(self.feat_loss)
+            self.optimizer_step()
+            return losses
+        with self.ops.lib.record() as calls:
+            eng.vis_mask_forward_backward(self.feat_loss)
+            self.optimizer_step()
+        self._plans[key] = self.ops.lib.make_plan(calls)
+        return eng.losses
+
     def optimizer_step(self):
-        st, ops = self.store, self.ops
         self.t += 1                      # host mirror of step_dev (seeds, logging): never read by a kernel
+        self._optimizer_launches()
+
+    def _optimizer_launches(self):
+        st, ops = self.store, self.ops
         b1, b2 = self.betas
         ops.schedule_step(self.step_dev, self.lr, self.warmup_steps, self.total_steps, b1, b2, self.lrs)
         n = st.n_used
         if self.clip > 0:
-            self.sumsq.zero_()
+            ops.zero(self.sumsq)
             ops.sumsq(st.grad, self.sumsq, n)
         flags = st.decay_flags
         if self.chunk_steps is not None:
