@@ -137,44 +137,53 @@ __device__ __forceinline__ bf16x8_t gfrag(const bf16_t* __restrict__ base, int l
 
 // (the transposed-operand gathers and the K-major fragments below both read tiles staged ONCE per problem with coalesced
 //  16-byte loads: per-lane strided global fragment loads touch 64 cache lines per instruction and were ~6x slower)
-template <int DH> struct Tile {
+// SW (backward kernel, DH = 64): no row padding -- 128-byte rows whose 16-byte chunk c sits at chunk c ^ ((row >> 1) & 7), the
+// layout of the GEMM's K-major operand tile: ds_read_b128 row fragments are conflict-free without the 16 pad bytes per row,
+// and three 8 KiB tiles per (batch, head) problem let six workgroups share a CU instead of four.
+template <int DH, bool SW = false> struct Tile {
+    static_assert(!SW || DH == 64, "swizzled tile: 128-byte rows");
     static constexpr int DHP = DH < 32 ? 32 : DH;       // padded so that every MFMA row d<32 exists (zeros)
-    static constexpr int PITCH = DHP * 2 + 16;          // bytes per sequence row
+    static constexpr int PITCH = SW ? DHP * 2 : DHP * 2 + 16;      // bytes per sequence row
     static constexpr int BYTES = MAXN * PITCH;
+    // byte offset of element (row, d)
+    __device__ static __forceinline__ int off(int row, int d) {
+        if (SW) return row * PITCH + ((((d >> 3) ^ (row >> 1)) & 7) << 4) + (d & 7) * 2;
+        return row * PITCH + d * 2;
+    }
 };
 
 // stage rows [0,64) x [0,DH) of a [n, ld] matrix (head slice at column c0) into an LDS tile; rows >= n and
 // columns >= DH are zero.
-template <int DH, int ROWS = MAXN>
+template <int DH, int ROWS = MAXN, bool SW = false>
 __device__ __forceinline__ void stage_tile(uint8_t* tile, const bf16_t* __restrict__ base, int ld, int n, int c0, int lane,
                                            int nthr = 64) {
-    constexpr int CH = Tile<DH>::DHP / 8;               // 16-byte chunks per row
+    constexpr int CH = Tile<DH, SW>::DHP / 8;           // 16-byte chunks per row
     for (int idx = lane; idx < ROWS * CH; idx += nthr) {
         const int row = idx / CH, c = idx % CH;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < n && c * 8 < DH) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c0 + c * 8);
-        *reinterpret_cast<uint4*>(tile + row * Tile<DH>::PITCH + c * 16) = v;
+        *reinterpret_cast<uint4*>(tile + Tile<DH, SW>::off(row, c * 8)) = v;
     }
 }
 
 // K-major fragment from a staged tile: row `row`, 8 features at d = s*16 + (lane>>5)*8 (rows >= n are zero in the tile)
-template <int DH>
+template <int DH, bool SW = false>
 __device__ __forceinline__ bf16x8_t lfrag(const uint8_t* tile, int row, int s, int lane) {
-    return *reinterpret_cast<const bf16x8_t*>(tile + row * Tile<DH>::PITCH + (s * 16 + (lane >> 5) * 8) * 2);
+    return *reinterpret_cast<const bf16x8_t*>(tile + Tile<DH, SW>::off(row, s * 16 + (lane >> 5) * 8));
 }
 
 // A operand "X^T": MFMA row = feature d0+(lane&31); k-slots j=0..7 <-> sequence index
 //   seq = sbase + 8*(j>>2) + 4*(lane>>5) + (j&3)           (the order in which a lane's accumulator rows come)
-template <int DH, bool TR>
+template <int DH, bool TR, bool SW = false>
 __device__ __forceinline__ bf16x8_t tfrag(const uint8_t* tile, int d0, int sbase, int lane) {
-    constexpr int PITCH = Tile<DH>::PITCH;
+    using TL = Tile<DH, SW>;
     const int hi = lane >> 5;
     if (TR) {
         const int t = lane & 15;
         const int dcol = d0 + ((lane >> 4) & 1) * 16 + (t & 3) * 4;
         const int s0 = sbase + 4 * hi + (t >> 2);
-        auto p0 = (__attribute__((address_space(3))) v4bf16s_t*)(tile + s0 * PITCH + dcol * 2);
-        auto p1 = (__attribute__((address_space(3))) v4bf16s_t*)(tile + (s0 + 8) * PITCH + dcol * 2);
+        auto p0 = (__attribute__((address_space(3))) v4bf16s_t*)(tile + TL::off(s0, dcol));
+        auto p1 = (__attribute__((address_space(3))) v4bf16s_t*)(tile + TL::off(s0 + 8, dcol));
         bf16x4_t lo = __builtin_bit_cast(bf16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p0));
         bf16x4_t hi4 = __builtin_bit_cast(bf16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p1));
         return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -184,7 +193,7 @@ __device__ __forceinline__ bf16x8_t tfrag(const uint8_t* tile, int d0, int sbase
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int s = sbase + 8 * (j >> 2) + 4 * hi + (j & 3);
-            f[j] = *reinterpret_cast<const short*>(tile + s * PITCH + d * 2);
+            f[j] = *reinterpret_cast<const short*>(tile + TL::off(s, d));
         }
         return f;
     }
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
 }
 
 template <int DH, int NQF, int NKF, bool TR, bool DROP, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                     bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
@@ -298,10 +307,16 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
                                                     float p_drop, float inv_keep, uint64_t seed, float* __restrict__ cs_ws,
                                                     const uint64_t* __restrict__ step_seed) {
     if (DROP) seed = with_step_seed(seed, step_seed);
-    __shared__ __attribute__((aligned(16))) uint8_t tk[NKF * 32 * Tile<DH>::PITCH];     // K   [key][d]
-    __shared__ __attribute__((aligned(16))) uint8_t tq[NQF * 32 * Tile<DH>::PITCH];     // Q   [q][d]
-    __shared__ __attribute__((aligned(16))) uint8_t tdo[NQF * 32 * Tile<DH>::PITCH];    // dO  [q][d]
-    __shared__ __attribute__((aligned(16))) uint8_t tv[NKF * 32 * Tile<DH>::PITCH];     // V   [key][d]
+    // K, Q, dO are needed both as row fragments and transposed: staged in LDS (unpadded swizzled tiles for DH = 64).  V is only
+    // ever read as row fragments -- its own row by the lane that owns the key (phase 2), the same rows as the A operand of
+    // dP^T = V dO^T (phase 1) -- so every wave keeps the V fragments in registers, straight from global: three tiles instead
+    // of four, 26 KiB per workgroup at 64 x 64, six workgroups (12 waves) per CU instead of four.  The kernel is latency-
+    // bound (54 % of its wave cycles wait, 21 % issue VALU): occupancy is what it lacked.
+    constexpr bool SW = DH == 64;
+    using TL = Tile<DH, SW>;
+    __shared__ __attribute__((aligned(16))) uint8_t tk[NKF * 32 * TL::PITCH];     // K   [key][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tq[NQF * 32 * TL::PITCH];     // Q   [q][d]
+    __shared__ __attribute__((aligned(16))) uint8_t tdo[NQF * 32 * TL::PITCH];    // dO  [q][d]
     __shared__ float s_delta[MAXN];
     __shared__ float s_lse[MAXN];
     // bias gradients of the q/k/v projections without re-reading dQ/dK/dV: column sums factor through per-token scalars,
@@ -317,10 +332,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
     const bf16_t* kb = k + (size_t)b * nk * ldk;
     const bf16_t* vb = v + (size_t)b * nk * ldv;
     const bf16_t* dob = dout + (size_t)b * nq * ldo;
-    stage_tile<DH, NKF * 32>(tk, kb, ldk, nk, h * DH, tid, NW * 64);
-    stage_tile<DH, NQF * 32>(tq, qb, ldq, nq, h * DH, tid, NW * 64);
-    stage_tile<DH, NQF * 32>(tdo, dob, ldo, nq, h * DH, tid, NW * 64);
-    stage_tile<DH, NKF * 32>(tv, vb, ldv, nk, h * DH, tid, NW * 64);
+    bf16x8_t vf[NKF][DH / 16];                  // V row fragments: row i*32 + (lane & 31), features s*16 + (lane >> 5)*8 ..
+#pragma unroll
+    for (int i = 0; i < NKF; ++i)
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) vf[i][s] = gfrag(vb, ldv, i * 32 + l31, nk, h * DH + s * 16 + hi * 8);
+    stage_tile<DH, NKF * 32, SW>(tk, kb, ldk, nk, h * DH, tid, NW * 64);
+    stage_tile<DH, NQF * 32, SW>(tq, qb, ldq, nq, h * DH, tid, NW * 64);
+    stage_tile<DH, NQF * 32, SW>(tdo, dob, ldo, nq, h * DH, tid, NW * 64);
     if (tid < MAXN) s_lse[tid] = tid < nq ? lse[(size_t)bh * nq + tid] : 0.f;
     constexpr int ND = (DH + 31) / 32;
     __syncthreads();
@@ -334,11 +353,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
         for (int i = 0; i < NKF; ++i) { st[i] = zero16(); dpt[i] = zero16(); }
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
-            const bf16x8_t fq = lfrag<DH>(tq, j * 32 + l31, s, lane), fdo = lfrag<DH>(tdo, j * 32 + l31, s, lane);
+            const bf16x8_t fq = lfrag<DH, SW>(tq, j * 32 + l31, s, lane), fdo = lfrag<DH, SW>(tdo, j * 32 + l31, s, lane);
 #pragma unroll
             for (int i = 0; i < NKF; ++i) {
-                st[i] = mfma32(lfrag<DH>(tk, i * 32 + l31, s, lane), fq, st[i]);
-                dpt[i] = mfma32(lfrag<DH>(tv, i * 32 + l31, s, lane), fdo, dpt[i]);
+                st[i] = mfma32(lfrag<DH, SW>(tk, i * 32 + l31, s, lane), fq, st[i]);
+                dpt[i] = mfma32(vf[i][s], fdo, dpt[i]);
             }
         }
         const int qi = j * 32 + l31;
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
             for (int i = 0; i < NKF; ++i)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    qa = mfma32(tfrag<DH, TR>(tk, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), qa);
+                    qa = mfma32(tfrag<DH, TR, SW>(tk, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), qa);
             store_rows<DH>(qa, dq + (size_t)b * nq * lddq, lddq, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
         }
     }
@@ -399,11 +418,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
         for (int j = 0; j < NQF; ++j) { s2[j] = zero16(); dp2[j] = zero16(); }
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
-            const bf16x8_t fk = lfrag<DH>(tk, i * 32 + l31, s, lane), fv = lfrag<DH>(tv, i * 32 + l31, s, lane);
+            const bf16x8_t fk = lfrag<DH, SW>(tk, i * 32 + l31, s, lane);
+            bf16x8_t fv = vf[0][s];             // fragment i of the register copy (i is a run-time wave index: select, do not index)
+#pragma unroll
+            for (int ii = 1; ii < NKF; ++ii) fv = (i == ii) ? vf[ii][s] : fv;
 #pragma unroll
             for (int j = 0; j < NQF; ++j) {
-                s2[j] = mfma32(lfrag<DH>(tq, j * 32 + l31, s, lane), fk, s2[j]);
-                dp2[j] = mfma32(lfrag<DH>(tdo, j * 32 + l31, s, lane), fv, dp2[j]);
+                s2[j] = mfma32(lfrag<DH, SW>(tq, j * 32 + l31, s, lane), fk, s2[j]);
+                dp2[j] = mfma32(lfrag<DH, SW>(tdo, j * 32 + l31, s, lane), fv, dp2[j]);
             }
         }
         const int key = i * 32 + l31;
@@ -439,8 +461,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
             for (int j = 0; j < NQF; ++j)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    va = mfma32(tfrag<DH, TR>(tdo, id * 32, j * 32 + u * 16, lane), acc_to_frag(s2[j], u), va);
-                    ka = mfma32(tfrag<DH, TR>(tq, id * 32, j * 32 + u * 16, lane), acc_to_frag(dp2[j], u), ka);
+                    va = mfma32(tfrag<DH, TR, SW>(tdo, id * 32, j * 32 + u * 16, lane), acc_to_frag(s2[j], u), va);
+                    ka = mfma32(tfrag<DH, TR, SW>(tq, id * 32, j * 32 + u * 16, lane), acc_to_frag(dp2[j], u), ka);
                 }
             store_rows<DH>(va, dv + (size_t)b * nk * lddv, lddv, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
             store_rows<DH>(ka, dk + (size_t)b * nk * lddk, lddk, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
@@ -450,18 +472,17 @@ __global__ __launch_bounds__(NW * 64, 2) void sdpa_bwd_mfma(const bf16_t* __rest
         // slab b of the workspace: [q | k | v] x [H*DH] partial bias gradients of this batch element (plain stores: every
         // element has exactly one writer; the second stage sums the B slabs)
         __syncthreads();
-        constexpr int PITCH = Tile<DH>::PITCH;
         for (int w = tid; w < 3 * DH; w += NW * 64) {
             const int which = w / DH, d = w % DH;
             float acc = 0.f;
             if (which == 0) {
                 for (int key = 0; key < NKF * 32; ++key)
-                    acc += bf2f(*reinterpret_cast<const bf16_t*>(tk + key * PITCH + d * 2)) * s_ds_k[key];
+                    acc += bf2f(*reinterpret_cast<const bf16_t*>(tk + TL::off(key, d))) * s_ds_k[key];
             } else {
                 const uint8_t* tile = which == 1 ? tq : tdo;
                 const float* sc = which == 1 ? s_ds_q : s_p_q;
                 for (int qi = 0; qi < NQF * 32; ++qi)
-                    acc += bf2f(*reinterpret_cast<const bf16_t*>(tile + qi * PITCH + d * 2)) * sc[qi];
+                    acc += bf2f(*reinterpret_cast<const bf16_t*>(tile + TL::off(qi, d))) * sc[qi];
             }
             cs_ws[((size_t)b * 3 + which) * (H * DH) + h * DH + d] = acc;
         }
