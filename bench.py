@@ -195,7 +195,7 @@ def main():
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595,
                       total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout,
                       bucket_mb=float(os.environ.get("XL_BUCKET_MB", "64")),
-                      plan=(world == 1 and not grouped and not args.eager and not args.single_stream))
+                      plan=(world == 1 and not grouped and not args.eager and not args.single_stream), drop_grads=True)
     if args.single_stream:
         tr.engine.side = None
     g = torch.Generator().manual_seed(9595)

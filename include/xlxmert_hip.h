@@ -265,11 +265,13 @@ int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, int total_s
  * {lr, bias_corr1 = 1-beta1^t, bias_corr2 = 1-beta2^t, unused}; chunk_steps (device int32 per chunk, may be NULL): the
  * per-tensor update count state["step"] of transformers' AdamW -- when given, the bias corrections are computed from it
  * instead of lr_and_steps[1..2] (the caller increments it for the chunks it does not skip).  Writes the compute copy
- * (`dtype`) of every updated parameter to p_compute (may be NULL). */
-int xl_adamw(float* p, const float* g, float* m, float* v, void* p_compute,
+ * (`dtype`) of every updated parameter to p_compute (may be NULL).  zero_grad != 0: the gradient of every updated chunk is
+ * cleared in the same pass (the trainer's optimizer.zero_grad(), ref lxmert_pretrain.py:336 -- 4 bytes per element written
+ * here instead of a separate 0.8 GB clear before the next backward). */
+int xl_adamw(float* p, float* g, float* m, float* v, void* p_compute,
              const uint8_t* decay_flags, const int* chunk_steps, const float* sumsq, const float* lr_and_steps,
              int64_t n, float beta1, float beta2, float eps, float weight_decay, float max_norm,
-             float grad_scale, int dtype, void* stream);
+             float grad_scale, int zero_grad, int dtype, void* stream);
 /* dst (`dtype`) = src (fp32), n elements */
 int xl_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
 /* dst (fp32) = src (`dtype`) */

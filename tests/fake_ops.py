@@ -346,7 +346,7 @@ class FakeOps:
         lr_and_steps[0], lr_and_steps[1], lr_and_steps[2], lr_and_steps[3] = base_lr * f, 1.0 - beta1 ** t, 1.0 - beta2 ** t, float(t)
 
     def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
-              max_norm, grad_scale=1.0, chunk_steps=None):
+              max_norm, grad_scale=1.0, chunk_steps=None, zero_grad=False):
         lr, bc1, bc2 = (float(x) for x in lr_and_steps[:3])
         clip = grad_scale
         if max_norm > 0 and sumsq is not None:
@@ -371,6 +371,8 @@ class FakeOps:
         p[:n].copy_(torch.where(act, p_new, p[:n]))
         if p_compute is not None and p_compute.data_ptr() != p.data_ptr():
             p_compute[:n].copy_(p[:n])
+        if zero_grad:
+            g[:n].copy_(torch.where(act, torch.zeros_like(g[:n]), g[:n]))
 
     def cast_from_f32(self, src, dst, n):
         if dst.data_ptr() != src.data_ptr():

@@ -358,3 +358,28 @@ def test_random_word_batch_statistics():
     assert 0.75 < is_mask.sum().item() / chosen.sum().item() < 0.85
     kept = (masked == ids) & chosen
     assert 0.06 < kept.sum().item() / chosen.sum().item() < 0.14
+
+
+def test_optimizer_pass_clears_the_gradients_when_asked():
+    """drop_grads: xl_adamw clears the gradient buffer in its own pass and the next step's backward starts without a clear --
+    same losses and parameters as the step that clears before every backward; the gradients are gone after step()."""
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 3, 8, 4
+    keep, _ = make_step(cfg, B, L, grid, lr=1e-2)
+    drop, _ = make_step(cfg, B, L, grid, lr=1e-2, drop_grads=True)
+    assert not keep.drop_grads and drop.drop_grads
+    for t in range(3):
+        batch = synthetic_batch(cfg, B, L, grid, seed=200 + t)
+        lk, ld = keep.step(batch).clone(), drop.step(batch).clone()
+        assert torch.equal(lk, ld)
+        assert keep.grad_norm() == drop.grad_norm()
+        assert keep.store.grad[:keep.store.n_used].abs().max().item() > 0
+        assert drop.store.grad[:drop.store.n_used].abs().max().item() == 0 and drop.engine.grad_is_zero
+        assert torch.equal(keep.store.master, drop.store.master)
+    # a backward outside the trainer dirties the buffer again: the next step clears it
+    drop.engine.set_inputs(batch["input_ids"], batch["attention_mask"], None, batch["visual_pos"], cluster_ids=batch["cluster_ids"],
+                           vis_mask=batch["vis_mask"], obj_labels=batch["obj_labels"])
+    drop.engine.vis_mask_forward_backward(True)
+    assert not drop.engine.grad_is_zero
+    batch = synthetic_batch(cfg, B, L, grid, seed=300)
+    assert torch.equal(keep.step(batch), drop.step(batch)) and torch.equal(keep.store.master, drop.store.master)

@@ -44,11 +44,12 @@ __device__ __forceinline__ void store4(bf16_t* dst, const float (&a)[4]) {      
 
 // one thread = 4 consecutive parameters (n is padded to a multiple of 256 by the caller's layout)
 template <typename T>
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, T* __restrict__ pc, const uint8_t* __restrict__ decay,
                                                     const int* __restrict__ chunk_steps,
                                                     const float* __restrict__ sumsq, const float* __restrict__ lrs, int64_t n4,
-                                                    float beta1, float beta2, float eps, float wd, float max_norm, float gscale) {
+                                                    float beta1, float beta2, float eps, float wd, float max_norm, float gscale,
+                                                    int zero_grad) {
     const float lr = lrs[0], bc1 = lrs[1], bc2 = lrs[2];
     float clip = gscale;
     if (max_norm > 0.f && sumsq != nullptr) {
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         }
         const float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the step's optimizer.zero_grad(), in this pass
         const float4 mv = reinterpret_cast<float4*>(m)[i];
         const float4 vv = reinterpret_cast<float4*>(v)[i];
         const bool dec = wd > 0.f && (fl & 1);
@@ -142,10 +144,10 @@ extern "C" int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream) {
     return XL_OK;
 }
 
-extern "C" int xl_adamw(float* p, const float* g, float* m, float* v, void* p_compute,
+extern "C" int xl_adamw(float* p, float* g, float* m, float* v, void* p_compute,
                         const uint8_t* decay_flags, const int* chunk_steps, const float* sumsq, const float* lr_and_steps,
                         int64_t n, float beta1, float beta2, float eps, float weight_decay, float max_norm,
-                        float grad_scale, int dtype, void* stream) {
+                        float grad_scale, int zero_grad, int dtype, void* stream) {
     XL_CHECK_ARG(p && g && m && v && lr_and_steps, XL_ERR_BAD_ARG, "xl_adamw: null pointer");
     XL_CHECK_ARG(n > 0 && n % 256 == 0, XL_ERR_BAD_SHAPE, "xl_adamw: n=%lld must be a positive multiple of 256", (long long)n);
     XL_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), XL_ERR_UNALIGNED, "xl_adamw: unaligned buffer");
@@ -153,10 +155,10 @@ extern "C" int xl_adamw(float* p, const float* g, float* m, float* v, void* p_co
     const int64_t n4 = n >> 2;
     if (dtype == XL_BF16)
         hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_compute,
-                           decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
+                           decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale, zero_grad);
     else if (dtype == XL_F32)
         hipLaunchKernelGGL((adamw_kernel<float>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (float*)p_compute,
-                           decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale);
+                           decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale, zero_grad);
     else { set_error("xl_adamw: bad dtype %d", dtype); return XL_ERR_BAD_DTYPE; }
     XL_CHECK_LAUNCH();
     return XL_OK;

@@ -533,6 +533,7 @@ class Engine:
         # then [language_range.hi, n_used); language stream language_range itself (exchange stream, see _ready_lang)
         self.grad_ready = None
         self._lane_lo = None
+        self.grad_is_zero = False       # set by the trainer when its optimizer pass cleared the gradient buffer
         self._n_sites = 2               # sites 0 / 1: embedding and visual-feature-encoder output dropout
         self._seed = 0
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)       # step part of the dropout seeds
@@ -1112,8 +1113,7 @@ class Engine:
 
     def _task_step(self, task, **kw):
         out = self.task_forward(task, **kw)
-        st = self.store
-        self.ops.zero(st.grad[st.n_mat:st.n_used])
+        self.clear_grads()
         self.task_backward()
         return out
 
@@ -1215,14 +1215,22 @@ class Engine:
     # ------------------------------------------------------------ backward
     def zero_accumulated_grads(self):
         """start of a training step's backward: clear the gradient buffer, defer the column reductions' second stages."""
-        st = self.store
-        self.ops.zero(st.grad[st.n_mat:st.n_used])
+        self.clear_grads()
         self.begin_backward()
+
+    def clear_grads(self):
+        """gradient buffer := 0 before a step's backward -- skipped when the optimizer pass of the previous step has already
+        cleared it (trainer drop_grads: xl_adamw zero_grad) and nothing has accumulated since."""
+        st = self.store
+        if not self.grad_is_zero:
+            self.ops.zero(st.grad[st.n_mat:st.n_used])
+        self.grad_is_zero = False
 
     def begin_backward(self):
         """start of a backward pass that ACCUMULATES into the gradient buffer (the nn.Module path: zeroing is the caller's
         zero_grad(), as with autograd): second stages of the column reductions deferred until encoder_backward ends."""
         self.defer_reductions(True)
+        self.grad_is_zero = False
         self._lane_lo = {"v": 0, "l": self.store.language_range()[0]}
 
     def head_backward(self, d_vis, report=True):

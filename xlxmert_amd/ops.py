@@ -241,10 +241,10 @@ class HipOps:
                       float(beta2), self._p(lr_and_steps), self._stream())
 
     def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
-              max_norm, grad_scale=1.0, chunk_steps=None):
+              max_norm, grad_scale=1.0, chunk_steps=None, zero_grad=False):
         self.lib.call("xl_adamw", self._p(p), self._p(g), self._p(m), self._p(v), self._p(p_compute),
                       self._p(decay_flags), self._p(chunk_steps), self._p(sumsq), self._p(lr_and_steps), n, float(beta1), float(beta2),
-                      float(eps), float(weight_decay), float(max_norm), float(grad_scale), self.dt, self._stream())
+                      float(eps), float(weight_decay), float(max_norm), float(grad_scale), int(zero_grad), self.dt, self._stream())
 
     def cast_from_f32(self, src, dst, n):
         self.lib.call("xl_cast_from_f32", self._p(src), self._p(dst), n, self.dt, self._stream())

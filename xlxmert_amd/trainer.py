@@ -52,7 +52,7 @@ class PretrainStep:
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
                  bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None,
-                 plan=None):
+                 plan=None, drop_grads=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -73,7 +73,11 @@ class PretrainStep:
         Everything a step varies lives in device memory: inputs in the engine's static buffers, the dropout step seed
         (engine.seed_dev), the schedule scalars (xl_schedule_step), the masked-row list padded to the GEMM row tile.
         Single-process runs only (a gradient exchange keeps the eager path); default off, env XL_PLAN=1|0 overrides.
-        (A hipGraph of the same step was measured and rejected: see csrc/plan.hip.)"""
+        (A hipGraph of the same step was measured and rejected: see csrc/plan.hip.)
+        drop_grads: the optimizer pass clears the gradient buffer itself (the reference's optim.zero_grad(),
+        lxmert_pretrain.py:241, folded into xl_adamw: 4 bytes per element more in that pass instead of a separate 0.8 GB
+        clear before the next backward); store.grad is then zero after step().  Default: on with `plan`, else off (the
+        gradients of the last step stay readable).  Not with task="all" (skipped tensors keep their buffers)."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -121,6 +125,7 @@ class PretrainStep:
         self.plan_mode = bool(int(env)) if env else bool(plan)
         self.plan_mode = self.plan_mode and isinstance(self.ops, HipOps) and not self.exchange and task == "vis_mask"
         self._plans, self._plan_warm = {}, False
+        self.drop_grads = (self.plan_mode if drop_grads is None else bool(drop_grads)) and task != "all"
         if self.world > 1:
             self.sync_replicas()
 
@@ -329,7 +334,9 @@ class PretrainStep:
         ops.adamw(st.master, st.grad, st.exp_avg, st.exp_avg_sq,
                   st.compute if st.compute_dtype != torch.float32 else None, flags,
                   self.sumsq if self.clip > 0 else None, self.lrs, n, b1, b2, self.eps, self.wd, self.clip,
-                  grad_scale=1.0 / self.world, chunk_steps=self.chunk_steps)
+                  grad_scale=1.0 / self.world, chunk_steps=self.chunk_steps, zero_grad=self.drop_grads)
+        if self.drop_grads:
+            self.engine.grad_is_zero = True          # the next backward starts from a clean buffer without clearing it
 
     def grad_norm(self):
         return math.sqrt(float(self.sumsq.item())) / self.world
