@@ -97,15 +97,23 @@ int  xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const
                          const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
                          int count, int dtype, void* stream);
 
-/* Split-K without atomics on the output: a per-stream workspace (caller-owned device memory, 16-byte aligned) for the
- * ping-pong kernel's partial tiles.  With one registered for `stream`, split-K launches on that stream (xl_gemm weight-
- * gradient shapes, xl_gemm_wgrad_group) let the splits of an output tile meet in memory -- the last workgroup to arrive
- * sums the partial tiles and makes ONE read-modify-write pass over C -- instead of one pass of fp32 atomics per split.
- * xl_gemm_workspace_bytes(slabs): bytes for `slabs` = output tiles x K splits of the largest launch (256 covers every
- * chip-filling launch; a launch that needs more falls back to atomics).  ws = NULL unregisters.  The workspace must not be
- * shared by streams that run concurrently; results are identical up to fp32 summation order. */
+/* Slab workspace of the ping-pong kernel: per-stream, caller-owned device memory (16-byte aligned) in which the K slices
+ * of one output tile meet -- every slice's workgroup writes its partial tile, the last to arrive sums them and runs the
+ * epilogue.  With one registered for `stream`, launches on that stream use it for
+ *   (a) the tail split: a launch of more than one round of tiles whose last round would be nearly empty (264 tiles on 256
+ *       CUs) and whose contraction is deep runs those last tiles as K slices that fill the CUs as the previous round drains
+ *       (the 10k-codebook contractions of the masked-row head: 446 -> ~250 us);
+ *   (b) weight-gradient K splits (xl_gemm a_kmajor=b_kmajor=0 fp32 out, xl_gemm_wgrad_group) when
+ *       xl_set_gemm_wgrad_slabs(1): one read-modify-write pass over C by the last arriver instead of a pass of fp32 atomics
+ *       per split -- a fixed summation order (deterministic weight gradients), measured 1-3 % slower than the atomics.
+ * xl_gemm_workspace_bytes(slabs): bytes for `slabs` partial tiles (256 covers every chip-filling launch; a launch that
+ * needs more falls back).  ws = NULL unregisters.  A workspace must not be shared by streams that run concurrently. */
 int64_t xl_gemm_workspace_bytes(int slabs);
 int  xl_gemm_set_workspace(void* ws, int64_t bytes, void* stream);
+int  xl_set_gemm_wgrad_slabs(int on);
+/* tail split thresholds: at most `max_tail_tiles` tiles in the last round (0 disables; default 64) and a contraction of at
+ * least `min_k` (default 4096: measured gain at K = 10000, none at K = 2048). */
+int  xl_set_gemm_tail_split(int max_tail_tiles, int min_k);
 
 /* ---------------------------------------------------------------- LayerNorm (eps inside sqrt, HF:188 et al.)
  * y = (x-mean)*rstd*gamma+beta over the last dim N; saves mean,rstd (fp32 [M]).  */

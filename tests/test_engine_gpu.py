@@ -652,8 +652,10 @@ def test_task_round_robin_full_size_bf16():
         loss = tr.step(dev_batch, task=task)
         torch.cuda.synchronize()
         assert torch.isfinite(loss).all() and torch.isfinite(tr.store.master).all()
-        if task == "word_mask":
-            assert tr.engine.lang_heads.n_rows == int((wl >= 0).sum().item())
+        if task == "word_mask":             # labelled rows, the list padded to the GEMM row tile with -1 entries
+            n_lab = int((wl >= 0).sum().item())
+            assert tr.engine.lang_heads.n_rows == min(tr.engine.ML, (n_lab + 255) // 256 * 256)
+            assert (tr.engine.lang_heads.rows[n_lab:tr.engine.lang_heads.n_rows] == -1).all()
         same = {k: torch.equal(before[k], tr.store.view(k)) for k in before}
         assert same["obj_predict_head.linear_feat.weight"] == (task != "vis_mask")
         assert same["cls.seq_relationship.weight"] == (task != "matched")

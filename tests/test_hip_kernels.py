@@ -213,9 +213,54 @@ def slab_ws(request):
         nbytes = int(ops.lib.raw("xl_gemm_workspace_bytes")(256))
         ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
         ops.lib.call("xl_gemm_set_workspace", ws.data_ptr(), nbytes, st)
+    ops.set_gemm_wgrad_slabs(request.param)
     yield request.param
     torch.cuda.synchronize()
+    ops.set_gemm_wgrad_slabs(0)
     ops.lib.call("xl_gemm_set_workspace", None, 0, st)
+
+
+@pytest.mark.parametrize("epi,bk,of32", [(0, 1, True), (2, 0, False), (1, 1, False), (3, 0, False)])
+@pytest.mark.parametrize("M,N,K", [(8448, 2048, 1536), (4352, 4096, 1096)])
+def test_gemm_tail_split_exact(M, N, K, epi, bk, of32, slab_ws):
+    """264 / 272 output tiles on 256 CUs: with a slab workspace on the stream the last 8 / 16 tiles run as K slices (3 / 2,
+    the second shape with a ragged last K tile) combined by the last arriver, which runs the epilogue; without one the
+    launch takes a second round.  Integer operands: both must equal the fp32 reference exactly (bf16 outputs: after the
+    same rounding), launch after launch (tickets return to zero)."""
+    g = torch.Generator().manual_seed(M + K + epi)
+    ops = hip(torch.bfloat16)
+    A = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16)
+    B = torch.randint(-2, 3, ((N, K) if bk else (K, N)), generator=g).to(torch.bfloat16)
+    bias = torch.randint(-3, 4, (N,), generator=g).float()
+    res = torch.randint(-4, 5, (M, N), generator=g).to(torch.bfloat16) if epi == 2 else None
+    aux = torch.randint(-2, 3, (M, N), generator=g).to(torch.bfloat16) if epi == 3 else (torch.zeros(M, N).to(torch.bfloat16) if epi == 1 else None)
+    acc = A.float() @ (B.float().t() if bk else B.float()) + bias
+    if epi == 1:
+        ref, ref_aux = torch.nn.functional.gelu(acc), acc
+    elif epi == 2:
+        ref = acc + res.float()
+    elif epi == 3:
+        x = aux.float()
+        ref = acc * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
+    else:
+        ref = acc
+    Ag, Bg, bg = A.cuda(), B.cuda(), bias.cuda()
+    rg = res.cuda() if res is not None else None
+    ops.lib.call("xl_set_gemm_tail_split", 64, 1024)           # (default depth threshold: 4096)
+    for rep in range(2):
+        C = torch.full((M, N), 7.0, dtype=torch.float32 if of32 else torch.bfloat16, device="cuda")
+        xg = aux.cuda() if aux is not None else None
+        ops.gemm(Ag, Bg, C, bg, rg, xg, M, N, K, K, (K if bk else N), N, ldr=N, ldx=N, a_kmajor=1, b_kmajor=bk, out_f32=of32,
+                 epilogue=epi)
+        torch.cuda.synchronize()
+        if of32 or epi in (0, 2):
+            want = ref if of32 else ref.to(torch.bfloat16).float()
+            assert torch.equal(C.float().cpu(), want), f"rep {rep}: max abs diff {(C.float().cpu() - want).abs().max().item()}"
+        else:               # GELU / dGELU: the bf16 path's erf approximation, not bit-exact against torch.erf
+            assert (C.float().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+        if epi == 1:
+            assert torch.equal(xg.float().cpu(), ref_aux.to(torch.bfloat16).float())
+    ops.lib.call("xl_set_gemm_tail_split", 64, 4096)
 
 
 @pytest.mark.parametrize("K", [4096, 1000])

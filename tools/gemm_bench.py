@@ -8,8 +8,8 @@ from xlxmert_amd.ops import HipOps, EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU
 
 ops = HipOps(torch.bfloat16)
 dev = "cuda"
-if os.environ.get("XL_GEMM_SLABS", "0") != "0":
-    ops.gemm_workspace(256)          # split-K weight gradients meet in slabs (no fp32 atomics on the output)
+if os.environ.get("XL_GEMM_SLABS", "1") != "0":
+    ops.gemm_workspace(256)          # slab workspace of the current stream: tail split (and, XL_GEMM_WGRAD_SLABS=1, weight gradients)
 ML, MV, MX = 5120, 16384, 21504
 SHAPES = [  # name, M, N, K, ak, bk, epi, out_f32
     ("vis qkv  NT", MV, 2304, 768, 1, 1, EPI_NONE, False),

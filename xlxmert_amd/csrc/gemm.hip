@@ -233,6 +233,8 @@ static int env_int(const char* name, int dflt) {
 unsigned long long* g_gemm_trace = nullptr;   // xl_gemm_trace
 int g_gemm_pp = -1;      // 0 / 1 / 2, see xl_set_gemm_pingpong; -1 = read XL_GEMM_PP (default 1)
 int g_gemm_bn192 = -1;   // 0 / 1 / 2, see xl_set_gemm_tile192; -1 = read XL_GEMM_BN192 (default 1)
+int g_tail_max = -1, g_tail_min_k = 4096;   // tail split: at most this many tiles in the last round, contraction at least this deep (xl_set_gemm_tail_split)
+int g_wgrad_slabs = -1;  // weight-gradient K splits through slabs instead of atomics (xl_set_gemm_wgrad_slabs); -1 = read XL_GEMM_WGRAD_SLABS (default 0)
 
 // split-K slab workspaces, one per stream (xl_gemm_set_workspace): caller-owned memory, [16 KiB of tickets | slabs]
 struct SlabWs { uint8_t* ptr; size_t bytes; };
@@ -253,6 +255,18 @@ static bool slab_workspace(hipStream_t st, long tiles, long slabs, float** slab,
 
 
 using namespace xl;
+
+extern "C" int xl_set_gemm_tail_split(int max_tail_tiles, int min_k) {
+    XL_CHECK_ARG(max_tail_tiles >= 0 && max_tail_tiles < 256 && min_k >= 1024, XL_ERR_BAD_ARG,
+                 "xl_set_gemm_tail_split: max_tail_tiles %d (0..255), min_k %d (>= 1024)", max_tail_tiles, min_k);
+    g_tail_max = max_tail_tiles; g_tail_min_k = min_k;
+    return XL_OK;
+}
+
+extern "C" int xl_set_gemm_wgrad_slabs(int on) {
+    g_wgrad_slabs = on ? 1 : 0;
+    return XL_OK;
+}
 
 extern "C" int64_t xl_gemm_workspace_bytes(int slabs) {
     return (int64_t)SLAB_TICKET_BYTES + (int64_t)std::max(slabs, 0) * (int64_t)(SLAB_FLOATS * sizeof(float));
@@ -316,7 +330,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.step_seed = g_step_seed; p.ablate = ablate;
     p.trace = g_gemm_trace;
     p.colsum_ws = nullptr;
-    p.slab = nullptr; p.tickets = nullptr;
+    p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0;
     if (colsum_out != nullptr)
         XL_CHECK_ARG(colsum_ws != nullptr && !accumulate && (long)((M + 63) / 64) * N <= xl_workspace_floats(N), XL_ERR_BAD_ARG,
                      "xl_gemm: colsum_out needs a workspace (xl_workspace_floats), accumulate = 0 and M <= 262144");
@@ -371,7 +385,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.atomic_out = (accumulate || splitk > 1) ? 1 : 0;
     // split-K of the ping-pong kernel meets in slabs when the stream has a workspace (xl_gemm_set_workspace): one
     // read-modify-write pass over C by the last arriver of every tile instead of a pass of fp32 atomics per split
-    if (use_pp && splitk > 1) slab_workspace(st, tiles, (long)tiles * splitk, &p.slab, &p.tickets);
+    if (g_wgrad_slabs < 0) g_wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
+    if (use_pp && splitk > 1 && g_wgrad_slabs) slab_workspace(st, tiles, (long)tiles * splitk, &p.slab, &p.tickets);
     if (splitk > 1 && !accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: memset failed: %s", hipGetErrorString(e));
@@ -391,7 +406,26 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     const bool colsum_fused = colsum_out != nullptr && mfma_ok && epik >= 0 && splitk == 1 && a_kmajor && M % tile == 0 &&
                               N % tile == 0;
     if (colsum_fused) p.colsum_ws = colsum_ws;
-    const int nblk = p.tiles_m * p.tiles_n * splitk;
+    int nblk = p.tiles_m * p.tiles_n * splitk;
+    // tail split (gemm_pp.hip): more than one round of tiles, a nearly empty last round, a deep contraction, and a slab
+    // workspace on this stream (xl_gemm_set_workspace)
+    // (measured at the masked-row head, 8448 rows: d(feat) = d(logits) C, K = 10000, 264 tiles: 466 -> 332 us; the logits
+    // contraction, K = 2048, 1320 tiles, does not gain -- 338 -> 368 us -- hence the depth threshold)
+    if (g_tail_max < 0) { g_tail_max = env_int("XL_GEMM_TAIL_MAX", 64); g_tail_min_k = env_int("XL_GEMM_TAIL_MIN_K", 4096); }
+    const int tail_max = g_tail_max, tail_min_k = g_tail_min_k;
+    if (use_pp && splitk == 1 && !p.atomic_out && tiles > 256 && tiles % 256 <= tail_max && tiles % 256 > 0 && K >= tail_min_k) {
+        const int rem = tiles % 256;
+        int S = std::min(std::min(256 / rem, K / 512), 8);          // >= 8 K tiles per slice, <= 7 slabs for the last arriver to add
+        if (S >= 2) {
+            int kper_t = (K + S - 1) / S;
+            kper_t = (kper_t + 63) / 64 * 64;
+            S = (K + kper_t - 1) / kper_t;
+            if (S >= 2 && slab_workspace(st, rem, (long)rem * S, &p.slab, &p.tickets)) {
+                p.tail_tiles = rem; p.tail_kper = kper_t; p.splitk = S;
+                nblk = tiles - rem + rem * S;
+            }
+        }
+    }
     if (use_pp) {
         hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -459,7 +493,8 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
             const char* b1 = b0 + ((size_t)(M[j] - 1) * ldc[j] + N[j]) * sizeof(float);
             if (a0 < b1 && b0 < a1) { disjoint = false; break; }
         }
-    if (disjoint) slab_workspace(st, total, total * splitk, &g.slab, &g.tickets);
+    if (g_wgrad_slabs < 0) g_wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
+    if (disjoint && g_wgrad_slabs) slab_workspace(st, total, total * splitk, &g.slab, &g.tickets);
     int acc = 0;
     for (int i = 0; i < count; ++i) {
         GroupProblem& pr = g.prob[i];

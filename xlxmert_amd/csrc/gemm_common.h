@@ -20,6 +20,7 @@ struct GemmParams {
     float* colsum_ws;                 // fused column sums of C: one partial slab [N] per wave tile (64 / 128 rows; fast epilogue only)
     float* slab;                      // split-K through slabs (slab_exchange): partial tiles [tile][split][64 Ki floats], or null
     int* tickets;                     // ... and one arrival counter per output tile (zero between launches)
+    int tail_tiles, tail_kper;        // tail split (ping-pong kernel): the last tail_tiles tiles run as `splitk` K slices each
 };
 
 // ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)
@@ -59,15 +60,20 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 // tile id -> (tile_m, tile_n, split) with an XCD-aware remap: block b runs on XCD b%8 (observed
 // placement, speed only); give every XCD a contiguous chunk of a grouped (8 m-tiles x all n) order
 // so that the tiles co-resident on one XCD share A row panels and B column panels in its L2.
-__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn, int& z) {
-    const int nblk = gridDim.x;
+__device__ __forceinline__ int linear_block(int nblk = gridDim.x) {
     const int b = blockIdx.x;
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = b & 7, pos = b >> 3;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+__device__ __forceinline__ void tile_of(const GemmParams& p, int t, int& tm, int& tn);
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn, int& z) {
+    const int L = linear_block();
     const int tiles = p.tiles_m * p.tiles_n;
     z = L / tiles;
-    const int t = L - z * tiles;
+    tile_of(p, L - z * tiles, tm, tn);
+}
+__device__ __forceinline__ void tile_of(const GemmParams& p, int t, int& tm, int& tn) {
     constexpr int GM = 8;
     const int per_group = GM * p.tiles_n;
     const int g = t / per_group;

@@ -234,8 +234,9 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     [[maybe_unused]] float bias8b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // BN = 192: third column fragment
     if constexpr (EPIK >= 0) {
         if (n0 + wc * WTN + WTN <= p.N) {
-            load_bias8(p, lane, first, n0 + wc * WTN, bias8);
-            if constexpr (BN == 192) sub_load_bias8<32>(p, lane, first, n0 + wc * WTN + 64, bias8b);
+            const bool with_bias = first || slab_tile >= 0;        // slabs: whichever slice arrives last adds the bias
+            load_bias8(p, lane, with_bias, n0 + wc * WTN, bias8);
+            if constexpr (BN == 192) sub_load_bias8<32>(p, lane, with_bias, n0 + wc * WTN + 64, bias8b);
         }
     }
     const int nkt = (kend - kbeg + BK - 1) / BK;
@@ -340,6 +341,26 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
 template <bool AK, bool BKM, int EPIK, int BN>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
     int tm, tn, z;
+    if (p.tail_tiles > 0) {
+        // Tail split: a launch whose last round would hold only a few tiles (264 tiles on 256 CUs: a second round of 8) runs
+        // those tiles as `splitk` K slices each, combined through slabs by the last arriver, which also runs the epilogue --
+        // they fill the CUs as the first round drains instead of keeping 8 of them busy for another full tile.
+        // (workgroups are dispatched in blockIdx order: the whole tiles take the first `full` indices, XCD-aware among
+        // themselves, the slices the rest)
+        const int full = p.tiles_m * p.tiles_n - p.tail_tiles;
+        if ((int)blockIdx.x < full) {
+            tile_of(p, linear_block(full), tm, tn);
+            pp_tile<AK, BKM, EPIK, BN>(p, tm, tn, 0, p.K, true);
+        } else {
+            const int r = (int)blockIdx.x - full, tt = r / p.splitk;
+            z = r - tt * p.splitk;
+            tile_of(p, full + tt, tm, tn);
+            const int kbeg = z * p.tail_kper;
+            pp_tile<AK, BKM, EPIK, BN>(p, tm, tn, kbeg, min(p.K, kbeg + p.tail_kper), z == 0, tt, z,
+                                       (p.K + p.tail_kper - 1) / p.tail_kper);
+        }
+        return;
+    }
     tile_coords(p, tm, tn, z);
     const int kbeg = z * p.kper;
     pp_tile<AK, BKM, EPIK, BN>(p, tm, tn, kbeg, min(p.K, kbeg + p.kper), z == 0,
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     p.epilogue = XL_EPI_NONE; p.out_f32 = 1; p.atomic_out = 1; p.splitk = g.splitk; p.kper = pr.kper; p.vec_epi = 0;
     p.alpha = 1.0f; p.p_drop = 0.f; p.inv_keep = 1.f; p.seed = 0; p.step_seed = nullptr;
     p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr; p.colsum_ws = nullptr;
-    p.slab = g.slab; p.tickets = g.tickets; p.vec_epi = pr.vec;
+    p.slab = g.slab; p.tickets = g.tickets; p.vec_epi = pr.vec; p.tail_tiles = 0; p.tail_kper = 0;
     if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
     const int tl = t - g.tile_start[i];
     const int kbeg = z * pr.kper;

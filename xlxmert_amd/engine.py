@@ -643,11 +643,10 @@ class Engine:
         if two_streams and self.dev.type == "cuda":
             self.side, dwv, dwl = reserve_streams(self.dev)
             self._dw = {"v": dwv, "l": dwl}
-        # split-K slab workspaces of the streams that launch weight gradients (ops.gemm_workspace): no fp32 atomics on the
-        # gradient buffer and a fixed summation order (deterministic weight gradients).  Opt-in (XL_GEMM_SLABS=1): measured 1-3 % slower
-        # than the atomics -- L2 atomics are fire-and-forget, the slabs add a write + read of every partial tile.
+        # slab workspaces (xl_gemm_set_workspace) of every stream this engine launches contractions on: the tail split of
+        # the 10k-codebook contractions, and -- opt-in, XL_GEMM_WGRAD_SLABS=1 -- deterministic weight gradients
         self._slab_ws = []
-        if self.dev.type == "cuda" and hasattr(ops, "gemm_workspace") and os.environ.get("XL_GEMM_SLABS", "0") != "0":
+        if self.dev.type == "cuda" and hasattr(ops, "gemm_workspace") and os.environ.get("XL_GEMM_SLABS", "1") != "0":
             streams = list(self._dw.values()) if self._dw is not None else []
             streams += [torch.cuda.current_stream()] + ([self.side] if self.side is not None else [])
             for s_ in streams:

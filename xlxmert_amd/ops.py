@@ -108,10 +108,12 @@ class HipOps:
         ints = [ia(*[int(v) for v in cols[j]]) for j in range(3, 9)]
         self.lib.call("xl_gemm_wgrad_group", *ptrs, *ints, n, self.dt, self._stream())
 
+    def set_gemm_wgrad_slabs(self, on):
+        """weight-gradient K splits through the slab workspace (fixed summation order) instead of fp32 atomics."""
+        self.lib.call("xl_set_gemm_wgrad_slabs", int(on))
+
     def gemm_workspace(self, slabs=256, stream=None):
-        """allocate and register the split-K slab workspace of `stream` (default: the current one): weight-gradient launches
-        on that stream then combine their K splits in memory instead of through fp32 atomics on the gradient buffer.
-        Returns the tensor (the caller keeps it alive)."""
+        """allocate and register the slab workspace of `stream` (default: the current one): xl_gemm_set_workspace."""
         st = stream if stream is not None else torch.cuda.current_stream()
         key = (st.device_index, st.cuda_stream, int(slabs))
         if key not in _SLAB_WS:               # one per stream for the life of the process: the library keeps the pointer
