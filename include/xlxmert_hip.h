@@ -42,6 +42,10 @@ extern "C" {
 #define XL_EPI_RESIDUAL 2   /* C = dropout(acc+bias) + residual                   HF:276-279, 338-341 */
 #define XL_EPI_DGELU    3   /* C = acc * gelu_erf'(aux)          (backward of XL_EPI_GELU)            */
 #define XL_EPI_TANH     4   /* C = tanh(acc+bias)                                        HF:566-572   */
+#define XL_EPI_ROWMAX   5   /* no C: aux[(n/64)*M + m] = float4{max, sum exp(x - max), argmax (int bits), 0} of x = acc+bias over the
+                             * 64-column segment n/64 of row m -- the sampler's softmax(-1).max(-1) over the 10k codebook without the
+                             * logits ever reaching memory (ref tasks/imggen_model.py:229-235); finish with xl_rowmax_combine.  bf16
+                             * operands, a_kmajor = b_kmajor = 1, M and N multiples of 256 (pad N with zero rows and bias -1e30) */
 
 const char* xl_last_error(void);
 int  xl_version(void);
@@ -256,6 +260,10 @@ int xl_scatter_rows(const void* src, const int* rows, void* dst, int n_rows, int
  * xl_featloss_fwd_bwd gives them no loss and a zero gradient row, and xl_gather_labels hands the cross-entropy the ignore
  * label:  out[r] = rows[r] >= 0 ? labels[rows[r]] : -100. */
 int xl_gather_labels(const int64_t* labels, const int* rows, int64_t* out, int n_rows, void* stream);
+/* Second half of XL_EPI_ROWMAX: per row m, over the n_seg segment records ws[seg*M + m] of the GEMM epilogue:
+ * row_argmax[m] = argmax_n x (lowest index on ties, as torch.max), row_maxprob[m] = softmax(x)[argmax] = 1 / sum_n exp(x_n - max),
+ * row_lse[m] = max + log(sum) (any output may be NULL). */
+int xl_rowmax_combine(const float* ws, int n_seg, int M, float* row_maxprob, int* row_argmax, float* row_lse, void* stream);
 
 /* ---------------------------------------------------------------- optimizer side (ref lxmert_pretrain.py:343-364)
  * sumsq[0] += sum g^2 over n fp32 elements */

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH, EPI_ROWMAX = 0, 1, 2, 3, 4, 5
 
 
 def v2(t, rows, cols, ld):
@@ -85,6 +85,15 @@ class FakeOps:
             acc = acc * gelu_grad(v2(aux, M, N, ldx).float())
         elif epilogue == EPI_TANH:
             acc = torch.tanh(acc)
+        elif epilogue == EPI_ROWMAX:           # no C: per row and 64-column segment {max, sum exp(x - max), argmax bits, 0} -> aux
+            assert N % 64 == 0
+            seg = acc.view(M, N // 64, 64)
+            mx, am = seg.max(-1)
+            se = torch.exp(seg - mx[..., None]).sum(-1)
+            idx = (am + torch.arange(N // 64)[None, :] * 64).to(torch.int32)
+            rec = torch.stack([mx, se, idx.view(torch.float32), torch.zeros_like(mx)], -1)     # [M, nseg, 4]
+            aux.view(-1)[:(N // 64) * M * 4].copy_(rec.permute(1, 0, 2).reshape(-1))
+            return
         c = v2(C, M, N, ldc)
         if out_f32:
             assert C.dtype == torch.float32
@@ -330,6 +339,19 @@ class FakeOps:
         g = rows.view(-1)[:n_rows].long()
         keep = g >= 0                    # padding entries are skipped
         torch.as_strided(dst, (int(g.max()) + 1, N), (ld_dst, 1))[g[keep]] = v2(src, n_rows, N, ld_src)[keep]
+
+    def rowmax_combine(self, ws, n_seg, M, row_maxprob, row_argmax, row_lse=None):
+        rec = ws.view(-1)[:n_seg * M * 4].view(n_seg, M, 4)
+        mx, se, idx = rec[..., 0], rec[..., 1], rec[..., 2].contiguous().view(torch.int32)
+        gmx = mx.max(0).values
+        tot = (se * torch.exp(mx - gmx[None, :])).sum(0)
+        cand = torch.where(mx == gmx[None, :], idx, torch.full_like(idx, 2 ** 31 - 1))
+        if row_argmax is not None:
+            row_argmax[:M].copy_(cand.min(0).values)
+        if row_maxprob is not None:
+            row_maxprob[:M].copy_(1.0 / tot)
+        if row_lse is not None:
+            row_lse[:M].copy_(gmx + torch.log(tot))
 
     def gather_labels(self, labels, rows, out, n_rows):
         g = rows.view(-1)[:n_rows].long()

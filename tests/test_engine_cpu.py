@@ -349,3 +349,36 @@ def test_ar_sampler_vs_reference_fixture(mode):
     g = load_golden("sampler_ar_tiny")
     eng, sd = make_sampler_engine(g, FakeOps(torch.float32))
     check_ar_sampler(g, eng, mode)
+
+
+def test_fused_predict_equals_logits_path_bf16(monkeypatch):
+    """Sampler on the bf16 path: the codebook contraction ending in the row-max epilogue (no logits in memory) gives the codes,
+    masks and probabilities of the path that materialises the fp32 logits (engine sequencing + the host restatement of
+    XL_EPI_ROWMAX / xl_rowmax_combine; the kernels themselves are compared on the GPU).  4 images x 8x8 grid = 256 rows, a
+    100-entry codebook padded to 256."""
+    g = load_golden("sampler_tiny")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    B, L, grid = 4, 8, 8
+    ids = torch.from_numpy(g["in_input_ids"])[:1].expand(B, -1).clone()
+    ids[1:, 2] = (ids[1:, 2] + torch.arange(1, B)) % (cfg.vocab_size - 1) + 1
+    pos = torch.from_numpy(O.box_position(grid)).unsqueeze(0).expand(B, -1, -1)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("XL_FUSED_PREDICT", fused)
+        store = ParamStore(cfg, "cpu", torch.bfloat16, task="vis_mask")
+        store.load_named(sd)
+        eng = Engine(cfg, store, FakeOps(torch.bfloat16), B, L, grid * grid, need_lang=False)
+        eng.sync_compute_weights()
+        eng.set_inputs(ids, ids > 0, None, pos, cluster_ids=torch.zeros(B, grid * grid, dtype=torch.long),
+                       vis_mask=torch.ones(B, grid * grid, dtype=torch.bool))
+        assert eng.fused_predict_available() == (fused == "1")
+        cid, code, prob = eng.sample_codes_nar(3)
+        outs[fused] = (cid.clone(), prob.clone(), eng.vmask.clone(), [c for c in eng.ops.calls if c[0] == "gemm" and c[-1] == 5])
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][2], outs["0"][2])
+    assert (outs["1"][1] - outs["0"][1]).abs().max().item() < 1e-5
+    assert len(outs["1"][3]) == 3 and not outs["0"][3]

@@ -1,5 +1,7 @@
 """GPU parity of the whole path: engine on HipOps (C-ABI kernels on a real MI355X) against the committed golden
 fixtures (outputs of the reference itself) and against the CPU oracle on seeded inputs."""
+import os
+
 import pytest
 import torch
 
@@ -565,6 +567,19 @@ def test_sampler_full_size_properties_bf16():
     assert torch.equal(cid1, cid2) and cid1.min().item() >= 0 and cid1.max().item() < cfg.num_clusters
     assert torch.equal(code1.view(B * V, -1), store.centroids_c[cid1.view(-1)])
     assert eng.vmask.sum(1).eq(16).all()            # last step re-masks int(1/4 * 64) positions per image
+    # the runs above ended the codebook contraction in the row-max epilogue (no logits in memory); the path that writes the
+    # fp32 logits and reduces them with xl_ce_fwd_bwd must give the same codes
+    assert eng.fused_predict_available() and eng.ops.block is not None
+    prob_fused = eng.row_maxprob.clone()
+    os.environ["XL_FUSED_PREDICT"] = "0"
+    try:
+        assert not eng.fused_predict_available()
+        cid3 = eng.sample_codes_nar(4)[0].clone()
+    finally:
+        del os.environ["XL_FUSED_PREDICT"]
+    torch.cuda.synchronize()
+    assert torch.equal(cid1, cid3)
+    assert (prob_fused - eng.row_maxprob).abs().max().item() < 1e-5
 
 
 # ---------------------------------------------------------------- language pretraining branches

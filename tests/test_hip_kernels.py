@@ -323,6 +323,42 @@ def test_gemm_wgrad_group(rows, dtype, slab_ws):
         assert torch.equal(pr[2].cpu()[:, :n], ref), f"dW {m}x{n}: max abs diff {(pr[2].cpu()[:, :n] - ref).abs().max().item()}"
 
 
+@pytest.mark.parametrize("M,N,K,n_real", [(256, 256, 64, 256), (512, 768, 200, 700), (1024, 10240, 2048, 10000)])
+def test_gemm_rowmax_epilogue(M, N, K, n_real):
+    """XL_EPI_ROWMAX + xl_rowmax_combine: argmax / max softmax probability / log-sum-exp of x = A B^T + bias per row without C in
+    memory, against the same contraction written out in fp32 (same kernel, same accumulation order: identical argmax) and
+    softmax on the host; columns >= n_real are padding (zero operand rows, bias -1e30)."""
+    g = torch.Generator().manual_seed(M + N)
+    ops = hip(torch.bfloat16)
+    A = rnd(g, M, K, dtype=torch.bfloat16).cuda()
+    B = rnd(g, N, K, dtype=torch.bfloat16)
+    bias = rnd(g, N)
+    B[n_real:] = 0
+    bias[n_real:] = -1e30
+    A[7] = 0                                           # a row of ties at the bias maximum
+    bias[5], bias[300 % n_real] = 9.0, 9.0
+    B, bias = B.cuda(), bias.cuda()
+    ops.set_gemm_pingpong(2)
+    try:
+        C = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+        ops.gemm(A, B, C, bias, None, None, M, N, K, K, K, N, out_f32=True)
+        ws = torch.zeros((N // 64) * M * 4, device="cuda")
+        prob, arg, lse = torch.zeros(M, device="cuda"), torch.zeros(M, dtype=torch.int32, device="cuda"), torch.zeros(M, device="cuda")
+        for rep in range(2):
+            ops.gemm(A, B, None, bias, None, ws, M, N, K, K, K, N, epilogue=5)
+            ops.rowmax_combine(ws, N // 64, M, prob, arg, lse)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_pingpong(1)
+    x = C.double().cpu()[:, :n_real]
+    ref_max, ref_arg = x.max(-1)
+    assert torch.equal(arg.cpu().long(), ref_arg), (arg.cpu().long() != ref_arg).sum().item()
+    assert arg[7].item() == 5
+    ref_lse = torch.logsumexp(x, -1)
+    assert (lse.cpu().double() - ref_lse).abs().max().item() < 1e-4
+    assert (prob.cpu().double() - torch.exp(ref_max - ref_lse)).abs().max().item() < 1e-5
+
+
 def test_gemm_in_place_residual_bf16(pingpong):
     """C aliases the residual (cross-attention context gradient accumulates into the other stream's buffer)."""
     g = torch.Generator().manual_seed(9)

@@ -311,10 +311,15 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     XL_CHECK_ARG(M > 0 && N > 0 && K > 0, XL_ERR_BAD_SHAPE, "xl_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     XL_CHECK_ARG(in_dtype == XL_F32 || in_dtype == XL_BF16, XL_ERR_BAD_DTYPE, "xl_gemm: bad in_dtype %d", in_dtype);
     XL_CHECK_ARG(out_dtype == in_dtype || out_dtype == XL_F32, XL_ERR_BAD_DTYPE, "xl_gemm: bad out_dtype %d", out_dtype);
-    XL_CHECK_ARG(A && B && C, XL_ERR_BAD_ARG, "xl_gemm: null operand");
+    XL_CHECK_ARG(A && B && (C || epilogue == XL_EPI_ROWMAX), XL_ERR_BAD_ARG, "xl_gemm: null operand");
     XL_CHECK_ARG(lda >= (a_kmajor ? K : M) && ldb >= (b_kmajor ? K : N) && ldc >= N, XL_ERR_BAD_SHAPE,
                  "xl_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
-    XL_CHECK_ARG(epilogue >= XL_EPI_NONE && epilogue <= XL_EPI_TANH, XL_ERR_BAD_ARG, "xl_gemm: bad epilogue %d", epilogue);
+    XL_CHECK_ARG(epilogue >= XL_EPI_NONE && epilogue <= XL_EPI_ROWMAX, XL_ERR_BAD_ARG, "xl_gemm: bad epilogue %d", epilogue);
+    if (epilogue == XL_EPI_ROWMAX)
+        XL_CHECK_ARG(in_dtype == XL_BF16 && a_kmajor && b_kmajor && M % 256 == 0 && N % 256 == 0 && K % 8 == 0 && lda % 8 == 0 &&
+                     ldb % 8 == 0 && aux && aligned16(aux) && aligned16(A) && aligned16(B) && (!bias || aligned16(bias)) &&
+                     !accumulate && !colsum_out && g_use_tr_read, XL_ERR_BAD_SHAPE,
+                     "xl_gemm: XL_EPI_ROWMAX takes bf16 K-major operands with M, N multiples of 256 (M=%d N=%d) and a 16-byte aligned aux", M, N);
     if (epilogue == XL_EPI_RESIDUAL) XL_CHECK_ARG(residual && ldr >= N, XL_ERR_BAD_ARG, "xl_gemm: residual missing");
     if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU) XL_CHECK_ARG(aux && ldx >= N, XL_ERR_BAD_ARG, "xl_gemm: aux missing");
     XL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, XL_ERR_BAD_ARG, "xl_gemm: p_drop %f", p_drop);
@@ -350,7 +355,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // workgroups they drop into the 64 idle CUs instead of competing for all of them (-0.5 ms per step)
     long pp_blocks = t256n;
     if (may_split && t256n < 256 && K >= 1024) pp_blocks = t256n * std::max<long>(1, std::min<long>(256 / t256n, K / 512));
-    const bool use_pp = pp_ok && (pp_mode == 2 || (pp_mode == 1 && pp_blocks >= pp_min_tiles));
+    const bool use_pp = pp_ok && (pp_mode == 2 || (pp_mode == 1 && pp_blocks >= pp_min_tiles) || epilogue == XL_EPI_ROWMAX);
     const int tile = use_pp ? 256 : mfma_ok ? 128 : 64;
     p.tiles_m = (M + tile - 1) / tile;
     // 256x192 tiles (forward / dX layouts with a fast epilogue, every tile interior): taken when they shorten the launch,
@@ -361,7 +366,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     const int bn192_mode = g_gemm_bn192;
     int bn = 256;
     if (use_pp && bn192_mode && a_kmajor && M % 256 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate &&
-        colsum_out == nullptr && epilogue != XL_EPI_TANH) {
+        colsum_out == nullptr && epilogue != XL_EPI_TANH && epilogue != XL_EPI_ROWMAX) {
         const long t256 = (long)p.tiles_m * ((N + 255) / 256), t192 = (long)p.tiles_m * (N / 192);
         const double c256 = (double)((t256 + 255) / 256), c192 = 0.8 * (double)((t192 + 255) / 256);
         if (bn192_mode == 2 || c192 < c256) bn = 192;
@@ -393,6 +398,10 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     }
     // 16-byte epilogue accesses need 8-element (bf16) / 4-element (fp32) aligned rows of C / residual / aux
     p.vec_epi = aligned16(C) && (out_dtype == XL_F32 ? ldc % 4 == 0 : ldc % 8 == 0);
+    if (epilogue == XL_EPI_ROWMAX) {
+        XL_CHECK_ARG(use_pp, XL_ERR_BAD_SHAPE, "xl_gemm: XL_EPI_ROWMAX needs the ping-pong kernel's operand ranges");
+        p.vec_epi = 1;
+    }
     if (epilogue == XL_EPI_RESIDUAL) p.vec_epi = p.vec_epi && aligned16(residual) && ldr % 8 == 0;
     if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU) p.vec_epi = p.vec_epi && aligned16(aux) && ldx % 8 == 0;
     // fast (templated) epilogue: aligned rows, a kind that has one, plain stores

@@ -407,7 +407,27 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
             unpack8(op.row[ps], av);
             gelu_grad_mul8(v, av);
         }
-        if (p.out_f32) {
+        if constexpr (EPI == XL_EPI_ROWMAX) {
+            // (max, sum exp(x - max), argmax) of this row's 64-column segment: 8 columns per lane, then the 8 lanes of the row
+            float mx = v[0];
+            int idx = n;
+#pragma unroll
+            for (int e = 1; e < 8; ++e) if (v[e] > mx) { mx = v[e]; idx = n + e; }
+            float se = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) se += __expf(v[e] - mx);
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64);
+                const int oi = __shfl_xor(idx, o, 64);
+                const float nm = fmaxf(mx, omx);
+                se = se * __expf(mx - nm) + ose * __expf(omx - nm);
+                idx = (omx > mx || (omx == mx && oi < idx)) ? oi : idx;
+                mx = nm;
+            }
+            if (c8 == 0)
+                reinterpret_cast<float4*>(p.aux)[(size_t)(nq >> 6) * p.M + m] = make_float4(mx, se, __int_as_float(idx), 0.f);
+        } else if (p.out_f32) {
             float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
             *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -432,6 +432,9 @@ static hipError_t launch_pp_layout(const GemmParams& p, int epik, int bn, int nb
             case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU>(p, nblk, st);
             case XL_EPI_RESIDUAL: return launch_pp_one<AK, BKM, XL_EPI_RESIDUAL>(p, nblk, st);
             case XL_EPI_DGELU: return launch_pp_one<AK, BKM, XL_EPI_DGELU>(p, nblk, st);
+            case XL_EPI_ROWMAX:
+                if constexpr (BKM) return launch_pp_one<AK, BKM, XL_EPI_ROWMAX>(p, nblk, st);
+                return hipErrorInvalidValue;
             default: break;
         }
     }

@@ -1533,6 +1533,47 @@ extern "C" int xl_scatter_rows(const void* src, const int* rows, void* dst, int 
     return move_rows(src, rows, dst, n_rows, N, ld_src, ld_dst, dtype, stream, true);
 }
 
+// second half of the GEMM's XL_EPI_ROWMAX epilogue over the [n_seg][M] segment records: 64 rows per block, four threads per
+// row (every fourth segment each: four independent load chains per row instead of one of 160), merged through LDS
+__device__ __forceinline__ void rowmax_merge(float& mx, float& se, int& idx, float omx, float ose, int oi) {
+    const float nm = fmaxf(mx, omx);
+    se = se * __expf(mx - nm) + ose * __expf(omx - nm);
+    idx = (omx > mx || (omx == mx && oi < idx)) ? oi : idx;
+    mx = nm;
+}
+__global__ __launch_bounds__(256) void rowmax_combine_kernel(const float4* __restrict__ ws, int n_seg, int M, float* row_maxprob,
+                                                             int* row_argmax, float* row_lse) {
+    __shared__ float4 part[4][64];
+    const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + r;
+    float mx = -INFINITY, se = 0.f;
+    int idx = 0x7fffffff;
+    if (m < M)
+        for (int s = q; s < n_seg; s += 4) {
+            const float4 rec = ws[(size_t)s * M + m];
+            rowmax_merge(mx, se, idx, rec.x, rec.y, __float_as_int(rec.z));
+        }
+    part[q][r] = make_float4(mx, se, __int_as_float(idx), 0.f);
+    __syncthreads();
+    if (q != 0 || m >= M) return;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const float4 o = part[k][r];
+        if (o.y > 0.f) rowmax_merge(mx, se, idx, o.x, o.y, __float_as_int(o.z));
+    }
+    if (row_argmax) row_argmax[m] = idx;
+    if (row_maxprob) row_maxprob[m] = 1.0f / se;
+    if (row_lse) row_lse[m] = mx + logf(se);
+}
+
+extern "C" int xl_rowmax_combine(const float* ws, int n_seg, int M, float* row_maxprob, int* row_argmax, float* row_lse, void* stream) {
+    XL_CHECK_ARG(ws && n_seg > 0 && M > 0 && aligned16(ws), XL_ERR_BAD_ARG, "xl_rowmax_combine: bad args");
+    hipLaunchKernelGGL(rowmax_combine_kernel, dim3((M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(ws), n_seg, M, row_maxprob, row_argmax, row_lse);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
 extern "C" int xl_gather_labels(const int64_t* labels, const int* rows, int64_t* out, int n_rows, void* stream) {
     XL_CHECK_ARG(labels && rows && out && n_rows > 0, XL_ERR_BAD_ARG, "xl_gather_labels: bad args (n_rows=%d)", n_rows);
     hipLaunchKernelGGL(gather_labels_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, labels, rows, out, n_rows);

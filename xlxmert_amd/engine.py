@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from .ops import EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_TANH
+from .ops import EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_ROWMAX, EPI_TANH
 
 
 class _Att:
@@ -1157,6 +1157,39 @@ class Engine:
                             self.MV, self.K, self.K, self.Kp, 1.0)
         return self.row_maxprob, self.row_argmax
 
+    # Sampling never needs the logits themselves, only softmax(-1).max(-1): on the bf16 path the codebook contraction ends in
+    # the XL_EPI_ROWMAX epilogue (per row and 64-column segment: max, sum exp, argmax) and xl_rowmax_combine finishes the rows --
+    # 42 MB of segment records instead of writing and re-reading the 655 MB fp32 [B*V, 10000] matrix.  The codebook is padded
+    # to a multiple of 256 rows for it (zero centroids with bias -1e30: never the maximum, exp() = 0).
+    def fused_predict_available(self):
+        return (self.cdtype == torch.bfloat16 and self.MV % 256 == 0 and self.F % 8 == 0 and hasattr(self.ops, "rowmax_combine")
+                and os.environ.get("XL_FUSED_PREDICT", "1") != "0")
+
+    def _prepare_fused_predict(self):
+        Kq = (self.K + 255) // 256 * 256
+        if getattr(self, "_cent_pad", None) is None or self._cent_pad.shape[0] != Kq:
+            self._cent_pad = torch.zeros(Kq, self.F, dtype=self.cdtype, device=self.dev)
+            self._bias_pad = torch.full((Kq,), -1e30, dtype=torch.float32, device=self.dev)
+            self._rowmax_ws = torch.zeros((Kq // 64) * self.MV * 4, dtype=torch.float32, device=self.dev)
+        self._cent_pad[:self.K].copy_(self.store.centroids_c)          # (frozen, but set_centroids may have replaced it)
+        self._bias_pad[:self.K].copy_(self.hd["bc"][0])
+
+    def predict_codes_fused(self):
+        """head_forward(want_logits=False) must have run: self.feat -> (max prob, argmax) per row, no logits in memory."""
+        Kq = self._cent_pad.shape[0]
+        self.ops.gemm(self.feat, self._cent_pad, None, self._bias_pad, None, self._rowmax_ws, self.MV, Kq, self.F, self.F, self.F, Kq,
+                      epilogue=EPI_ROWMAX)
+        self.ops.rowmax_combine(self._rowmax_ws, Kq // 64, self.MV, self.row_maxprob, self.row_argmax, self.row_lse)
+        return self.row_maxprob, self.row_argmax
+
+    def _predict_step(self, fused):
+        if fused:
+            self.head_forward(want_logits=False)
+            self.predict_codes_fused()
+        else:
+            self.head_forward()
+            self.predict_codes()
+
     def sample_codes_nar(self, n_steps=4):
         """Iterative Mask-Predict sampling (ref tasks/imggen_model.py:169-243) without a host round trip between steps:
         re-mask the lowest-confidence positions -> encoder -> codebook head -> softmax-max / argmax -> keep the predictions
@@ -1167,6 +1200,9 @@ class Engine:
         st = self.store
         self.use_codebook, self.has_vmask = True, True
         self.cid.zero_()
+        fused = self.fused_predict_available()
+        if fused:
+            self._prepare_fused_predict()
         for i in range(n_steps):
             n_mask = int((n_steps - i) / n_steps * V)                      # ref :201-202 (host arithmetic on the step index)
             if i == 0:
@@ -1174,8 +1210,7 @@ class Engine:
             else:
                 ops.remask_lowest(self.row_maxprob, self.vmask, B, V, n_mask)
             self.encoder_forward(want_pooled=False)                        # codebook_gather == where(mask, mask_feat, vis_emb(ids))
-            self.head_forward()
-            self.predict_codes()
+            self._predict_step(fused)
             ops.sampler_update(self.row_argmax, self.vmask, self.cid, B * V)
         ops.codebook_gather(self.cid, None, st.centroids_c, st.view("mask_feat"), self.feats, self.MV, self.F)
         return self.cid, self.feats, self.row_maxprob
@@ -1195,6 +1230,9 @@ class Engine:
             self.visited = torch.zeros(B, V, dtype=torch.uint8, device=self.dev)
         self.visited.zero_()
         positions = list(positions) if positions is not None else None
+        fused = self.fused_predict_available()
+        if fused:
+            self._prepare_fused_predict()
         for i in range(n_steps):
             cur = -1
             if mode == "random":
@@ -1203,8 +1241,7 @@ class Engine:
             elif mode == "tlbr":
                 cur = i
             self.encoder_forward(want_pooled=False)
-            self.head_forward()
-            self.predict_codes()
+            self._predict_step(fused)
             ops.sampler_ar_update(self.row_maxprob, self.row_argmax, self.visited, self.vmask, self.cid, B, V, cur)
             if trace is not None:
                 trace.append(self.vmask.clone())

@@ -10,7 +10,7 @@ import torch
 from ._lib import XlError, get_lib
 
 XL_F32, XL_BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH, EPI_ROWMAX = 0, 1, 2, 3, 4, 5
 
 TORCH_DTYPE = {XL_F32: torch.float32, XL_BF16: torch.bfloat16}
 _SLAB_WS = {}
@@ -230,6 +230,11 @@ class HipOps:
 
     def scatter_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
         self.lib.call("xl_scatter_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
+
+    def rowmax_combine(self, ws, n_seg, M, row_maxprob, row_argmax, row_lse=None):
+        """second half of gemm(epilogue=EPI_ROWMAX, aux=ws): per-row argmax / max softmax probability / log-sum-exp."""
+        self.lib.call("xl_rowmax_combine", self._p(ws), n_seg, M, self._p(row_maxprob), self._p(row_argmax), self._p(row_lse),
+                      self._stream())
 
     def gather_labels(self, labels, rows, out, n_rows):
         self.lib.call("xl_gather_labels", self._p(labels), self._p(rows), self._p(out), n_rows, self._stream())
