@@ -275,7 +275,7 @@ def _dp_worker_modes(rank, world, port, out_dir):
     trv = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
                        total_steps=10, lr=1e-2, task="vqa", num_answers=A, bucket_mb=0.05)
     trv.step(O.make_vqa_inputs(oc, A, 600 + rank, B, L, grid))
-    assert trv.verify_replicas() == [] and len(trv._works) > 3
+    assert trv.verify_replicas() == [] and len(trv._works) >= 2       # (paired weight-gradient launches report every second layer)
     res["vqa"] = {k: trv.store.view(k).clone() for k in trv.store.names()}
     # (3) task round-robin on one parameter set with the QA head riding on every branch
     NQ = 11

@@ -504,6 +504,8 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
         }
     if (g_wgrad_slabs < 0) g_wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
     if (disjoint && g_wgrad_slabs) slab_workspace(st, total, total * splitk, &g.slab, &g.tickets);
+    g.rmw = (disjoint && splitk == 1) ? 1 : 0;      // one workgroup per output tile: it owns the tile (two layers' weight gradients in
+                                                    // one launch: 216 tiles, no K split, no atomics)
     int acc = 0;
     for (int i = 0; i < count; ++i) {
         GroupProblem& pr = g.prob[i];

@@ -606,6 +606,7 @@ struct GroupProblem {
 struct GroupParams {
     int count, splitk;
     float* slab; int* tickets;         // split-K through slabs (null: fp32 atomics)
+    int rmw;                           // no K split and no two problems share any of C: plain vector read-modify-write, no atomics
     int tile_start[9];                 // prefix sums of the problems' 256x256 tile counts
     GroupProblem prob[8];
 };

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     const int tl = t - g.tile_start[i];
     const int kbeg = z * pr.kper;
     pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, kbeg, min(pr.K, kbeg + pr.kper), z == 0,
-                              g.slab != nullptr ? t : -1, z, (pr.K + pr.kper - 1) / pr.kper);
+                              (g.slab != nullptr || g.rmw) ? t : -1, z, (pr.K + pr.kper - 1) / pr.kper);
 }
 
 hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st) {

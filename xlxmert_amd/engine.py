@@ -104,7 +104,7 @@ class SelfAttBlock:
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                      e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws)      # + d(b_q | b_k | b_v)
         e.wgrad_defer(dqkv, self.x, p.gwqkv, 3 * d, d, M, 3 * d, d, d)
-        e.wgrad_flush()
+        e.wgrad_flush(pair=True)        # this layer's four weight gradients: launched together with the next layer's
         ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)
 
@@ -539,6 +539,7 @@ class Engine:
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)       # step part of the dropout seeds
         self._tmp = {}
         self._pending = {"v": [], "l": []}
+        self._held, self._held_layers, self._gen = {"v": [], "l": []}, {"v": 0, "l": 0}, {"v": 0, "l": 0}
         self._pending_block = {"v": "", "l": ""}
         self.act_bytes = 0
         st, d = store, self.d
@@ -723,22 +724,42 @@ class Engine:
         self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc))
         self._pending_block[self._tag] = getattr(self.ops, "block", "")
 
-    def wgrad_flush(self):
+    PAIR_LAYERS = int(os.environ.get("XL_WGRAD_PAIR", "2"))          # layers per weight-gradient launch (1: every layer its own)
+
+    def wgrad_flush(self, pair=False, force=False):
         """queue the registered weight gradients as ONE grouped launch on the companion stream of the current stream
-        (after everything queued so far): off the dX dependency chain, and one K split of 2-7 for the whole group.
-        An FFN block leaves its two problems pending for the attention block of the same layer: four per launch."""
-        probs = self._pending[self._tag]
+        (after everything queued so far): off the dX dependency chain.  An FFN block leaves its two problems pending for the
+        attention block of the same layer: four per layer.
+        pair=True (self-attention + FFN layers): the layer's four problems are HELD and launched together with the next
+        layer's -- 216 output tiles of 256x256 fill the chip without a K split, so every tile has one writer and the launch needs
+        no atomics (two launches with a K split of 2 and a pass of fp32 atomics each: 2 x 247 us per visual layer pair, one
+        launch: ~390 us).  The held problems read backward scratch of their layer, so the scratch alternates between two sets
+        (tmp(): generation); force=True launches whatever is held (end of a stream's backward)."""
+        tag = self._tag
+        if pair:
+            self._held[tag] += self._pending[tag]
+            self._pending[tag] = []
+            self._held_layers[tag] += 0 if force else 1
+            if not force:
+                self._gen[tag] ^= 1             # the next layer writes the other scratch set
+            if not self._held[tag] or (self._held_layers[tag] < self.PAIR_LAYERS and not force):
+                return
+            probs, self._held[tag], self._held_layers[tag] = self._held[tag], [], 0
+        else:
+            probs, self._pending[tag] = self._pending[tag], []
         if not probs:
             return
-        self._pending[self._tag] = []
-        self.ops.block = self._pending_block[self._tag]
-        dw = self._dw.get(self._tag) if (self._dw is not None and self.side is not None) else None
-        if dw is None:
-            return self.ops.gemm_wgrad_group(probs)
-        self.ops.stream_fork(torch.cuda.current_stream(), dw)
-        with torch.cuda.stream(dw):
-            self.ops.gemm_wgrad_group(probs)
-        self._dw_busy[self._tag] = True
+        self.ops.block = self._pending_block[tag]
+        dw = self._dw.get(tag) if (self._dw is not None and self.side is not None) else None
+        for i in range(0, len(probs), 8):       # (xl_gemm_wgrad_group takes up to 8 problems)
+            chunk = probs[i:i + 8]
+            if dw is None:
+                self.ops.gemm_wgrad_group(chunk)
+                continue
+            self.ops.stream_fork(torch.cuda.current_stream(), dw)
+            with torch.cuda.stream(dw):
+                self.ops.gemm_wgrad_group(chunk)
+            self._dw_busy[tag] = True
 
     def wgrad_sync(self):
         """current stream waits for the weight-gradient GEMMs queued so far by this stream (nothing to wait for when none
@@ -748,8 +769,9 @@ class Engine:
             self._dw_busy[self._tag] = False
 
     def tmp(self, name, M, N):
-        """backward scratch, shared by all blocks of one stream (sized for the largest user)."""
-        key = (name, N, self._tag)
+        """backward scratch, shared by all blocks of one stream (sized for the largest user); two sets per stream, alternating
+        with the layers whose weight gradients are held for a paired launch (wgrad_flush)."""
+        key = (name, N, self._tag, self._gen[self._tag])
         if key not in self._tmp:
             self._tmp[key] = torch.zeros(self.MX, N, dtype=self.cdtype, device=self.dev)
         return self._tmp[key][:M]
@@ -819,8 +841,8 @@ class Engine:
         assert not self._pending["v"] and not self._pending["l"], "weight gradients registered but never flushed"
         self.flush_reductions()
         self.wgrad_sync()
-        if self.grad_ready is not None:
-            self._report("v", hi)
+        if self.grad_ready is not None and not self._held["v"] and not self._held["l"]:   # (a held layer's weight gradients are
+            self._report("v", hi)                                    #  not final yet: the next report covers its range)
 
     def _report(self, lane, hi, flush=False):
         lo = self._lane_lo[lane]
@@ -832,8 +854,9 @@ class Engine:
         """inside lang_stream(): the language-range gradients below `hi` are final once the language stream and its
         weight-gradient companion stream reach this point: the language stream waits for the companion and issues the
         report itself (a third stream for this would need a fifth hardware queue: see reserve_streams)."""
-        if self.grad_ready is None:
+        if self.grad_ready is None or (self._held["l"] and not flush):
             return
+        assert not self._held["l"]
         self.wgrad_sync()
         self._report("l", hi, flush)
 
@@ -1266,6 +1289,8 @@ class Engine:
         """start of a backward pass that ACCUMULATES into the gradient buffer (the nn.Module path: zeroing is the caller's
         zero_grad(), as with autograd): second stages of the column reductions deferred until encoder_backward ends."""
         self.defer_reductions(True)
+        assert not self._held["v"] and not self._held["l"]
+        self._gen = {"v": 0, "l": 0}
         self.grad_is_zero = False
         self._lane_lo = {"v": 0, "l": self.store.language_range()[0]}
 
@@ -1330,6 +1355,8 @@ class Engine:
                 with self.lang_stream():
                     blk["ffn_l"].bwd(GA[:ML], GB[:ML])
                     blk["sa_l"].bwd(GB[:ML], GA[:ML])
+                    if i == 0:                  # the language side of the cross layers is reported by the main stream (below):
+                        self.wgrad_flush(pair=True, force=True)      # nothing of it may stay held into the language stack
                     self.flush_reductions()
                     self.wgrad_sync()
             if blk["vis_on"]:
@@ -1348,6 +1375,7 @@ class Engine:
                 sa.bwd(GB[:ML], GA[:ML])
                 self.flush_reductions()
                 self._ready_lang(st.range_of(f"bert.encoder.layer.{i}.")[1])
+            self.wgrad_flush(pair=True, force=True)      # an odd layer left over
             e = "bert.embeddings"
             if self.p_hid > 0:
                 ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
@@ -1365,6 +1393,8 @@ class Engine:
             sa, ffn = self.vis_layers[i]
             ffn.bwd(GA[ML:], GB[ML:])
             sa.bwd(GB[ML:], GA[ML:])
+            if i == 0:
+                self.wgrad_flush(pair=True, force=True)
             self._ready(f"bert.encoder.r_layers.{i}.")
         # ---- visual feature encoder (HF:468-476) + codebook input
         v = "bert.encoder.visn_fc"
