@@ -447,9 +447,48 @@ def gen_sampler(name, cfg, seed, B, L, grid, n_steps):
     print(name, "steps", n_steps, "final code norm", float(code.norm()))
 
 
+def gen_vismask(name, cfg, seed, B, L, grid):
+    """LxmertModel.forward with a visual_attention_mask (HF:760-770; None in every caller of the reference's drivers) and
+    output_hidden_states: real grid features in, ragged visual masks; also the gradients of a fixed linear functional of the
+    three outputs, so that the masked attention backward is pinned too."""
+    torch.manual_seed(0)
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    g = torch.Generator().manual_seed(seed + 2)
+    V = grid * grid
+    feats = torch.randn(B, V, cfg.visual_feat_dim, generator=g)
+    n_keep = torch.randint(V // 2, V + 1, (B,), generator=g)
+    vmask = (torch.rand(B, V, generator=g).argsort(1).argsort(1) < n_keep[:, None]).long()
+    wl, wv, wp = (torch.randn(s_, generator=g) for s_ in ((B, L, cfg.hidden_size), (B, V, cfg.hidden_size), (B, cfg.hidden_size)))
+    m.zero_grad(set_to_none=True)
+    bo = m.bert(input_ids=inp["input_ids"], visual_feats=feats, visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+                visual_attention_mask=vmask, token_type_ids=inp["token_type_ids"], output_hidden_states=True, return_dict=True)
+    real = inp["attention_mask"].bool()
+    loss = (bo.language_output * wl * real[..., None]).sum() + (bo.vision_output * wv * vmask[..., None]).sum() + (bo.pooled_output * wp).sum()
+    loss.backward()
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp), in_visual_feats=feats.numpy(), in_visual_attention_mask=vmask.numpy(),
+             w_lang=wl.numpy(), w_vis=wv.numpy(), w_pooled=wp.numpy(), loss=loss.detach().numpy(),
+             lang=bo.language_output.detach().numpy(), vis=bo.vision_output.detach().numpy(), pooled=bo.pooled_output.detach().numpy())
+    for i, h in enumerate(bo.language_hidden_states):
+        d[f"lang_h{i}"] = h.detach().numpy()
+    for i, h in enumerate(bo.vision_hidden_states):
+        d[f"vis_h{i}"] = h.detach().numpy()
+    grads = {k: p_.grad.detach().clone() for k, p_ in m.bert.named_parameters() if p_.grad is not None}
+    d["grad_names"] = np.array(sorted("bert." + k for k in grads))
+    for k, gr in grads.items():
+        d["grad:bert." + k] = gr.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "loss", float(loss), "n_grads", len(grads), "kept keys per image", n_keep.tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
+    if only == ["vismask"]:
+        gen_vismask("vismask_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
+                    num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
+                    num_clusters=50), seed=6420, B=3, L=8, grid=4)
+        sys.exit(0)
     if only == ["full"]:
         gen_full()
         sys.exit(0)
@@ -471,3 +510,4 @@ if __name__ == "__main__":
     gen_sampler_ar("sampler_ar_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=9753, B=3, L=8, grid=4)
     gen_sampler("sampler_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, B=3, L=8, grid=4, n_steps=4)
     gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)
+    gen_vismask("vismask_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=6420, B=3, L=8, grid=4)

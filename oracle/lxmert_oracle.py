@@ -192,10 +192,11 @@ def pooler(sd, cfg, lang, prefix="bert.pooler"):
 
 
 def lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=None,
-                 token_type_ids=None, prefix="bert", return_hidden=False):
+                 token_type_ids=None, prefix="bert", return_hidden=False, visual_attention_mask=None):
     """HF:691-822 -- returns (language_output, vision_output, pooled_output).
-    `visual_attention_mask` is None in every reference caller
-    (ref:x-lxmert/src/pretrain/lxmert_pretrain.py:207)."""
+    `visual_attention_mask` (HF:760-770: the same additive extension as the language mask, applied to the visual KEYS of the
+    visual self-attention and of the language -> vision cross-attention) is None in every reference caller
+    (ref:x-lxmert/src/pretrain/lxmert_pretrain.py:207); pinned by tests/golden/vismask_tiny.npz."""
     dtype = sd[prefix + ".embeddings.word_embeddings.weight"].dtype
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids)
@@ -203,7 +204,8 @@ def lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=No
         token_type_ids = torch.zeros_like(input_ids)
     mask_add = extended_mask(attention_mask, dtype)
     emb = embeddings(sd, cfg, input_ids, token_type_ids, prefix + ".embeddings")
-    out = encoder(sd, cfg, emb, mask_add, visual_feats.to(dtype), visual_pos.to(dtype), None,
+    vis_mask_add = extended_mask(visual_attention_mask, dtype) if visual_attention_mask is not None else None
+    out = encoder(sd, cfg, emb, mask_add, visual_feats.to(dtype), visual_pos.to(dtype), vis_mask_add,
                   prefix + ".encoder", return_hidden)
     lang, vis = out[0], out[1]
     pooled = pooler(sd, cfg, lang, prefix + ".pooler")

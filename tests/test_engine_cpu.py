@@ -382,3 +382,55 @@ def test_fused_predict_equals_logits_path_bf16(monkeypatch):
     assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][2], outs["0"][2])
     assert (outs["1"][1] - outs["0"][1]).abs().max().item() < 1e-5
     assert len(outs["1"][3]) == 3 and not outs["0"][3]
+
+
+def make_vismask_engine(g, ops, device="cpu", dtype=torch.float32):
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    t = lambda k: torch.from_numpy(g[k]).to(device)
+    B, L = g["in_input_ids"].shape
+    V = g["in_visual_feats"].shape[1]
+    store = ParamStore(cfg, device, dtype, task="all")
+    store.load_named(sd)
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=True)
+    eng.sync_compute_weights()
+    eng.set_inputs(t("in_input_ids"), t("in_attention_mask"), t("in_token_type_ids"), t("in_visual_pos"),
+                   visual_feats=t("in_visual_feats").to(dtype), visual_attention_mask=t("in_visual_attention_mask"))
+    return eng
+
+
+def check_vismask(g, eng, tol, gtol):
+    """forward (outputs + every hidden state) and backward (gradients of the fixture's linear functional of the three outputs,
+    through the pooler and the masked attention) against the reference's LxmertModel."""
+    dev = eng.dev
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    B, L, V, d = eng.B, eng.L, eng.V, eng.d
+    lang, vis, pooled = eng.encoder_forward(want_pooled=True)
+    real = t("in_attention_mask").bool()
+    assert maxdiff(lang.view(B, L, d)[real].float(), t("lang")[real]) < tol
+    assert maxdiff(vis.view(B, V, d).float(), t("vis")) < tol and maxdiff(pooled.float(), t("pooled")) < tol
+    lh, vh = eng.hidden_states()
+    assert len(lh) == eng.cfg.l_layers + eng.cfg.x_layers and len(vh) == eng.cfg.r_layers + eng.cfg.x_layers
+    for i, h in enumerate(lh):
+        assert maxdiff(h.view(B, L, d)[real].float(), t(f"lang_h{i}")[real]) < tol, i
+    for i, h in enumerate(vh):
+        assert maxdiff(h.view(B, V, d).float(), t(f"vis_h{i}")) < tol, i
+    eng.store.grad.zero_()
+    vm = t("in_visual_attention_mask")
+    eng.backward_from_outputs((t("w_lang") * real[..., None]).to(eng.cdtype), (t("w_vis") * vm[..., None]).to(eng.cdtype),
+                              t("w_pooled").to(eng.cdtype))
+    worst = 0.0
+    for k in [str(n) for n in g["grad_names"]]:
+        ref = t("grad:" + k).double()
+        got = eng.store.gview(k).double()
+        worst = max(worst, (got - ref).norm().item() / max(ref.norm().item(), 1e-3))      # key biases: exact-zero gradient
+    assert worst < gtol, worst
+
+
+def test_visual_attention_mask_hidden_states_and_pooled_gradient():
+    g = load_golden("vismask_tiny")
+    check_vismask(g, make_vismask_engine(g, FakeOps(torch.float32)), 5e-5, 1e-4)

@@ -765,6 +765,13 @@ def test_plan_replay_equals_eager_steps_bf16(drop):
     assert losses_p[4] != losses_p[7]
 
 
+def test_visual_attention_mask_hidden_states_and_pooled_gradient_fp32():
+    from test_engine_cpu import check_vismask, make_vismask_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("vismask_tiny")
+    check_vismask(g, make_vismask_engine(g, HipOps(torch.float32), device="cuda"), 1e-4, 1e-4)
+
+
 # ---------------------------------------------------------------- QA branch (task_qa model)
 @pytest.mark.parametrize("task", ["qa", "vis_mask", "word_mask", "matched"])
 def test_qa_branch_steps_fp32_match_reference_fixture(task):

@@ -251,3 +251,39 @@ def test_pretraining_module_without_qa_head_and_default_tasks():
             assert maxdiff(params[k].grad.cpu(), ref) <= 1e-4 * max(1.0, ref.abs().max().item()), (task, k)
     with pytest.raises(ValueError):
         m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], cluster_ids=inp["cluster_ids"], task="attr_mask", label_dict={})
+
+
+def test_bert_forward_options_match_reference_fixture():
+    """LxmertModel.forward(visual_attention_mask=, output_hidden_states=True) through the module API, and a loss that reads all
+    three outputs (the pooled_output gradient included) through autograd: outputs, every hidden state and every gradient
+    against the reference's own LxmertModel (fixture vismask_tiny)."""
+    g = load_golden("vismask_tiny")
+    m, oc, sd = make_model(g)
+    m.train(False)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    out = m.bert(input_ids=t("in_input_ids"), visual_feats=t("in_visual_feats"), visual_pos=t("in_visual_pos"),
+                 attention_mask=t("in_attention_mask"), visual_attention_mask=t("in_visual_attention_mask"),
+                 token_type_ids=t("in_token_type_ids"), output_hidden_states=True, return_dict=True)
+    real = t("in_attention_mask").bool()
+    assert maxdiff(out.language_output[real].cpu(), t("lang")[real].cpu()) < 1e-4
+    assert maxdiff(out.vision_output.cpu(), g["vis"]) < 1e-4 and maxdiff(out.pooled_output.cpu(), g["pooled"]) < 1e-4
+    assert len(out.language_hidden_states) == oc.l_layers + oc.x_layers and len(out.vision_hidden_states) == oc.r_layers + oc.x_layers
+    for i, h in enumerate(out.language_hidden_states):
+        assert maxdiff(h[real].cpu(), t(f"lang_h{i}")[real].cpu()) < 1e-4, i
+    for i, h in enumerate(out.vision_hidden_states):
+        assert maxdiff(h.cpu(), g[f"vis_h{i}"]) < 1e-4, i
+    m.zero_grad()
+    vm = t("in_visual_attention_mask")
+    loss = (out.language_output * t("w_lang") * real[..., None]).sum() + (out.vision_output * t("w_vis") * vm[..., None]).sum() + \
+        (out.pooled_output * t("w_pooled")).sum()
+    assert abs(loss.item() - g["loss"].item()) < 1e-4 * max(1.0, abs(g["loss"].item()))
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k in [str(n) for n in g["grad_names"]]:
+        ref = torch.from_numpy(g["grad:" + k]).double()
+        got = params[k].grad.double().cpu()
+        assert (got - ref).norm().item() <= 1e-4 * max(ref.norm().item(), 1e-3), k
+    # tuple form: HF appends the two hidden-state tuples
+    tup = m.bert(input_ids=t("in_input_ids"), visual_feats=t("in_visual_feats"), visual_pos=t("in_visual_pos"),
+                 attention_mask=t("in_attention_mask"), output_hidden_states=True, return_dict=False)
+    assert len(tup) == 5 and len(tup[3]) == oc.l_layers + oc.x_layers

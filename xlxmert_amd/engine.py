@@ -80,7 +80,7 @@ class SelfAttBlock:
         ops = e.ops
         ops.block = self.tag
         ops.gemm(x, p.wqkv, self.qkv, p.bqkv, None, None, M, 3 * d, d, d, d, 3 * d)
-        km = e.kmask if self.masked else None
+        km = e.kmask if self.masked else e.vkmask
         ops.sdpa_fwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, self.ctx, self.lse, e.B, e.H, self.n, self.n,
                      e.dh, 3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
         ops.gemm(self.ctx, p.wo, self.z, p.bo, x, None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
@@ -99,7 +99,7 @@ class SelfAttBlock:
         dctx = e.tmp("dctx", M, d)
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         dqkv = e.tmp("dqkv", M, 3 * d)
-        km = e.kmask if self.masked else None
+        km = e.kmask if self.masked else e.vkmask
         ops.sdpa_bwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                      e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws)      # + d(b_q | b_k | b_v)
@@ -186,7 +186,7 @@ class CrossAttBlock:
         if not self.need_vis:
             ops.gemm(X[:ML], p.wqkv, qkv_l, p.bqkv, None, None, ML, d, d, d, d, 3 * d)                    # Q of language rows
             ops.gemm(X[ML:], p.wqkv[d:], qkv_v[:, d:], p.bqkv[d:], None, None, MV, 2 * d, d, d, d, 3 * d)  # K,V of visual rows
-            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
+            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
                          3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
             ops.gemm(self.ctx[:ML], p.wo, self.z[:ML], p.bo, X[:ML], None, ML, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
                      p_drop=e.p_hid, seed=e.seed(self.site + 2))
@@ -196,7 +196,7 @@ class CrossAttBlock:
         if self.need_lang:
             ops.gemm(X, p.wqkv, self.qkv, p.bqkv, None, None, MX, 3 * d, d, d, d, 3 * d)
             # language queries over visual keys/values (no mask: visual_attention_mask is None in every caller)
-            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
+            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
                          3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
         else:
             ops.gemm(X[ML:], p.wqkv, qkv_v, p.bqkv, None, None, MV, d, d, d, d, 3 * d)                    # Q of visual rows
@@ -234,7 +234,7 @@ class CrossAttBlock:
                      e.p_attn, e.seed(self.site + 1), bias_grad=p.gbqkv, ws=e.ws)
         X = self.X
         if self.need_lang:
-            ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, dctx_full[:ML], self.lse_l, dqkv_l, dqkv_v[:, d:],
+            ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, dctx_full[:ML], self.lse_l, dqkv_l, dqkv_v[:, d:],
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
                          e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws)      # both directions share the projections
             e.wgrad_defer(dqkv, X, p.gwqkv, 3 * d, d, MX, 3 * d, d, d)
@@ -262,7 +262,7 @@ class CrossAttBlock:
         dqkv = e.tmp("dqkv", MX, 3 * d)
         dqkv_l, dqkv_v = dqkv[:ML], dqkv[ML:]
         qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
-        ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], None, dctx, self.lse_l, dqkv_l, dqkv_v[:, d:], dqkv_v[:, 2 * d:],
+        ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, dctx, self.lse_l, dqkv_l, dqkv_v[:, d:], dqkv_v[:, 2 * d:],
                      e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale, e.p_attn, e.seed(self.site),
                      bias_grad=p.gbqkv, ws=e.ws)
         e.wgrad_defer(dqkv_l, X[:ML], p.gwqkv, d, d, ML, 3 * d, d, d)
@@ -583,6 +583,7 @@ class Engine:
         self.XS = [self.act(self.MX, d) for _ in range(cfg.x_layers)]                # self-attention outputs
         self.pooled = self.act(B, d)
         self.kmask = torch.ones(B, L, dtype=torch.uint8, device=self.dev)
+        self.vkmask, self._vkmask_buf = None, None        # visual_attention_mask (HF:760-770): None in every reference caller
         self.pos = torch.zeros(self.MV, self.P, dtype=torch.float32, device=self.dev)
         self.ids = torch.zeros(B, L, dtype=torch.int64, device=self.dev)
         self.tt = torch.zeros(B, L, dtype=torch.int64, device=self.dev)
@@ -868,7 +869,8 @@ class Engine:
 
     # ------------------------------------------------------------ inputs
     def set_inputs(self, input_ids, attention_mask=None, token_type_ids=None, visual_pos=None, cluster_ids=None,
-                   vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None, feat_labels=None):
+                   vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None, feat_labels=None,
+                   visual_attention_mask=None):
         """masked_rows (optional): ascending ids b*V+v of the masked positions, i.e. vis_mask.flatten().nonzero(), as the data
         loader can compute them on the CPU next to vis_mask itself; given, the step needs no host <-> device round trip.
         feat_labels (optional, [B,V,F]): regression targets of the feature loss (label_dict['feat_labels'], ref
@@ -886,6 +888,12 @@ class Engine:
         else:
             self.tt.copy_(token_type_ids, non_blocking=True)
         self.pos.copy_(visual_pos.reshape(self.MV, self.P), non_blocking=True)
+        self.vkmask = None
+        if visual_attention_mask is not None:       # [B, V], nonzero = attend (HF:760-770): masks the visual KEYS of the visual
+            if self._vkmask_buf is None:            # self-attention and of the language -> vision cross-attention
+                self._vkmask_buf = torch.ones(B, V, dtype=torch.uint8, device=self.dev)
+            self._vkmask_buf.copy_(visual_attention_mask.reshape(B, V) != 0, non_blocking=True)
+            self.vkmask = self._vkmask_buf
         self.use_codebook = cluster_ids is not None
         if cluster_ids is not None:
             self.cid.copy_(cluster_ids, non_blocking=True)
@@ -906,6 +914,20 @@ class Engine:
                 self._feat_tgt_buf = self.act(self.MV, self.F)
             self._feat_tgt_buf.copy_(feat_labels.reshape(self.MV, self.F), non_blocking=True)
             self.feat_tgt = self._feat_tgt_buf
+
+    def hidden_states(self):
+        """(language_hidden_states, vision_hidden_states) of the last encoder_forward in HF's order (HF:516-544): the output of
+        every language layer then of every cross layer / of every visual layer then of every cross layer -- views of the
+        activation plan (valid until the next forward)."""
+        cfg, ML = self.cfg, self.ML
+        lang = [self.lang_out[i] if i < cfg.l_layers - 1 else self.X[0][:ML] for i in range(cfg.l_layers)]
+        vis = [self.vis_out[i] if i < cfg.r_layers - 1 else self.X[0][ML:] for i in range(cfg.r_layers)]
+        for i, blk in enumerate(self.x_layers):
+            if blk["lang_on"]:
+                lang.append(self.X[i + 1][:ML])
+            if blk["vis_on"]:
+                vis.append(self.X[i + 1][ML:])
+        return lang, vis
 
     # ------------------------------------------------------------ forward
     def encoder_forward(self, want_pooled=True):
@@ -1046,6 +1068,27 @@ class Engine:
         self.answer.fwd(self.pooled)
         self.answer.ce_loss_fwd_bwd(True)
         return True
+
+    def backward_from_outputs(self, d_lang=None, d_vis=None, d_pooled=None):
+        """backward of LxmertModel.forward from gradients of its three outputs (any may be None): ACCUMULATES into store.grad
+        (HF:691-822; the pooler's gradient joins the [CLS] rows of d(language_output))."""
+        assert self.need_lang, "needs the language side of the last cross layer (engine built with need_lang=True)"
+        ML, d = self.ML, self.d
+        self.begin_backward()
+        GA = self.GA
+        if d_lang is None or d_vis is None:
+            self.ops.zero(GA)
+        if d_lang is not None:
+            GA[:ML].copy_(d_lang.reshape(ML, d))
+        if d_vis is not None:
+            GA[ML:].copy_(d_vis.reshape(self.MV, d))
+        if d_pooled is not None:
+            if not hasattr(self, "_dpooled"):
+                self._dpooled, self._dpool_z = self.act(self.B, d), self.act(self.B, d)
+            self._dpooled.copy_(d_pooled.reshape(self.B, d))
+            cls_rows, d_cls = self._cls_views(GA)
+            self.pooler_backward(self._dpooled, self._dpool_z, cls_rows, d_cls, accumulate=True)
+        self.encoder_backward(have_lang_grad=True)
 
     def _cls_views(self, G):
         B, L, d = self.B, self.L, self.d

@@ -31,6 +31,7 @@ class LxmertModelOutput(tuple):
     def __new__(cls, lang, vis, pooled):
         obj = super().__new__(cls, (lang, vis, pooled))
         obj.language_output, obj.vision_output, obj.pooled_output = lang, vis, pooled
+        obj.language_hidden_states, obj.vision_hidden_states = None, None        # filled when output_hidden_states is asked for
         return obj
 
 
@@ -58,22 +59,14 @@ class _EncoderFn(torch.autograd.Function):
         eng = model._engine
         lang, vis, pooled = eng.encoder_forward(want_pooled=True)
         ctx.model = model
+        ctx.set_materialize_grads(False)            # outputs the loss does not read arrive as None in backward
         B, L, V, d = eng.B, eng.L, eng.V, eng.d
         return lang.view(B, L, d).clone(), vis.view(B, V, d).clone(), pooled.view(B, d).clone()
 
     @staticmethod
     def backward(ctx, d_lang, d_vis, d_pooled):
-        model = ctx.model
-        eng = model._engine
-        if d_pooled is not None and d_pooled.abs().sum().item() != 0:
-            raise NotImplementedError("gradient through pooled_output: N1 (VQA head) is a later row of the scope table")
-        ML = eng.ML
-        eng.GA.zero_()
-        if d_lang is not None:
-            eng.GA[:ML].copy_(d_lang.reshape(ML, eng.d))
-        if d_vis is not None:
-            eng.GA[ML:].copy_(d_vis.reshape(eng.MV, eng.d))
-        eng.encoder_backward(have_lang_grad=True)      # vec-type gradients accumulate: call model.zero_grad() per step
+        # vec-type gradients accumulate into param.grad (views of the flat buffer): call model.zero_grad() per step
+        ctx.model._engine.backward_from_outputs(d_lang, d_vis, d_pooled)
         return None, None
 
 
@@ -116,15 +109,13 @@ class LxmertModel(_Named):
             raise ValueError("`visual_pos` cannot be `None`")
         if inputs_embeds is not None:
             raise NotImplementedError("inputs_embeds: the path always starts from input_ids (every reference caller does)")
-        if visual_attention_mask is not None:
-            raise NotImplementedError("visual_attention_mask is None in every reference caller "
-                                      "(ref lxmert_pretrain.py:207, tasks/vqa.py:176-181)")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        if output_attentions:
+            raise NotImplementedError("attention maps are not materialised by the fused attention kernels")
         B, L = input_ids.shape
         V = visual_feats.shape[1]
         eng = self._engine_for(B, L, V)
-        eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats)
+        eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats,
+                       visual_attention_mask=visual_attention_mask)
         eng.use_codebook = False
         if torch.is_grad_enabled():
             lang, vis, pooled = _EncoderFn.apply(self, self._anchor)
@@ -132,7 +123,14 @@ class LxmertModel(_Named):
             l_, v_, p_ = eng.encoder_forward(want_pooled=True)
             lang, vis, pooled = l_.view(B, L, -1).clone(), v_.view(B, V, -1).clone(), p_.view(B, -1).clone()
         out = LxmertModelOutput(lang, vis, pooled)
-        return out if return_dict in (None, True) else tuple(out)
+        if output_hidden_states:        # HF:806-822: (language_hidden_states, vision_hidden_states); copies without a gradient path
+            lh, vh = eng.hidden_states()
+            out.language_hidden_states = tuple(h.view(B, L, -1).detach().clone() for h in lh)
+            out.vision_hidden_states = tuple(h.view(B, V, -1).detach().clone() for h in vh)
+        if return_dict in (None, True):
+            return out
+        t = tuple(out)
+        return t + (out.language_hidden_states, out.vision_hidden_states) if output_hidden_states else t
 
 
 LXRTModel = LxmertModel          # legacy names (original LXMERT code base / BASELINE.json wording)
