@@ -264,6 +264,52 @@ def gen_vqa(name, cfg, num_answers, seed, B, L, grid):
     print(name, "loss", float(loss), "n_grads", len(grads))
 
 
+def gen_nlvr2(name, cfg, seed, P, L, grid):
+    """SURVEY 8f N1, NLVR2 variant: the reference's NLVR2Model.forward (tasks/nlvr2_model.py:21-93: pair flattening, encoder,
+    pooled_output viewed as [P, 2d]) + CrossEntropyLoss (tasks/nlvr2.py:72).  The published class builds `logit_fc` with a
+    d-wide input and its forward calls `self.answer_head`, which nobody defines: the shim gives it that
+    attribute -- HF's LxmertVisualAnswerHead with the first Linear widened to the 2d-wide vector the forward feeds it -- and
+    nothing else; every line of the reference's forward runs as published."""
+    from tasks.nlvr2_model import NLVR2Model
+    from transformers.models.lxmert.modeling_lxmert import LxmertVisualAnswerHead
+
+    class NShim(NLVR2Model):
+        def init_weights(self):
+            if not getattr(self, "_in_post", False):
+                self._in_post = True
+                self.post_init()
+            else:
+                PreTrainedModel.init_weights(self)
+
+    hf = LxmertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                      num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                      max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                      l_layers=cfg.l_layers, x_layers=cfg.x_layers, r_layers=cfg.r_layers,
+                      visual_feat_dim=cfg.visual_feat_dim, visual_pos_dim=cfg.visual_pos_dim)
+    m = NShim(hf, 2)
+    del m.logit_fc                                   # never read by forward
+    m.answer_head = LxmertVisualAnswerHead(hf, 2)
+    m.answer_head.logit_fc[0] = torch.nn.Linear(2 * cfg.hidden_size, 2 * cfg.hidden_size)
+    sd = O.make_nlvr2_state_dict(cfg, seed)
+    m.load_state_dict({k: v for k, v in sd.items() if k.startswith("bert.") or k.startswith("answer_head.")}, strict=True)
+    m.eval()
+    inp = O.make_nlvr2_inputs(cfg, seed + 1, P, L, grid)
+    out = m(input_ids=inp["input_ids"], visual_feats=inp["visual_feats"], visual_pos=inp["visual_pos"],
+            attention_mask=inp["input_ids"] > 0)
+    logit = out["logit"]
+    loss = torch.nn.CrossEntropyLoss()(logit, inp["labels"])
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp))
+    d.update(logit=logit.detach().numpy(), loss=loss.detach().numpy())
+    d["grad_names"] = np.array(sorted(grads.keys()))
+    for k, g in grads.items():
+        d["grad:" + k] = g.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "loss", float(loss), "n_grads", len(grads))
+
+
 def gen_lang_tasks(name, cfg, seed, B, L, grid):
     """the reference's `word_mask` and `matched` branches (lxrt/modeling.py:211-235) with the pretraining heads
     of HF:589-657.  transformers 4.1.1 ties `cls.predictions.decoder.weight` to the word embeddings in the constructor
@@ -492,6 +538,11 @@ if __name__ == "__main__":
     if only == ["full"]:
         gen_full()
         sys.exit(0)
+    if only == ["nlvr2"]:
+        gen_nlvr2("nlvr2_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
+                  num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
+                  num_clusters=50), seed=1357, P=3, L=8, grid=4)
+        sys.exit(0)
     if only == ["qa"]:
         gen_qa_tasks("qa_tasks_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
                      num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
@@ -511,3 +562,4 @@ if __name__ == "__main__":
     gen_sampler("sampler_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, B=3, L=8, grid=4, n_steps=4)
     gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)
     gen_vismask("vismask_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=6420, B=3, L=8, grid=4)
+    gen_nlvr2("nlvr2_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, P=3, L=8, grid=4)

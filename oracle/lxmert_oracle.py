@@ -460,6 +460,50 @@ def make_vqa_inputs(cfg, num_answers, seed, B, L=20, grid=8):
             "visual_feats": torch.from_numpy(feats), "targets": torch.from_numpy(tgt)}
 
 
+# --------------------------------------------------------------------------- NLVR2 fine-tune head
+def nlvr2_forward(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=None, labels=None, token_type_ids=None):
+    """ref:x-lxmert/src/tasks/nlvr2_model.py:50-93: visual_feats [P, 2, V, F] / visual_pos [P, 2, V, 4] are flattened to 2P
+    encoder rows (input_ids already holds every statement twice, `:35-48`), pooled_output [2P, d] is viewed as [P, 2d] and
+    fed to the answer head; ref:x-lxmert/src/tasks/nlvr2.py:72 trains it with CrossEntropyLoss over the 2 classes.
+    The published class builds `logit_fc` with a d-wide input and then calls an `answer_head` it never defines (SURVEY
+    App. A #14); the head used here is the one its forward needs: Linear(2d, 2d) -> GeLU -> LayerNorm(2d) -> Linear(2d, 2),
+    HF's LxmertVisualAnswerHead with a 2d-wide first Linear, under the name the forward calls."""
+    P, two, V, Fd = visual_feats.shape
+    assert two == 2
+    if attention_mask is None:
+        attention_mask = input_ids > 0
+    lang, vis, pooled = lxmert_model(sd, cfg, input_ids, visual_feats.reshape(P * 2, V, Fd), visual_pos.reshape(P * 2, V, -1),
+                                     attention_mask, token_type_ids)
+    logit = visual_answer_head(sd, cfg, pooled.reshape(P, 2 * cfg.hidden_size))
+    out = {"logit": logit, "pooled": pooled}
+    if labels is not None:
+        out["loss"] = F.cross_entropy(logit, labels)
+    return out
+
+
+def make_nlvr2_state_dict(cfg, seed, perturb=True):
+    """make_vqa_state_dict(cfg, 2, seed) with the head's first Linear widened to (2d, 2d) (drawn from seed + 9)."""
+    sd = make_vqa_state_dict(cfg, 2, seed, perturb)
+    d = cfg.hidden_size
+    rng = np.random.default_rng(seed + 9)
+    sd["answer_head.logit_fc.0.weight"] = torch.from_numpy(0.02 * rng.standard_normal((2 * d, 2 * d), dtype=np.float32))
+    return sd
+
+
+def make_nlvr2_inputs(cfg, seed, P, L=20, grid=8):
+    """Synthetic NLVR2 batch (ref nlvr2_data.py: one statement, two images, a True/False label): P statements -> input_ids
+    [2P, L] with every statement repeated for its two images, features [P, 2, V, F], boxes [P, 2, V, 4], labels [P]."""
+    base = make_inputs(cfg, seed, P, L, grid)
+    rng = np.random.default_rng(seed + 13)
+    V = grid * grid
+    feats = np.maximum(rng.standard_normal((P, 2, V, cfg.visual_feat_dim), dtype=np.float32), 0.0)
+    ids = base["input_ids"].repeat_interleave(2, dim=0)
+    pos = base["visual_pos"].unsqueeze(1).repeat(1, 2, 1, 1).contiguous()
+    labels = torch.from_numpy(rng.integers(0, 2, size=(P,)).astype(np.int64))
+    return {"input_ids": ids, "attention_mask": ids > 0, "visual_pos": pos, "visual_feats": torch.from_numpy(feats),
+            "labels": labels}
+
+
 # --------------------------------------------------------------------------- head + losses
 def head_transform(sd, cfg, x, prefix="obj_predict_head.transform"):
     """HF:582-586 -- LN(gelu(dense(x)))."""

@@ -180,6 +180,51 @@ def test_vqa_step_vs_reference_fixture():
     assert set(names) <= used and not any(n.startswith("obj_predict_head") or n == "mask_feat" for n in used)
 
 
+def make_nlvr2_engine(g, ops, device="cpu", dtype=torch.float32):
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    sd = O.make_nlvr2_state_dict(oc, int(g["seed"]))
+    inp = golden_inputs(g)
+    B, L = inp["input_ids"].shape                      # B = 2 P encoder rows
+    P, _, V, Fd = inp["visual_feats"].shape
+    store = ParamStore(cfg, device, dtype, task="nlvr2")
+    store.load_named(sd)
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=True)
+    eng.sync_compute_weights()
+    dev = torch.device(device)
+    eng.set_inputs(inp["input_ids"].to(dev), inp["attention_mask"].to(dev), None, inp["visual_pos"].reshape(B, V, -1).to(dev),
+                   visual_feats=inp["visual_feats"].reshape(B, V, Fd).to(dev))
+    return eng, inp
+
+
+def check_nlvr2_grads(eng, g, tol):
+    names = [str(n) for n in g["grad_names"]]
+    for k in names:
+        ref = torch.from_numpy(g["grad:" + k])
+        got = eng.store.gview(k).float().cpu()
+        if "embeddings" in k and k.endswith("embeddings.weight"):
+            ref = ref.clone()
+            ref[0] = got[0]
+        assert maxdiff(got, ref) <= tol * max(1.0, ref.abs().max().item()), k
+    used = {m.name for u in eng.store.units if u.used for m in u.members}
+    assert set(names) == used                          # the optimizer range is exactly the reference's grad-carrying set
+
+
+def test_nlvr2_step_vs_reference_fixture():
+    """SURVEY 8f N1, NLVR2 variant: 2P encoder rows, pooled_output read as [P, 2d] by the pair head, CrossEntropyLoss over
+    the 2 classes, backward through head, pooler and the whole encoder -- against the reference's NLVR2Model.forward."""
+    g = load_golden("nlvr2_tiny")
+    eng, inp = make_nlvr2_engine(g, FakeOps(torch.float32))
+    loss = eng.nlvr2_forward_backward(inp["labels"])
+    assert eng.answer.logit.shape == (inp["labels"].shape[0], 2)
+    assert maxdiff(eng.answer.logit, g["logit"]) < 5e-5
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    check_nlvr2_grads(eng, g, 1e-4)
+
+
 def make_sampler_engine(g, ops, device="cpu", dtype=torch.float32):
     oc = golden_cfg(g)
     cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",

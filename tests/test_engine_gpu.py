@@ -436,6 +436,36 @@ def test_training_mode_dropout_step_matches_host_restatement(dtype, tol):
 
 
 # ---------------------------------------------------------------- VQA / GQA fine-tune step
+def test_nlvr2_step_fp32_matches_reference_fixture():
+    """NLVR2 fine-tune step on the GPU (pair head over pooled_output viewed [P, 2d], CE) == the reference's NLVR2Model."""
+    from test_engine_cpu import make_nlvr2_engine, check_nlvr2_grads
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("nlvr2_tiny")
+    eng, inp = make_nlvr2_engine(g, HipOps(torch.float32), device="cuda", dtype=torch.float32)
+    loss = eng.nlvr2_forward_backward(inp["labels"].cuda())
+    torch.cuda.synchronize()
+    assert maxdiff(eng.answer.logit.cpu(), g["logit"]) < 1e-4
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    check_nlvr2_grads(eng, g, 1e-4)
+
+
+def test_nlvr2_step_bf16_close_to_reference_fixture():
+    from test_engine_cpu import make_nlvr2_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("nlvr2_tiny")
+    eng, inp = make_nlvr2_engine(g, HipOps(torch.bfloat16), device="cuda", dtype=torch.bfloat16)
+    loss = eng.nlvr2_forward_backward(inp["labels"].cuda())
+    torch.cuda.synchronize()
+    assert maxdiff(eng.answer.logit.cpu(), g["logit"]) < 5e-2
+    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    for k in (str(n) for n in g["grad_names"]):
+        ref = torch.from_numpy(g["grad:" + k]).double()
+        got = eng.store.gview(k).cpu().double()
+        if k.endswith("embeddings.weight"):
+            ref = ref.clone(); ref[0] = got[0]
+        assert (got - ref).norm().item() <= 0.05 * max(ref.norm().item(), 1e-3), k
+
+
 def _vqa_engine(g, dtype):
     from test_engine_cpu import make_vqa_engine
     from xlxmert_amd.ops import HipOps

@@ -117,6 +117,38 @@ def test_vqa_model_dropin_matches_reference_fixture():
     assert set(m.state_dict().keys()) >= {"answer_head.logit_fc.3.bias", "bert.pooler.dense.weight"}
 
 
+def test_nlvr2_model_dropin_matches_reference_fixture():
+    """SURVEY 8f N1, NLVR2: the nn.Module surface of tasks/nlvr2_model.py -- [P,2,V,F] pairs in, {'logit': [P,2]} out, and the
+    reference's training idiom (CrossEntropyLoss, tasks/nlvr2.py:72) gives the fixture's gradients."""
+    import lxmert_oracle as O
+    from _util import golden_cfg, golden_inputs, load_golden, maxdiff
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.modeling import NLVR2Model
+    g = load_golden("nlvr2_tiny")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "l_layers", "x_layers",
+                                                      "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+    m = NLVR2Model(cfg, dtype=torch.float32).eval()
+    missing, _ = m.load_state_dict(O.make_nlvr2_state_dict(oc, int(g["seed"])))
+    assert not missing
+    inp = {k: v.cuda() for k, v in golden_inputs(g).items()}
+    m.zero_grad()
+    out = m(input_ids=inp["input_ids"], visual_feats=inp["visual_feats"], visual_pos=inp["visual_pos"],
+            attention_mask=inp["input_ids"] > 0)
+    assert out["logit"].shape == (inp["labels"].shape[0], 2)
+    assert maxdiff(out["logit"].cpu(), g["logit"]) < 1e-4
+    loss = torch.nn.CrossEntropyLoss()(out["logit"], inp["labels"])
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    for k in [str(n) for n in g["grad_names"]]:
+        ref = torch.from_numpy(g["grad:" + k])
+        assert maxdiff(params[k].grad.cpu(), ref) <= 1e-4 * max(1.0, ref.abs().max().item()), k
+    assert tuple(m.state_dict()["answer_head.logit_fc.0.weight"].shape) == (2 * cfg.hidden_size, 2 * cfg.hidden_size)
+
+
 def test_sample_codes_dropin_matches_reference_fixture():
     """SURVEY 8f N2 through the module surface: XLxmertForPretraining.sample_codes == the reference loop's final codes."""
     import lxmert_oracle as O

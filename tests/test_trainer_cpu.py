@@ -149,6 +149,34 @@ def test_vqa_two_steps_match_closed_form():
     assert torch.equal(tr.store.view(dead), sd[dead])
 
 
+def test_nlvr2_step_matches_closed_form():
+    """SURVEY 8f N1, NLVR2: one fine-tune step (pairs flattened by the trainer, CE over 2 classes, clip, AdamW) vs the oracle."""
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    P, L, grid = 3, 8, 4
+    sd = O.make_nlvr2_state_dict(oc, 5)
+    tr = PretrainStep(cfg, 2 * P, L, grid * grid, dtype=torch.float32, device="cpu", ops=FakeOps(torch.float32),
+                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="nlvr2")
+    tr.store.load_named(sd)
+    tr.engine.sync_compute_weights()
+    batch = O.make_nlvr2_inputs(oc, 77, P, L, grid)
+    loss = tr.step(batch)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.nlvr2_forward(leaf, oc, batch["input_ids"], batch["visual_feats"], batch["visual_pos"], labels=batch["labels"])
+    assert abs(loss.item() - out["loss"].item()) < 3e-6
+    out["loss"].backward()
+    gn = sorted(k for k in leaf if leaf[k].grad is not None)
+    used = sorted(m.name for u in tr.store.units if u.used for m in u.members)
+    assert gn == used
+    norm, clipped = O.clip_grad_norm([leaf[k].grad for k in gn], 1.0)
+    assert abs(tr.grad_norm() - norm.item()) < 1e-4 * max(1.0, norm.item())
+    lr = 1e-2 * linear_schedule(0, 2, 10)
+    for k, g in zip(gn, clipped):
+        wd = 0.0 if ("bias" in k or "LayerNorm.weight" in k) else 0.01
+        ref, _, _ = O.adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr, weight_decay=wd)
+        assert (tr.store.view(k) - ref.detach()).abs().max().item() < 2e-5, k
+
+
 def test_task_round_robin_on_one_parameter_set():
     """vis_mask -> word_mask -> matched -> vis_mask on ONE parameter set (ref lxmert_pretrain.py:296-298).
     The reference sets .grad = None after every step, so AdamW touches only the tensors of the step's branch and each

@@ -276,9 +276,14 @@ class AnswerHead:
     """LxmertVisualAnswerHead on pooled_output (HF:602-614: Linear(d,2d) -> GeLU -> LayerNorm(2d) -> Linear(2d,A)) with
     BCEWithLogitsLoss on soft targets -- the VQA/GQA fine-tune step (ref tasks/vqa_model.py:22-72, vqa.py:166-187)."""
 
-    def __init__(self, eng, num_answers):
-        self.e, self.A = eng, num_answers
-        st, d, B = eng.store, eng.d, eng.B
+    def __init__(self, eng, num_answers, pair=False):
+        self.e, self.A, self.pair = eng, num_answers, pair
+        st, d = eng.store, eng.d
+        # pair head (NLVR2, ref tasks/nlvr2_model.py:80-86): pooled_output [2P, d] of the flattened (statement, image) rows is
+        # read as [P, 2d] -- a view of the same contiguous buffer -- by a head whose first Linear is (2d, 2d)
+        assert not pair or eng.B % 2 == 0, "the pair head needs an even number of encoder rows (two images per statement)"
+        B = self.Bh = eng.B // 2 if pair else eng.B
+        self.din = 2 * d if pair else d
         p = "answer_head.logit_fc"
         self.w0, self.gw0 = st.cview(p + ".0.weight"), st.gview(p + ".0.weight")
         self.b0, self.gb0 = st.view(p + ".0.bias"), st.gview(p + ".0.bias")
@@ -293,7 +298,7 @@ class AnswerHead:
         self.targets = torch.zeros(B, num_answers, dtype=torch.float32, device=eng.dev)
         self.dlogit = eng.act(B, self.Ap)
         self.dhn, self.dh, self.dpre = eng.act(B, 2 * d), eng.act(B, 2 * d), eng.act(B, 2 * d)
-        self.dpooled, self.dz = eng.act(B, d), eng.act(B, d)
+        self.dpooled, self.dz = eng.act(eng.B, d), eng.act(eng.B, d)
         self.loss = eng.f32(1)
         # pretraining QA branch (ref lxrt/modeling.py:292-304): CrossEntropyLoss over one answer id per example (-100 = none)
         self.labels = torch.full((B,), -100, dtype=torch.int64, device=eng.dev)
@@ -302,15 +307,16 @@ class AnswerHead:
         self.row_lse, self.row_maxprob = eng.f32(B), eng.f32(B)
 
     def fwd(self, pooled):
-        e, d, B, A = self.e, self.e.d, self.e.B, self.A
+        e, d, B, A, din = self.e, self.e.d, self.Bh, self.A, self.din
         ops = e.ops
-        ops.gemm(pooled, self.w0, self.h, self.b0, None, self.pre, B, 2 * d, d, d, d, 2 * d, ldx=2 * d, epilogue=EPI_GELU)
+        pooled = pooled.view(B, din)
+        ops.gemm(pooled, self.w0, self.h, self.b0, None, self.pre, B, 2 * d, din, din, din, 2 * d, ldx=2 * d, epilogue=EPI_GELU)
         ops.layernorm_fwd(self.h, self.g, self.b, self.hn, self.mean, self.rstd, B, 2 * d, 1e-12)
         ops.gemm(self.hn, self.w3, self.logit, self.b3, None, None, B, A, 2 * d, 2 * d, 2 * d, A, out_f32=True)
         return self.logit
 
     def loss_fwd_bwd(self, want_grad=True):
-        B, A = self.e.B, self.A
+        B, A = self.Bh, self.A
         self.e.ops.zero(self.loss)
         self.e.ops.bce_logits_fwd_bwd(self.logit, self.targets, self.dlogit if want_grad else None, self.loss, B, A, A, A, self.Ap)
         return self.loss
@@ -318,7 +324,7 @@ class AnswerHead:
     def ce_loss_fwd_bwd(self, want_grad=True):
         """qa_loss = CrossEntropyLoss()(answer_score, qa_labels) (ref lxrt/modeling.py:295-298; ignore_index -100) and its
         d(logit); also records qa_pred = argmax (ref :300)."""
-        B, A = self.e.B, self.A
+        B, A = self.Bh, self.A
         ops = self.e.ops
         ops.zero(self.loss)
         ops.mask_counts(self.labels, self._ones, self.counts, self._nm, B, 1)          # counts[0] = #labels != -100
@@ -336,17 +342,17 @@ class AnswerHead:
 
     def bwd_to_pooled(self, pooled):
         """consumes dlogit; accumulates the head's parameter gradients; leaves d(pooled_output) in self.dpooled."""
-        e, d, B, A, Ap = self.e, self.e.d, self.e.B, self.A, self.Ap
+        e, d, B, A, Ap, din = self.e, self.e.d, self.Bh, self.A, self.Ap, self.din
         ops, st = e.ops, e.store
-        L = e.L
+        pooled, dpooled = pooled.view(B, din), self.dpooled.view(B, din)
         ops.colsum(self.dlogit, self.gb3_pad(), B, Ap, Ap, ws=e.ws)      # pad columns of dlogit are zero
         e.wgrad_defer(self.dlogit, self.hn, self.gw3, A, 2 * d, B, Ap, 2 * d, 2 * d)
         ops.gemm(self.dlogit, self.w3, self.dhn, None, None, None, B, 2 * d, A, Ap, 2 * d, 2 * d, a_kmajor=1, b_kmajor=0)
         ops.layernorm_bwd(self.dhn, self.h, self.g, self.mean, self.rstd, self.dh, self.gg, self.gb, None, B, 2 * d, ws=e.ws)
         ops.gelu_bwd(self.dh, self.pre, self.dpre, B * 2 * d)
         ops.colsum(self.dpre, self.gb0, B, 2 * d, 2 * d, ws=e.ws)
-        e.wgrad_defer(self.dpre, pooled, self.gw0, 2 * d, d, B, 2 * d, d, d)
-        ops.gemm(self.dpre, self.w0, self.dpooled, None, None, None, B, d, 2 * d, 2 * d, d, d, a_kmajor=1, b_kmajor=0)
+        e.wgrad_defer(self.dpre, pooled, self.gw0, 2 * d, din, B, 2 * d, din, din)
+        ops.gemm(self.dpre, self.w0, dpooled, None, None, None, B, din, 2 * d, 2 * d, din, din, a_kmajor=1, b_kmajor=0)
 
     def gb3_pad(self):
         """bias-gradient view padded to the 8-column granule of dlogit (the bias unit is padded in the flat buffer)."""
@@ -596,7 +602,7 @@ class Engine:
         self.task = getattr(store, "task", "vis_mask")
         # answer head on pooled_output: the VQA/GQA fine-tune model, or a pretraining model built with task_qa (then its CE
         # loss joins every task's loss, ref lxrt/modeling.py:292-304)
-        self.answer = AnswerHead(self, store.num_answers) if getattr(store, "num_answers", 0) > 0 else None
+        self.answer = AnswerHead(self, store.num_answers, getattr(store, "pair", False)) if getattr(store, "num_answers", 0) > 0 else None
         self.task_qa = self.answer is not None and self.task != "vqa"
         self.lang_heads = LangHeads(self) if self.task in ("word_mask", "matched", "all") else None
         if self.task in ("vqa", "word_mask", "matched", "qa", "all") or self.task_qa:
@@ -1211,6 +1217,24 @@ class Engine:
         loss = ans.loss_fwd_bwd(True)
         GA = self.GA
         self.ops.zero(GA)                            # only the [CLS] rows of the language output carry gradient
+        cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
+        ans.bwd(self.pooled, cls_rows, GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
+        self._ready_heads()
+        self.encoder_backward(True)
+        return loss
+
+    def nlvr2_forward_backward(self, labels):
+        """one NLVR2 fine-tune forward + backward (ref tasks/nlvr2.py:72 CrossEntropyLoss over the 2-way logit of each
+        statement; tasks/nlvr2_model.py:50-86: encoder over the flattened [2P] (statement, image) rows, pooled outputs of a
+        statement's two images concatenated).  `labels` [P] int64.  Returns the device loss buffer [1]."""
+        ans = self.answer
+        assert ans is not None and ans.pair, "build the store with task='nlvr2'"
+        ans.labels.copy_(labels.reshape(-1), non_blocking=True)
+        self.vqa_forward()
+        self.zero_accumulated_grads()
+        loss = ans.ce_loss_fwd_bwd(True)
+        GA = self.GA
+        self.ops.zero(GA)
         cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
         ans.bwd(self.pooled, cls_rows, GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
         self._ready_heads()

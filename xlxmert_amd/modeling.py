@@ -428,11 +428,13 @@ class VQAModel(nn.Module):
     {'logit': [B, num_answers] fp32}.  Unlike the published class this one can be constructed (its ctor reads
     `config.num_answers` before setting it and calls `_init_weights` on a non-existent attribute)."""
 
+    _task = "vqa"
+
     def __init__(self, config: XLxmertConfig, num_answers, num_clusters=-1, device=None, dtype=torch.bfloat16):
         super().__init__()
         self.config, self.num_answers = config, num_answers
         dev = torch.device(device if device is not None else "cuda")
-        self._store = ParamStore(config, dev, dtype, task="vqa", num_answers=num_answers)
+        self._store = ParamStore(config, dev, dtype, task=self._task, num_answers=num_answers)
         self.bert = LxmertModel(config, store=self._store, device=dev)
         self.answer_head = LxmertVisualAnswerHead(self._store)
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
@@ -465,7 +467,7 @@ class VQAModel(nn.Module):
             raise NotImplementedError("visual_attention_mask / inputs_embeds are None in every reference caller")
         B, L = input_ids.shape
         V = visual_feats.shape[1]
-        key = (B, L, V, self.training, "vqa")
+        key = (B, L, V, self.training, self._task)
         if self.bert._geom != key:
             self.bert._engine = Engine(self.config, self._store, self.bert._ops, B, L, V, need_lang=True,
                                        train_dropout=self.training)
@@ -475,3 +477,22 @@ class VQAModel(nn.Module):
         eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats)
         logit = _VqaFn.apply(self, self._anchor) if torch.is_grad_enabled() else eng.vqa_forward().clone()
         return {"logit": logit}
+
+
+class NLVR2Model(VQAModel):
+    """ref tasks/nlvr2_model.py:7-93: `.bert` + `.answer_head`; forward takes visual_feats [P, 2, V, F], visual_pos
+    [P, 2, V, 4] and input_ids [2P, L] (every statement repeated for its two images), flattens the pairs, and feeds
+    pooled_output viewed as [P, 2d] to the head; returns {'logit': [P, 2] fp32}.  The published class cannot run (its ctor
+    builds `logit_fc` with a d-wide input, its forward calls an undefined `answer_head` on the 2d-wide vector); this one has
+    the head that forward needs -- Linear(2d, 2d) -> GeLU -> LayerNorm(2d) -> Linear(2d, 2) -- under `.answer_head`."""
+    _task = "nlvr2"
+
+    def __init__(self, config: XLxmertConfig, num_answers=2, num_clusters=-1, device=None, dtype=torch.bfloat16):
+        super().__init__(config, num_answers, num_clusters, device, dtype)
+
+    def forward(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None, visual_attention_mask=None,
+                token_type_ids=None, inputs_embeds=None, return_dict=True):
+        P, n_images, V, Fd = visual_feats.shape
+        assert n_images == 2                                                             # ref :64
+        return super().forward(input_ids, visual_feats.reshape(P * 2, V, Fd), visual_pos.reshape(P * 2, V, -1), attention_mask,
+                               visual_attention_mask, token_type_ids, inputs_embeds, return_dict)

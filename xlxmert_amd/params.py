@@ -50,9 +50,11 @@ def _decays(name):
     return not ("bias" in name or "LayerNorm.weight" in name)
 
 
-def build_units(cfg, task="vis_mask", num_answers=0):
+def build_units(cfg, task="vis_mask", num_answers=0, pair=False):
     """task: "vis_mask" (masked-visual-token pretraining step) or "vqa" (VQA/GQA fine-tune: real features in, pooled output
     -> LxmertVisualAnswerHead, ref tasks/vqa_model.py:7-72; the codebook head and mask_feat are not part of that model).
+    pair=True is the NLVR2 model (ref tasks/nlvr2_model.py:7-93): the same layout, but the head reads the concatenated
+    pooled outputs of a statement's two images, so its first Linear is (2d, 2d).
     Pretraining tasks ("vis_mask", "word_mask", "matched", "qa", "all") with num_answers > 0 describe a model built with
     `task_qa` (ref lxrt/modeling.py:89-90): the answer head over pooled_output joins EVERY task's loss (ref :292-304), so the
     pooler, the language side of the last cross layer and `answer_head.*` are live in every branch."""
@@ -140,7 +142,7 @@ def build_units(cfg, task="vis_mask", num_answers=0):
         U("vec", rel, (f"{c}.seq_relationship.bias", (2,)))
     if task == "vqa" or qa:
         a = "answer_head.logit_fc"                       # nn.Sequential indices of HF:606-611
-        U("mat", True, (f"{a}.0.weight", (2 * d, d)))
+        U("mat", True, (f"{a}.0.weight", (2 * d, 2 * d if pair else d)))
         U("vec", True, (f"{a}.0.bias", (2 * d,)))
         U("vec", True, (f"{a}.2.weight", (2 * d,)))
         U("vec", True, (f"{a}.2.bias", (2 * d,)))
@@ -173,9 +175,13 @@ class ParamStore:
     """Flat fp32 master parameters + gradients + Adam state + compute-dtype copy, on one device."""
 
     def __init__(self, cfg, device, compute_dtype=torch.bfloat16, task="vis_mask", num_answers=0):
+        # "nlvr2" = the VQA layout with a pair head (two images per statement, ref tasks/nlvr2_model.py:50-86)
+        self.pair = task == "nlvr2"
+        if self.pair:
+            task, num_answers = "vqa", (num_answers or 2)
         self.cfg, self.device, self.compute_dtype, self.task = cfg, torch.device(device), compute_dtype, task
         self.num_answers = num_answers
-        units = build_units(cfg, task, num_answers)
+        units = build_units(cfg, task, num_answers, self.pair)
         # used tensors in the order backward FINISHES them (head, cross layers N..0, visual layers | language layers,
         # embeddings | visual feature encoder): the main stream completes a growing prefix and, at the very end, the tail;
         # the language stream completes the block in between layer by layer (language_range), so the data-parallel
@@ -220,7 +226,7 @@ class ParamStore:
         """per-chunk optimizer flags for one step of `task` on a multi-task ("all") store: bit 0 = weight decay, bit 1 = skip
         (tensors that get no gradient in that branch of the reference: .grad stays None and AdamW leaves them alone)."""
         if task not in self._task_flags:
-            active = {m.name for u in build_units(self.cfg, task, self.num_answers) if u.used for m in u.members}
+            active = {m.name for u in build_units(self.cfg, task, self.num_answers, self.pair) if u.used for m in u.members}
             fl = self.decay_flags.clone()
             for u in self.units:
                 if not all(m.name in active for m in u.members):

@@ -231,7 +231,7 @@ class PretrainStep:
         cluster_ids, vis_mask, obj_labels (optional: derived from cluster_ids/vis_mask as the reference does)."""
         eng, st, ops = self.engine, self.store, self.ops
         run = self.task if self.task != "all" else task           # a multi-task step object is told which branch to run
-        assert run in ("vis_mask", "word_mask", "matched", "qa", "vqa"), "PretrainStep(task='all').step(batch, task=...)"
+        assert run in ("vis_mask", "word_mask", "matched", "qa", "vqa", "nlvr2"), "PretrainStep(task='all').step(batch, task=...)"
         # a model built with task_qa (ParamStore num_answers > 0 on a pretraining task): batch["qa_labels"] [B] (-100 = no
         # answer; the caller applies the reference's matched-task flip mask, lxmert_pretrain.py:186-190) joins every branch;
         # the qa loss of the step is self.engine.answer.loss
@@ -260,14 +260,19 @@ class PretrainStep:
                 self._finish_exchange()
             self.optimizer_step()
             return loss
-        if run == "vqa":
-            # batch: input_ids (word_ids), visual_feats [B,V,F] (vis_feats), visual_pos (boxes), targets [B,A] soft scores
+        if run in ("vqa", "nlvr2"):
+            # vqa: input_ids (word_ids), visual_feats [B,V,F] (vis_feats), visual_pos (boxes), targets [B,A] soft scores
+            # nlvr2 (ref tasks/nlvr2_model.py:35-66): input_ids [2P,L] (every statement twice), visual_feats [P,2,V,F],
+            #        visual_pos [P,2,V,4], labels [P]
+            feats, pos = batch["visual_feats"], batch["visual_pos"]
+            if run == "nlvr2":
+                feats, pos = feats.reshape(-1, *feats.shape[2:]), pos.reshape(-1, *pos.shape[2:])
             eng.set_step_seed(self.t * self.world + self.rank)
-            eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], visual_feats=batch["visual_feats"])
+            eng.set_inputs(ids, am, batch.get("token_type_ids"), pos, visual_feats=feats)
             if self.exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
-            loss = eng.vqa_forward_backward(batch["targets"])
+            loss = eng.vqa_forward_backward(batch["targets"]) if run == "vqa" else eng.nlvr2_forward_backward(batch["labels"])
             if self.exchange:
                 self._finish_exchange()
             self.optimizer_step()
