@@ -527,9 +527,43 @@ def gen_vismask(name, cfg, seed, B, L, grid):
     print(name, "loss", float(loss), "n_grads", len(grads), "kept keys per image", n_keep.tolist())
 
 
+def gen_embeds(name, cfg, seed, B, L, grid):
+    """LxmertModel.forward(inputs_embeds=...) (HF:699,731-744; None in every caller of the reference's drivers): the three
+    outputs and, for a fixed linear functional of them, d(inputs_embeds) and every parameter gradient."""
+    torch.manual_seed(0)
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    g = torch.Generator().manual_seed(seed + 2)
+    V = grid * grid
+    feats = torch.randn(B, V, cfg.visual_feat_dim, generator=g)
+    emb = (0.05 * torch.randn(B, L, cfg.hidden_size, generator=g)).requires_grad_(True)
+    wl, wv, wp = (torch.randn(s_, generator=g) for s_ in ((B, L, cfg.hidden_size), (B, V, cfg.hidden_size), (B, cfg.hidden_size)))
+    m.zero_grad(set_to_none=True)
+    bo = m.bert(inputs_embeds=emb, visual_feats=feats, visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+                token_type_ids=inp["token_type_ids"], return_dict=True)
+    real = inp["attention_mask"].bool()
+    loss = (bo.language_output * wl * real[..., None]).sum() + (bo.vision_output * wv).sum() + (bo.pooled_output * wp).sum()
+    loss.backward()
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp), in_visual_feats=feats.numpy(), in_inputs_embeds=emb.detach().numpy(),
+             w_lang=wl.numpy(), w_vis=wv.numpy(), w_pooled=wp.numpy(), loss=loss.detach().numpy(),
+             lang=bo.language_output.detach().numpy(), vis=bo.vision_output.detach().numpy(), pooled=bo.pooled_output.detach().numpy(),
+             d_inputs_embeds=emb.grad.numpy())
+    grads = {k: p_.grad.detach().clone() for k, p_ in m.bert.named_parameters() if p_.grad is not None}
+    d["grad_names"] = np.array(sorted("bert." + k for k in grads))
+    for k, gr in grads.items():
+        d["grad:bert." + k] = gr.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "loss", float(loss), "n_grads", len(grads))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
+    if only == ["embeds"]:
+        gen_embeds("embeds_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
+                   num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
+                   num_clusters=50), seed=8024, B=3, L=8, grid=4)
+        sys.exit(0)
     if only == ["vismask"]:
         gen_vismask("vismask_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
                     num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
@@ -563,3 +597,4 @@ if __name__ == "__main__":
     gen_vqa("vqa_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), num_answers=37, seed=2468, B=3, L=8, grid=4)
     gen_vismask("vismask_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=6420, B=3, L=8, grid=4)
     gen_nlvr2("nlvr2_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, P=3, L=8, grid=4)
+    gen_embeds("embeds_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=8024, B=3, L=8, grid=4)

@@ -80,14 +80,16 @@ def _layer_norm(sd, prefix, x, eps):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
 
 
-def embeddings(sd, cfg, input_ids, token_type_ids, prefix="bert.embeddings"):
-    """HF:191-214 -- LN(word[ids] + pos[0..L-1] + type[tt]); dropout is identity (eval)."""
-    B, L = input_ids.shape
-    pos_ids = torch.arange(L, device=input_ids.device)[None, :].expand(B, L)
+def embeddings(sd, cfg, input_ids, token_type_ids, prefix="bert.embeddings", inputs_embeds=None):
+    """HF:191-214 -- LN(word[ids] + pos[0..L-1] + type[tt]); dropout is identity (eval).  `inputs_embeds` [B, L, d] replaces
+    the word lookup (HF:199-206)."""
+    B, L = token_type_ids.shape
+    pos_ids = torch.arange(L, device=token_type_ids.device)[None, :].expand(B, L)
     # all three tables are nn.Embedding(..., padding_idx=0) (HF:184-186): forward is a plain gather,
     # but row 0 of each table receives NO gradient -- i.e. [PAD] word, position 0 ([CLS]) and
     # token-type 0 (every token; ref lxmert_pretrain.py:200) are frozen rows.
-    e = (F.embedding(input_ids, sd[prefix + ".word_embeddings.weight"], padding_idx=0)
+    word = inputs_embeds if inputs_embeds is not None else F.embedding(input_ids, sd[prefix + ".word_embeddings.weight"], padding_idx=0)
+    e = (word
          + F.embedding(pos_ids, sd[prefix + ".position_embeddings.weight"], padding_idx=0)
          + F.embedding(token_type_ids, sd[prefix + ".token_type_embeddings.weight"], padding_idx=0))
     return _layer_norm(sd, prefix + ".LayerNorm", e, cfg.layer_norm_eps)
@@ -192,18 +194,19 @@ def pooler(sd, cfg, lang, prefix="bert.pooler"):
 
 
 def lxmert_model(sd, cfg, input_ids, visual_feats, visual_pos, attention_mask=None,
-                 token_type_ids=None, prefix="bert", return_hidden=False, visual_attention_mask=None):
+                 token_type_ids=None, prefix="bert", return_hidden=False, visual_attention_mask=None, inputs_embeds=None):
     """HF:691-822 -- returns (language_output, vision_output, pooled_output).
     `visual_attention_mask` (HF:760-770: the same additive extension as the language mask, applied to the visual KEYS of the
     visual self-attention and of the language -> vision cross-attention) is None in every reference caller
     (ref:x-lxmert/src/pretrain/lxmert_pretrain.py:207); pinned by tests/golden/vismask_tiny.npz."""
     dtype = sd[prefix + ".embeddings.word_embeddings.weight"].dtype
+    shape = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]          # HF:735-741
     if attention_mask is None:
-        attention_mask = torch.ones_like(input_ids)
+        attention_mask = torch.ones(shape, dtype=torch.long)
     if token_type_ids is None:
-        token_type_ids = torch.zeros_like(input_ids)
+        token_type_ids = torch.zeros(shape, dtype=torch.long)
     mask_add = extended_mask(attention_mask, dtype)
-    emb = embeddings(sd, cfg, input_ids, token_type_ids, prefix + ".embeddings")
+    emb = embeddings(sd, cfg, input_ids, token_type_ids, prefix + ".embeddings", inputs_embeds)
     vis_mask_add = extended_mask(visual_attention_mask, dtype) if visual_attention_mask is not None else None
     out = encoder(sd, cfg, emb, mask_add, visual_feats.to(dtype), visual_pos.to(dtype), vis_mask_add,
                   prefix + ".encoder", return_hidden)

@@ -479,3 +479,42 @@ def check_vismask(g, eng, tol, gtol):
 def test_visual_attention_mask_hidden_states_and_pooled_gradient():
     g = load_golden("vismask_tiny")
     check_vismask(g, make_vismask_engine(g, FakeOps(torch.float32)), 5e-5, 1e-4)
+
+
+def check_inputs_embeds(g, ops, device="cpu", dtype=torch.float32, tol=5e-5, gtol=1e-4):
+    """Engine with inputs_embeds instead of input_ids: outputs, d(inputs_embeds), every parameter gradient; the word-embedding
+    table gets no gradient (fixture embeds_tiny, from the reference's LxmertModel)."""
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads",
+                                                      "intermediate_size", "max_position_embeddings", "type_vocab_size",
+                                                      "l_layers", "x_layers", "r_layers", "visual_feat_dim",
+                                                      "visual_pos_dim", "num_clusters")})
+    t = lambda k: torch.from_numpy(g[k]).to(device)
+    B, L, d = g["in_inputs_embeds"].shape
+    V = g["in_visual_feats"].shape[1]
+    store = ParamStore(cfg, device, dtype, task="all")
+    store.load_named(O.make_state_dict(oc, int(g["seed"])))
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=True)
+    eng.sync_compute_weights()
+    eng.set_inputs(None, t("in_attention_mask"), t("in_token_type_ids"), t("in_visual_pos"), visual_feats=t("in_visual_feats").to(dtype),
+                   inputs_embeds=t("in_inputs_embeds"))
+    lang, vis, pooled = eng.encoder_forward(want_pooled=True)
+    real = t("in_attention_mask").bool()
+    assert maxdiff(lang.view(B, L, d)[real].float(), t("lang")[real]) < tol
+    assert maxdiff(vis.view(B, V, d).float(), t("vis")) < tol and maxdiff(pooled.float(), t("pooled")) < tol
+    eng.store.grad.zero_()
+    eng.backward_from_outputs((t("w_lang") * real[..., None]).to(eng.cdtype), t("w_vis").to(eng.cdtype), t("w_pooled").to(eng.cdtype))
+    ref = t("d_inputs_embeds").double()
+    assert (eng.d_inputs_embeds().double() - ref).norm().item() <= gtol * ref.norm().item()
+    for k in [str(n) for n in g["grad_names"]]:
+        ref = t("grad:" + k).double()
+        assert (eng.store.gview(k).double() - ref).norm().item() <= gtol * max(ref.norm().item(), 1e-3), k
+    assert eng.store.gview("bert.embeddings.word_embeddings.weight").abs().max().item() == 0.0
+    # ... and the engine goes back to input_ids on the next call
+    eng.set_inputs(torch.zeros(B, L, dtype=torch.long, device=device), t("in_attention_mask"), t("in_token_type_ids"), t("in_visual_pos"),
+                   visual_feats=t("in_visual_feats").to(dtype))
+    assert not eng.embeds_mode
+
+
+def test_inputs_embeds_vs_reference_fixture():
+    check_inputs_embeds(load_golden("embeds_tiny"), FakeOps(torch.float32))

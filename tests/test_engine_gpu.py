@@ -830,3 +830,9 @@ def test_qa_branch_steps_bf16_stated_tolerance(task):
             worst = max(worst, abs(got_n - ref_n) / ref_n)
     print(f"qa fixture bf16 {task}: worst gradient-norm error {worst:.4f}")
     assert worst < 3e-2                 # measured 0.9 %
+
+
+def test_inputs_embeds_fp32_matches_reference_fixture():
+    from test_engine_cpu import check_inputs_embeds
+    from xlxmert_amd.ops import HipOps
+    check_inputs_embeds(load_golden("embeds_tiny"), HipOps(torch.float32), device="cuda", tol=1e-4, gtol=1e-4)

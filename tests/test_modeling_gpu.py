@@ -319,3 +319,26 @@ def test_bert_forward_options_match_reference_fixture():
     tup = m.bert(input_ids=t("in_input_ids"), visual_feats=t("in_visual_feats"), visual_pos=t("in_visual_pos"),
                  attention_mask=t("in_attention_mask"), output_hidden_states=True, return_dict=False)
     assert len(tup) == 5 and len(tup[3]) == oc.l_layers + oc.x_layers
+
+
+def test_bert_inputs_embeds_through_autograd():
+    """LxmertModel.forward(inputs_embeds=leaf) through the module API: outputs and d(inputs_embeds) via autograd (fixture
+    embeds_tiny from the reference's own LxmertModel)."""
+    g = load_golden("embeds_tiny")
+    m, oc, sd = make_model(g)
+    m.train(False)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    emb = t("in_inputs_embeds").clone().requires_grad_(True)
+    out = m.bert(inputs_embeds=emb, visual_feats=t("in_visual_feats"), visual_pos=t("in_visual_pos"),
+                 attention_mask=t("in_attention_mask"), token_type_ids=t("in_token_type_ids"), return_dict=True)
+    real = t("in_attention_mask").bool()
+    assert maxdiff(out.language_output[real].cpu(), t("lang")[real].cpu()) < 1e-4
+    assert maxdiff(out.vision_output.cpu(), g["vis"]) < 1e-4 and maxdiff(out.pooled_output.cpu(), g["pooled"]) < 1e-4
+    m.zero_grad()
+    loss = (out.language_output * t("w_lang") * real[..., None]).sum() + (out.vision_output * t("w_vis")).sum() + \
+        (out.pooled_output * t("w_pooled")).sum()
+    loss.backward()
+    ref = t("d_inputs_embeds").double()
+    assert (emb.grad.double() - ref).norm().item() <= 1e-4 * ref.norm().item()
+    with pytest.raises(ValueError):
+        m.bert(input_ids=t("in_input_ids"), inputs_embeds=emb, visual_feats=t("in_visual_feats"), visual_pos=t("in_visual_pos"))

@@ -876,15 +876,28 @@ class Engine:
     # ------------------------------------------------------------ inputs
     def set_inputs(self, input_ids, attention_mask=None, token_type_ids=None, visual_pos=None, cluster_ids=None,
                    vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None, feat_labels=None,
-                   visual_attention_mask=None):
+                   visual_attention_mask=None, inputs_embeds=None):
         """masked_rows (optional): ascending ids b*V+v of the masked positions, i.e. vis_mask.flatten().nonzero(), as the data
         loader can compute them on the CPU next to vis_mask itself; given, the step needs no host <-> device round trip.
         feat_labels (optional, [B,V,F]): regression targets of the feature loss (label_dict['feat_labels'], ref
         lxrt/modeling.py:275; the trainer passes the real grid features, lxmert_pretrain.py:177-179); without them the
         feature loss regresses onto the centroid of each position's cluster id."""
         B, L, V = self.B, self.L, self.V
-        assert tuple(input_ids.shape) == (B, L), (input_ids.shape, (B, L))
-        self.ids.copy_(input_ids, non_blocking=True)
+        # inputs_embeds [B, L, d] instead of input_ids (HF:699,731-744,773 -> HF:191-214: they replace the word-embedding
+        # lookup; position / token-type embeddings, LayerNorm and dropout still apply): staged as a per-call "word table" of
+        # B*L + 1 rows addressed by ids 1..B*L, so the embedding kernels run unchanged and their scatter-add leaves
+        # d(inputs_embeds) in rows 1.. of a table-shaped fp32 buffer (row 0 is the kernels' frozen padding_idx row)
+        self.embeds_mode = inputs_embeds is not None
+        if self.embeds_mode:
+            assert input_ids is None and tuple(inputs_embeds.shape) == (B, L, self.d), (inputs_embeds.shape, (B, L, self.d))
+            if getattr(self, "_emb_tab", None) is None:
+                self._emb_tab = torch.zeros(B * L + 1, self.d, dtype=self.cdtype, device=self.dev)
+                self._emb_grad = torch.zeros(B * L + 1, self.d, dtype=torch.float32, device=self.dev)
+                self._emb_ids = torch.arange(1, B * L + 1, dtype=torch.int64, device=self.dev).view(B, L)
+            self._emb_tab[1:].copy_(inputs_embeds.reshape(B * L, self.d), non_blocking=True)
+        else:
+            assert tuple(input_ids.shape) == (B, L), (input_ids.shape, (B, L))
+            self.ids.copy_(input_ids, non_blocking=True)
         if attention_mask is None:
             self.kmask.fill_(1)
         else:
@@ -921,6 +934,11 @@ class Engine:
             self._feat_tgt_buf.copy_(feat_labels.reshape(self.MV, self.F), non_blocking=True)
             self.feat_tgt = self._feat_tgt_buf
 
+    def d_inputs_embeds(self):
+        """gradient w.r.t. the inputs_embeds of the last backward ([B, L, d] fp32 view; valid until the next backward)."""
+        assert getattr(self, "embeds_mode", False)
+        return self._emb_grad[1:].view(self.B, self.L, self.d)
+
     def hidden_states(self):
         """(language_hidden_states, vision_hidden_states) of the last encoder_forward in HF's order (HF:516-544): the output of
         every language layer then of every cross layer / of every visual layer then of every cross layer -- views of the
@@ -947,7 +965,9 @@ class Engine:
         self.fork()
         with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream
             e = "bert.embeddings"
-            ops.embed_ln_fwd(self.ids, self.tt, st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
+            emb = getattr(self, "embeds_mode", False)
+            ops.embed_ln_fwd(self._emb_ids if emb else self.ids, self.tt,
+                             self._emb_tab if emb else st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
                              st.cview(e + ".token_type_embeddings.weight"), st.view(e + ".LayerNorm.weight"),
                              st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
                              self.B, self.L, d, self.eps)
@@ -1449,7 +1469,11 @@ class Engine:
             dpre = self.tmp("emb_dz", ML, d)      # not "dz": layer 0's weight-gradient group may still be reading it
             ops.layernorm_bwd(GA[:ML], self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
                               st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d, ws=self.ws)
-            ops.embed_bwd(dpre, self.ids, self.tt, st.gview(e + ".word_embeddings.weight"),
+            emb = getattr(self, "embeds_mode", False)
+            if emb:                                   # d(inputs_embeds) instead of d(word_embeddings): see set_inputs
+                ops.zero(self._emb_grad)
+            ops.embed_bwd(dpre, self._emb_ids if emb else self.ids, self.tt,
+                          self._emb_grad if emb else st.gview(e + ".word_embeddings.weight"),
                           st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
                           self.B, self.L, d)
             self.flush_reductions()

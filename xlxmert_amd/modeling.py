@@ -55,10 +55,11 @@ class _Named(nn.Module):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, anchor):
+    def forward(ctx, model, anchor, inputs_embeds=None):
         eng = model._engine
         lang, vis, pooled = eng.encoder_forward(want_pooled=True)
         ctx.model = model
+        ctx.emb_dtype = inputs_embeds.dtype if inputs_embeds is not None and inputs_embeds.requires_grad else None
         ctx.set_materialize_grads(False)            # outputs the loss does not read arrive as None in backward
         B, L, V, d = eng.B, eng.L, eng.V, eng.d
         return lang.view(B, L, d).clone(), vis.view(B, V, d).clone(), pooled.view(B, d).clone()
@@ -66,8 +67,9 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_lang, d_vis, d_pooled):
         # vec-type gradients accumulate into param.grad (views of the flat buffer): call model.zero_grad() per step
-        ctx.model._engine.backward_from_outputs(d_lang, d_vis, d_pooled)
-        return None, None
+        eng = ctx.model._engine
+        eng.backward_from_outputs(d_lang, d_vis, d_pooled)
+        return None, None, (eng.d_inputs_embeds().to(ctx.emb_dtype) if ctx.emb_dtype is not None else None)
 
 
 class LxmertModel(_Named):
@@ -107,18 +109,16 @@ class LxmertModel(_Named):
             raise ValueError("`visual_feats` cannot be `None`")
         if visual_pos is None:
             raise ValueError("`visual_pos` cannot be `None`")
-        if inputs_embeds is not None:
-            raise NotImplementedError("inputs_embeds: the path always starts from input_ids (every reference caller does)")
         if output_attentions:
             raise NotImplementedError("attention maps are not materialised by the fused attention kernels")
-        B, L = input_ids.shape
+        B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]          # HF:735-741
         V = visual_feats.shape[1]
         eng = self._engine_for(B, L, V)
         eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats,
-                       visual_attention_mask=visual_attention_mask)
+                       visual_attention_mask=visual_attention_mask, inputs_embeds=inputs_embeds)
         eng.use_codebook = False
         if torch.is_grad_enabled():
-            lang, vis, pooled = _EncoderFn.apply(self, self._anchor)
+            lang, vis, pooled = _EncoderFn.apply(self, self._anchor, inputs_embeds)
         else:
             l_, v_, p_ = eng.encoder_forward(want_pooled=True)
             lang, vis, pooled = l_.view(B, L, -1).clone(), v_.view(B, V, -1).clone(), p_.view(B, -1).clone()
@@ -463,9 +463,9 @@ class VQAModel(nn.Module):
 
     def forward(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None, visual_attention_mask=None,
                 token_type_ids=None, inputs_embeds=None, return_dict=True):
-        if visual_attention_mask is not None or inputs_embeds is not None:
-            raise NotImplementedError("visual_attention_mask / inputs_embeds are None in every reference caller")
-        B, L = input_ids.shape
+        if inputs_embeds is not None and inputs_embeds.requires_grad:
+            raise NotImplementedError("d(inputs_embeds) through the task wrappers: use .bert directly (no reference caller does)")
+        B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]
         V = visual_feats.shape[1]
         key = (B, L, V, self.training, self._task)
         if self.bert._geom != key:
@@ -474,7 +474,8 @@ class VQAModel(nn.Module):
             self.bert._geom = key
         eng = self.bert._engine
         eng.sync_compute_weights()
-        eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats)
+        eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats,
+                       visual_attention_mask=visual_attention_mask, inputs_embeds=inputs_embeds)
         logit = _VqaFn.apply(self, self._anchor) if torch.is_grad_enabled() else eng.vqa_forward().clone()
         return {"logit": logit}
 
