@@ -146,6 +146,80 @@ class GemmTimer:
         return out
 
 
+def other_workloads(cfg, dev, steps=8, warm=3):
+    """The SURVEY 8f rows next to the hot path, timed in the same run (one GPU, bf16, dropout on, synthetic data; after the
+    headline measurement, never part of `value`): VQA fine-tune step at BASELINE config 3's per-GPU batch, NLVR2 step,
+    word_mask / matched pretraining steps, T=4 Mask-Predict sampling (config 4).  Each entry: ms per step and rate."""
+    from xlxmert_amd.engine import Engine
+    from xlxmert_amd.ops import HipOps
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import PretrainStep, init_reference_weights, random_word_batch, synthetic_batch, word_rows_of
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps
+
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    cents = torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu()
+
+    def feats(*shape):
+        return torch.randn(*shape, cfg.visual_feat_dim, generator=g).relu().to(dev)
+
+    # N1: VQA / GQA fine-tune step (3129 answers, real 2048-d grid features in; config 3 = bs 512 over 4 GPUs -> 128 per GPU,
+    # and the full 512 on one GPU)
+    for B in (128, 512):
+        tr = PretrainStep(cfg, B, 20, 64, device=dev, task="vqa", num_answers=3129, train_dropout=True, total_steps=1000)
+        b = {k: v.to(dev) for k, v in synthetic_batch(cfg, B, 20, 8, seed=7).items()}
+        tgt = torch.zeros(B, 3129)
+        tgt[torch.arange(B), torch.randint(0, 3129, (B,), generator=g)] = 1.0
+        batch = {"input_ids": b["input_ids"], "visual_pos": b["visual_pos"], "visual_feats": feats(B, 64), "targets": tgt.to(dev)}
+        dt = timed(lambda: tr.step(batch))
+        out[f"vqa_step_bs{B}"] = {"ms": round(dt * 1e3, 2), "examples_per_s": round(B / dt, 1)}
+        del tr, batch
+    # N1: NLVR2 step (128 statements x 2 images = 256 encoder rows, ref tasks/nlvr2_model.py:50-86)
+    P = 128
+    tr = PretrainStep(cfg, 2 * P, 20, 64, device=dev, task="nlvr2", train_dropout=True, total_steps=1000)
+    b = synthetic_batch(cfg, P, 20, 8, seed=8)
+    batch = {"input_ids": b["input_ids"].repeat_interleave(2, 0).to(dev), "visual_pos": b["visual_pos"][:, None].expand(-1, 2, -1, -1).contiguous().to(dev),
+             "visual_feats": feats(P, 2, 64), "labels": torch.randint(0, 2, (P,), generator=g).to(dev)}
+    dt = timed(lambda: tr.step(batch))
+    out["nlvr2_step_128_statements"] = {"ms": round(dt * 1e3, 2), "statements_per_s": round(P / dt, 1)}
+    del tr, batch
+    # N3: language pretraining branches (30522-way tied decoder on the labelled rows / matched head), bs 256
+    B = 256
+    for task in ("word_mask", "matched"):
+        tr = PretrainStep(cfg, B, 20, 64, device=dev, task=task, train_dropout=True, total_steps=1000)
+        tr.set_centroids(cents)
+        b = synthetic_batch(cfg, B, 20, 8, seed=9)
+        ids, wl = random_word_batch(b["input_ids"], generator=g)
+        batch = {"input_ids": ids.to(dev), "visual_pos": b["visual_pos"].to(dev), "cluster_ids": b["cluster_ids"].to(dev),
+                 "word_labels": wl.to(dev), "matched_labels": torch.randint(0, 2, (B,), generator=g).to(dev), "word_rows": word_rows_of(wl)}
+        dt = timed(lambda: tr.step(batch))
+        out[f"{task}_step_bs{B}"] = {"ms": round(dt * 1e3, 2), "examples_per_s": round(B / dt, 1)}
+        del tr, batch
+    # N2: Mask-Predict sampling, T = 4 refinement steps over the 8x8 grid, codes for the frozen GAN decoder (config 4)
+    for B in (64, 256):
+        store = ParamStore(cfg, dev, torch.bfloat16, task="vis_mask")
+        init_reference_weights(store, 1)
+        store.set_centroids(cents)
+        eng = Engine(cfg, store, HipOps(torch.bfloat16), B, 20, 64, need_lang=False)
+        eng.sync_compute_weights()
+        b = {k: v.to(dev) for k, v in synthetic_batch(cfg, B, 20, 8, seed=10).items()}
+        eng.set_inputs(b["input_ids"], b["attention_mask"], None, b["visual_pos"],
+                       cluster_ids=torch.zeros(B, 64, dtype=torch.long, device=dev), vis_mask=torch.ones(B, 64, dtype=torch.bool, device=dev))
+        dt = timed(lambda: eng.sample_codes_nar(4))
+        out[f"sampler_T4_bs{B}"] = {"ms": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1)}
+        del eng, store
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +227,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (reference --batchSize, param.py:70)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the SURVEY 8f workloads (VQA / NLVR2 / word_mask / matched / sampler)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-dropout", action="store_true", help="eval-parity mode (the reference trains with p=0.1)")
     ap.add_argument("--single-stream", action="store_true", help="no language/visual stream overlap (profiling)")
@@ -301,6 +376,10 @@ def main():
                 "bucket_mb": round(tr.bucket_elems * (2 if tr.comm_buf is not None else 4) / (1 << 20), 1),
                 "bytes_per_step": int(tr.store.n_used * (2 if tr.comm_buf is not None else 4)),
                 "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3)}
+        if not args.no_extra and world == 1 and not args.single_stream:
+            del tr, batches
+            torch.cuda.empty_cache()
+            out["other_workloads"] = other_workloads(cfg, f"cuda:{local}")
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

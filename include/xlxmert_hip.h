@@ -46,6 +46,10 @@ extern "C" {
                              * 64-column segment n/64 of row m -- the sampler's softmax(-1).max(-1) over the 10k codebook without the
                              * logits ever reaching memory (ref tasks/imggen_model.py:229-235); finish with xl_rowmax_combine.  bf16
                              * operands, a_kmajor = b_kmajor = 1, M and N multiples of 256 (pad N with zero rows and bias -1e30) */
+#define XL_EPI_GELU_DG  6   /* C = gelu_erf(acc+bias); aux = gelu_erf'(acc+bias): the derivative is saved instead of the
+                             * pre-activation (same bytes; erf and exp(-x^2/2) are already in registers), so that the backward
+                             * epilogue is a multiply -- XL_EPI_MULAUX -- instead of a second erf + exp per element        */
+#define XL_EPI_MULAUX   7   /* C = acc * aux                      (backward of XL_EPI_GELU_DG)                            */
 
 const char* xl_last_error(void);
 int  xl_version(void);

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH, EPI_ROWMAX = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH, EPI_ROWMAX, EPI_GELU_DG, EPI_MULAUX = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def v2(t, rows, cols, ld):
@@ -85,6 +85,11 @@ class FakeOps:
             acc = acc * gelu_grad(v2(aux, M, N, ldx).float())
         elif epilogue == EPI_TANH:
             acc = torch.tanh(acc)
+        elif epilogue == EPI_GELU_DG:         # the derivative is saved instead of the pre-activation
+            v2(aux, M, N, ldx).copy_(gelu_grad(acc))
+            acc = torch.nn.functional.gelu(acc)
+        elif epilogue == EPI_MULAUX:
+            acc = acc * v2(aux, M, N, ldx).float()
         elif epilogue == EPI_ROWMAX:           # no C: per row and 64-column segment {max, sum exp(x - max), argmax bits, 0} -> aux
             assert N % 64 == 0
             seg = acc.view(M, N // 64, 64)

@@ -86,7 +86,7 @@ def test_gemm_layouts(M, N, K, layout, dtype, tr, pingpong):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("epi", [1, 2, 3, 4])
+@pytest.mark.parametrize("epi", [1, 2, 3, 4, 6, 7])
 def test_gemm_epilogues(epi, dtype, pingpong):
     if dtype == torch.float32 and pingpong == 2:
         pytest.skip("kernel switch only affects the bf16 MFMA kernels")
@@ -101,6 +101,8 @@ def test_gemm_epilogues(epi, dtype, pingpong):
     close(gpu[2], cpu[2], dtype, f"epilogue {epi} C")
     if epi == 1:
         close(gpu[5], cpu[5], dtype, "epilogue GELU aux (pre-activation)")
+    if epi == 6:
+        close(gpu[5], cpu[5], dtype, "epilogue GELU_DG aux (saved derivative)")
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -145,7 +147,7 @@ def test_gemm_pingpong_pipeline_depths(M, N, K, layout):
 
 
 @pytest.mark.parametrize("bk", [1, 0])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 768, 128), (768, 384, 200), (256, 2304, 1000), (1024, 768, 1536)])
 def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
     """the 256x192 variant of the ping-pong kernel (waves 4 x 2, wave tile 64 x 96, B staged in three 8 KiB parts) forced for
@@ -158,7 +160,7 @@ def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
     bias = torch.randint(-4, 5, (N,), generator=g).float()
     res = torch.randint(-8, 9, (M, N), generator=g).to(torch.bfloat16)
     aux = (torch.randint(-8, 9, (M, N), generator=g).float() * 0.25).to(torch.bfloat16)
-    alpha = 2.0 ** -6 if epi in (1, 3) else 1.0            # keep GELU / dGELU arguments in a sensible range
+    alpha = 2.0 ** -6 if epi in (1, 3, 6, 7) else 1.0      # keep GELU / dGELU arguments in a sensible range
     ops = hip(torch.bfloat16)
     ops.set_gemm_pingpong(2)
     ops.set_gemm_tile192(2)
@@ -166,7 +168,7 @@ def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
         for rep in range(2):
             C = torch.full((M, N), 7.0, dtype=torch.bfloat16)
             X = aux.clone()
-            cpu, gpu = run_both(torch.bfloat16, "gemm", [A, B, C, bias, res if epi == 2 else None, X if epi in (1, 3) else None,
+            cpu, gpu = run_both(torch.bfloat16, "gemm", [A, B, C, bias, res if epi == 2 else None, X if epi in (1, 3, 6, 7) else None,
                                                          M, N, K, K, (K if bk else N), N],
                                 dict(ldr=N, ldx=N, b_kmajor=bk, epilogue=epi, alpha=alpha))
             if epi in (0, 2):
@@ -176,6 +178,8 @@ def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
                 close(gpu[2], cpu[2], torch.bfloat16, f"256x192 epilogue {epi}", bf16_tol=1e-2)
             if epi == 1:
                 assert torch.equal(gpu[5], cpu[5]), "saved pre-activation"
+            if epi == 6:
+                close(gpu[5], cpu[5], torch.bfloat16, "saved derivative", bf16_tol=1e-2)
     finally:
         ops.set_gemm_pingpong(1)
         ops.set_gemm_tile192(1)

@@ -28,14 +28,18 @@ def needs_build():
 
 
 def build_library(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+              [os.path.join(HERE, "..", "include", "xlxmert_hip.h")]
+
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        deps = [os.path.join(CSRC, src)] + headers
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+            return obj                                  # object newer than its source and every header: reuse
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -46,6 +50,8 @@ def build_library(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(cc, SOURCES))
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
+        return LIB                                      # every object up to date and already linked
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -160,6 +160,20 @@ __device__ __forceinline__ void gelu_fast8(float (&v)[8]) {
         v[i] = y.x; v[i + 1] = y.y;
     }
 }
+// v[i] = gelu(v[i]), g[i] = gelu'(v[i]) from one erf / exp evaluation
+__device__ __forceinline__ void gelu_fast8_dg(float (&v)[8], float (&g)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_t x = {v[i], v[i + 1]};
+        f32x2_t er, e;
+        erf_parts2(x, er, e);
+        const f32x2_t h = (er + 1.0f) * 0.5f;
+        const f32x2_t y = x * h;
+        const f32x2_t d = h + x * 0.39894228040143267794f * e;
+        v[i] = y.x; v[i + 1] = y.y;
+        g[i] = d.x; g[i + 1] = d.y;
+    }
+}
 // v[i] *= gelu'(a[i])
 __device__ __forceinline__ void gelu_grad_mul8(float (&v)[8], const float (&a)[8]) {
 #pragma unroll

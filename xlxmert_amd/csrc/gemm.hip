@@ -219,6 +219,12 @@ static void launch_mfma(const GemmParams& p, int epik, int nblk, hipStream_t st)
             case XL_EPI_GELU: return launch_one<AK, BKM, true, XL_EPI_GELU>(p, nblk, st);
             case XL_EPI_RESIDUAL: return launch_one<AK, BKM, true, XL_EPI_RESIDUAL>(p, nblk, st);
             case XL_EPI_DGELU: return launch_one<AK, BKM, true, XL_EPI_DGELU>(p, nblk, st);
+            case XL_EPI_GELU_DG:
+                if constexpr (BKM) return launch_one<AK, BKM, true, XL_EPI_GELU_DG>(p, nblk, st);
+                break;
+            case XL_EPI_MULAUX:
+                if constexpr (!BKM) return launch_one<AK, BKM, true, XL_EPI_MULAUX>(p, nblk, st);
+                break;
             default: break;
         }
     }
@@ -314,14 +320,15 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     XL_CHECK_ARG(A && B && (C || epilogue == XL_EPI_ROWMAX), XL_ERR_BAD_ARG, "xl_gemm: null operand");
     XL_CHECK_ARG(lda >= (a_kmajor ? K : M) && ldb >= (b_kmajor ? K : N) && ldc >= N, XL_ERR_BAD_SHAPE,
                  "xl_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
-    XL_CHECK_ARG(epilogue >= XL_EPI_NONE && epilogue <= XL_EPI_ROWMAX, XL_ERR_BAD_ARG, "xl_gemm: bad epilogue %d", epilogue);
+    XL_CHECK_ARG(epilogue >= XL_EPI_NONE && epilogue <= XL_EPI_MULAUX, XL_ERR_BAD_ARG, "xl_gemm: bad epilogue %d", epilogue);
     if (epilogue == XL_EPI_ROWMAX)
         XL_CHECK_ARG(in_dtype == XL_BF16 && a_kmajor && b_kmajor && M % 256 == 0 && N % 256 == 0 && K % 8 == 0 && lda % 8 == 0 &&
                      ldb % 8 == 0 && aux && aligned16(aux) && aligned16(A) && aligned16(B) && (!bias || aligned16(bias)) &&
                      !accumulate && !colsum_out && g_use_tr_read, XL_ERR_BAD_SHAPE,
                      "xl_gemm: XL_EPI_ROWMAX takes bf16 K-major operands with M, N multiples of 256 (M=%d N=%d) and a 16-byte aligned aux", M, N);
     if (epilogue == XL_EPI_RESIDUAL) XL_CHECK_ARG(residual && ldr >= N, XL_ERR_BAD_ARG, "xl_gemm: residual missing");
-    if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU) XL_CHECK_ARG(aux && ldx >= N, XL_ERR_BAD_ARG, "xl_gemm: aux missing");
+    if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU || epilogue == XL_EPI_GELU_DG || epilogue == XL_EPI_MULAUX)
+        XL_CHECK_ARG(aux && ldx >= N, XL_ERR_BAD_ARG, "xl_gemm: aux missing");
     XL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, XL_ERR_BAD_ARG, "xl_gemm: p_drop %f", p_drop);
     if (accumulate) XL_CHECK_ARG(out_dtype == XL_F32 && epilogue == XL_EPI_NONE, XL_ERR_BAD_ARG,
                                  "xl_gemm: accumulate needs fp32 output and no epilogue");
@@ -403,10 +410,13 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         p.vec_epi = 1;
     }
     if (epilogue == XL_EPI_RESIDUAL) p.vec_epi = p.vec_epi && aligned16(residual) && ldr % 8 == 0;
-    if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU) p.vec_epi = p.vec_epi && aligned16(aux) && ldx % 8 == 0;
+    if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU || epilogue == XL_EPI_GELU_DG || epilogue == XL_EPI_MULAUX)
+        p.vec_epi = p.vec_epi && aligned16(aux) && ldx % 8 == 0;
     // fast (templated) epilogue: aligned rows, a kind that has one, plain stores
     int epik = -1;
     if (p.vec_epi && !p.atomic_out && epilogue != XL_EPI_TANH && (bias == nullptr || aligned16(bias))) epik = epilogue;
+    // the derivative-saving GELU pair is instantiated for the layouts that use it (forward NT / dX NN); generic otherwise
+    if ((epilogue == XL_EPI_GELU_DG && !b_kmajor) || (epilogue == XL_EPI_MULAUX && b_kmajor)) epik = -1;
     if (bn == 192 && epik < 0) {          // the 256x192 tile has the fast epilogue only: back to 256x256
         bn = 256;
         p.tiles_n = (N + tile - 1) / tile;

@@ -47,6 +47,17 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
             break;
         }
         case XL_EPI_TANH: v = tanhf(v); break;
+        case XL_EPI_GELU_DG: {
+            TIn* aux = reinterpret_cast<TIn*>(p.aux);
+            Elem<TIn>::st(aux + (size_t)m * p.ldx + n, gelu_erf_grad(v));
+            v = gelu_erf(v);
+            break;
+        }
+        case XL_EPI_MULAUX: {
+            const TIn* aux = reinterpret_cast<const TIn*>(p.aux);
+            v *= Elem<TIn>::ld(aux + (size_t)m * p.ldx + n);
+            break;
+        }
         default: break;
     }
     if (p.out_f32) {
@@ -255,6 +266,16 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, float* wbuf, 
             } else if (p.epilogue == XL_EPI_TANH) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            } else if (p.epilogue == XL_EPI_GELU_DG) {
+                float gv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gv[e] = gelu_grad_fast(v[e]); v[e] = gelu_fast(v[e]); }
+                stvec(reinterpret_cast<bf16_t*>(p.aux) + mn * p.ldx + n, gv);
+            } else if (p.epilogue == XL_EPI_MULAUX) {
+                float av[8];
+                ldvec(reinterpret_cast<const bf16_t*>(p.aux) + mn * p.ldx + n, av);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= av[e];
             }
             if (p.out_f32) {
                 float* c = reinterpret_cast<float*>(p.C) + mn * p.ldc + n;
@@ -300,7 +321,7 @@ __device__ __forceinline__ void sub_row_from_lds(const float* wbuf, int row, int
 }
 template <int EPI, int W>
 __device__ __forceinline__ void sub_operand_load(const GemmParams& p, int lane, int mq, int nq, QuadOperand& op) {
-    if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU) {
+    if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU || EPI == XL_EPI_MULAUX) {
         constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = 64 / RPP;
         const bf16_t* src = reinterpret_cast<const bf16_t*>(EPI == XL_EPI_RESIDUAL ? p.residual : p.aux);
         const int ld = EPI == XL_EPI_RESIDUAL ? p.ldr : p.ldx;
@@ -323,7 +344,7 @@ __device__ __forceinline__ void sub_load_bias8(const GemmParams& p, int lane, bo
 
 template <int EPI>
 __device__ __forceinline__ void quad_operand_load(const GemmParams& p, int lane, int mq, int nq, QuadOperand& op) {
-    if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU) {
+    if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU || EPI == XL_EPI_MULAUX) {
         const bf16_t* src = reinterpret_cast<const bf16_t*>(EPI == XL_EPI_RESIDUAL ? p.residual : p.aux);
         const int ld = EPI == XL_EPI_RESIDUAL ? p.ldr : p.ldx;
         const bf16_t* s0 = src + (size_t)(mq + (lane >> 3)) * ld + nq + (lane & 7) * 8;
@@ -406,6 +427,15 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
             float av[8];
             unpack8(op.row[ps], av);
             gelu_grad_mul8(v, av);
+        } else if constexpr (EPI == XL_EPI_GELU_DG) {
+            float gv[8];
+            gelu_fast8_dg(v, gv);
+            stvec(reinterpret_cast<bf16_t*>(p.aux) + m * p.ldx + n, gv);
+        } else if constexpr (EPI == XL_EPI_MULAUX) {
+            float av[8];
+            unpack8(op.row[ps], av);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= av[e];
         }
         if constexpr (EPI == XL_EPI_ROWMAX) {
             // (max, sum exp(x - max), argmax) of this row's 64-column segment: 8 columns per lane, then the 8 lanes of the row
@@ -481,6 +511,15 @@ __device__ __forceinline__ void sub_rows_fast(const GemmParams& p, const float* 
             float av[8];
             unpack8(op.row[ps], av);
             gelu_grad_mul8(v, av);
+        } else if constexpr (EPI == XL_EPI_GELU_DG) {
+            float gv[8];
+            gelu_fast8_dg(v, gv);
+            stvec(reinterpret_cast<bf16_t*>(p.aux) + m * p.ldx + n, gv);
+        } else if constexpr (EPI == XL_EPI_MULAUX) {
+            float av[8];
+            unpack8(op.row[ps], av);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= av[e];
         }
         if (p.out_f32) {
             float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;

@@ -424,6 +424,12 @@ static hipError_t launch_pp_layout(const GemmParams& p, int epik, int bn, int nb
                 case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU, 192>(p, nblk, st);
                 case XL_EPI_RESIDUAL: return launch_pp_one<AK, BKM, XL_EPI_RESIDUAL, 192>(p, nblk, st);
                 case XL_EPI_DGELU: return launch_pp_one<AK, BKM, XL_EPI_DGELU, 192>(p, nblk, st);
+                case XL_EPI_GELU_DG:
+                    if constexpr (BKM) return launch_pp_one<AK, BKM, XL_EPI_GELU_DG, 192>(p, nblk, st);
+                    return hipErrorInvalidValue;
+                case XL_EPI_MULAUX:
+                    if constexpr (!BKM) return launch_pp_one<AK, BKM, XL_EPI_MULAUX, 192>(p, nblk, st);
+                    return hipErrorInvalidValue;
                 default: return hipErrorInvalidValue;
             }
         }
@@ -432,6 +438,12 @@ static hipError_t launch_pp_layout(const GemmParams& p, int epik, int bn, int nb
             case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU>(p, nblk, st);
             case XL_EPI_RESIDUAL: return launch_pp_one<AK, BKM, XL_EPI_RESIDUAL>(p, nblk, st);
             case XL_EPI_DGELU: return launch_pp_one<AK, BKM, XL_EPI_DGELU>(p, nblk, st);
+            case XL_EPI_GELU_DG:
+                if constexpr (BKM) return launch_pp_one<AK, BKM, XL_EPI_GELU_DG>(p, nblk, st);
+                break;
+            case XL_EPI_MULAUX:
+                if constexpr (!BKM) return launch_pp_one<AK, BKM, XL_EPI_MULAUX>(p, nblk, st);
+                break;
             case XL_EPI_ROWMAX:
                 if constexpr (BKM) return launch_pp_one<AK, BKM, XL_EPI_ROWMAX>(p, nblk, st);
                 return hipErrorInvalidValue;

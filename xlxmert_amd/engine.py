@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from .ops import EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_ROWMAX, EPI_TANH
+from .ops import EPI_DGELU, EPI_GELU, EPI_GELU_DG, EPI_MULAUX, EPI_NONE, EPI_RESIDUAL, EPI_ROWMAX, EPI_TANH
 
 
 class _Att:
@@ -132,7 +132,9 @@ class FFNBlock:
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
         ops = e.ops
         ops.block = self.tag
-        ops.gemm(x, self.w1, self.h, self.b1, None, self.pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU)
+        # self.pre holds gelu'(pre-activation): erf and exp(-x^2/2) are in registers in the forward epilogue anyway, and the
+        # backward epilogue becomes a multiply (no second erf + exp per element of the [M, dff] gradient)
+        ops.gemm(x, self.w1, self.h, self.b1, None, self.pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU_DG)
         ops.gemm(self.h, self.w2, self.z, self.b2, x, None, M, d, dff, dff, dff, d, ldr=d, epilogue=EPI_RESIDUAL,
                  p_drop=e.p_hid, seed=e.seed(self.site))
         ops.layernorm_fwd(self.z, self.g, self.b, y, self.mean, self.rstd, M, d, e.eps)
@@ -151,7 +153,7 @@ class FFNBlock:
         e.wgrad_defer(dzm, self.h, self.gw2, d, dff, M, d, dff, dff)
         dpre = e.tmp("dpre", M, dff)
         ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
-                 epilogue=EPI_DGELU, colsum=self.gb1, ws=e.ws)       # d(b1) = column sums of dpre, in the same epilogue
+                 epilogue=EPI_MULAUX, colsum=self.gb1, ws=e.ws)      # d(b1) = column sums of dpre, in the same epilogue
         e.wgrad_defer(dpre, self.x, self.gw1, dff, d, M, dff, d, d)
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_RESIDUAL)

@@ -10,7 +10,7 @@ import torch
 from ._lib import XlError, get_lib
 
 XL_F32, XL_BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH, EPI_ROWMAX = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_TANH, EPI_ROWMAX, EPI_GELU_DG, EPI_MULAUX = 0, 1, 2, 3, 4, 5, 6, 7
 
 TORCH_DTYPE = {XL_F32: torch.float32, XL_BF16: torch.bfloat16}
 _SLAB_WS = {}
