@@ -3,6 +3,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -41,9 +42,11 @@ def build_library(force=False, verbose=True):
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
             return obj                                  # object newer than its source and every header: reuse
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        t_start = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        os.utime(obj, (t_start, t_start))               # a header edited DURING a minutes-long compile must still count as newer
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
         return obj
