@@ -68,9 +68,6 @@ int  xl_set_gemm_pingpong(int mode);
  * 1 = when they shorten the launch (default: N = 768 gives 192 tiles of 256x256 on 256 CUs but 256 of 256x192), 2 = whenever
  * eligible (test switch; env XL_GEMM_BN192 sets the initial value) */
 int  xl_set_gemm_tile192(int mode);
-/* Ping-pong kernel launches of at least two full rounds of whole tiles (>= 512 on the 256 CUs): 1 (default; env
- * XL_GEMM_PERSIST) = one workgroup per CU walks its share of the tiles, 0 = one workgroup per tile (tuning / test switch). */
-int  xl_set_gemm_persistent(int enable);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */
 int  xl_gemm_trace(void* buffer);

@@ -224,47 +224,6 @@ def slab_ws(request):
     ops.lib.call("xl_gemm_set_workspace", None, 0, st)
 
 
-@pytest.mark.parametrize("epi,bk", [(0, 1), (6, 1), (7, 0), (2, 0), (0, 0)])
-@pytest.mark.parametrize("M,N,K,bn", [(8192, 4096, 200, 256), (8960, 3840, 128, 256), (16384, 2304, 64, 192)])
-def test_gemm_persistent_tiles_exact(M, N, K, bn, epi, bk):
-    """launches of >= 512 tiles as one workgroup per CU walking its XCD's share of the tiles (512 tiles; 525 = uneven shares;
-    768 tiles of 256x192): every tile exactly once -- integer operands, so the plain result equals the host product bit for
-    bit -- and every epilogue identical to the one-workgroup-per-tile launch of the same kernel."""
-    if bn == 192 and bk == 0 and epi in (6,):
-        pytest.skip("no 256x192 instance for this pair")
-    g = torch.Generator().manual_seed(M + N + K + epi)
-    A = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16).cuda()
-    B = torch.randint(-3, 4, ((N, K) if bk else (K, N)), generator=g).to(torch.bfloat16).cuda()
-    bias = torch.randint(-4, 5, (N,), generator=g).float().cuda()
-    res = torch.randint(-8, 9, (M, N), generator=g).to(torch.bfloat16).cuda()
-    aux0 = (torch.randint(-8, 9, (M, N), generator=g).float() * 0.25).to(torch.bfloat16).cuda()
-    alpha = 2.0 ** -6 if epi in (6, 7) else 1.0
-    ops = hip(torch.bfloat16)
-    ops.set_gemm_pingpong(2)
-    ops.set_gemm_tile192(2 if bn == 192 else 0)
-    outs = []
-    try:
-        for persist in (1, 0, 1):
-            ops.set_gemm_persistent(persist)
-            C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
-            X = aux0.clone()
-            ops.gemm(A, B, C, bias, res if epi == 2 else None, X if epi in (6, 7) else None, M, N, K, K, (K if bk else N), N,
-                     ldr=N, ldx=N, b_kmajor=bk, epilogue=epi, alpha=alpha)
-            torch.cuda.synchronize()
-            outs.append((C, X))
-    finally:
-        ops.set_gemm_persistent(1)
-        ops.set_gemm_pingpong(1)
-        ops.set_gemm_tile192(1)
-    for C, X in outs[1:]:
-        assert torch.equal(C, outs[0][0]) and torch.equal(X, outs[0][1])
-    if epi in (0, 2):
-        ref = A.float() @ (B.float().t() if bk else B.float()) + bias
-        if epi == 2:
-            ref = ref + res.float()
-        assert torch.equal(outs[0][0], ref.to(torch.bfloat16))
-
-
 @pytest.mark.parametrize("epi,bk,of32", [(0, 1, True), (2, 0, False), (1, 1, False), (3, 0, False)])
 @pytest.mark.parametrize("M,N,K", [(8448, 2048, 1536), (4352, 4096, 1096)])
 def test_gemm_tail_split_exact(M, N, K, epi, bk, of32, slab_ws):

@@ -239,7 +239,6 @@ static int env_int(const char* name, int dflt) {
 unsigned long long* g_gemm_trace = nullptr;   // xl_gemm_trace
 int g_gemm_pp = -1;      // 0 / 1 / 2, see xl_set_gemm_pingpong; -1 = read XL_GEMM_PP (default 1)
 int g_gemm_bn192 = -1;   // 0 / 1 / 2, see xl_set_gemm_tile192; -1 = read XL_GEMM_BN192 (default 1)
-int g_gemm_persist = -1; // 0 / 1, see xl_set_gemm_persistent; -1 = read XL_GEMM_PERSIST (default 1)
 int g_tail_max = -1, g_tail_min_k = 4096;   // tail split: at most this many tiles in the last round, contraction at least this deep (xl_set_gemm_tail_split)
 int g_wgrad_slabs = -1;  // weight-gradient K splits through slabs instead of atomics (xl_set_gemm_wgrad_slabs); -1 = read XL_GEMM_WGRAD_SLABS (default 0)
 
@@ -308,11 +307,6 @@ extern "C" int xl_set_gemm_tile192(int mode) {
     return XL_OK;
 }
 
-extern "C" int xl_set_gemm_persistent(int enable) {
-    g_gemm_persist = enable ? 1 : 0;
-    return XL_OK;
-}
-
 extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
                        const void* residual, void* aux,
                        int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldx,
@@ -348,7 +342,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.step_seed = g_step_seed; p.ablate = ablate;
     p.trace = g_gemm_trace;
     p.colsum_ws = nullptr;
-    p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0; p.persist = 0;
+    p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0;
     if (colsum_out != nullptr)
         XL_CHECK_ARG(colsum_ws != nullptr && !accumulate && (long)((M + 63) / 64) * N <= xl_workspace_floats(N), XL_ERR_BAD_ARG,
                      "xl_gemm: colsum_out needs a workspace (xl_workspace_floats), accumulate = 0 and M <= 262144");
@@ -450,12 +444,6 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
                 nblk = tiles - rem + rem * S;
             }
         }
-    }
-    // persistent tiles (gemm_pp.hip): at least two full rounds of whole tiles -> one workgroup per CU walks its tiles
-    if (g_gemm_persist < 0) g_gemm_persist = env_int("XL_GEMM_PERSIST", 1);
-    if (use_pp && g_gemm_persist && splitk == 1 && !p.atomic_out && p.tail_tiles == 0 && tiles >= 512 && p.trace == nullptr) {
-        p.persist = 1;
-        nblk = 256;
     }
     if (use_pp) {
         hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st);

@@ -21,7 +21,6 @@ struct GemmParams {
     float* slab;                      // split-K through slabs (slab_exchange): partial tiles [tile][split][64 Ki floats], or null
     int* tickets;                     // ... and one arrival counter per output tile (zero between launches)
     int tail_tiles, tail_kper;        // tail split (ping-pong kernel): the last tail_tiles tiles run as `splitk` K slices each
-    int persist;                      // ping-pong kernel: one workgroup per CU walks its XCD's tiles (multi-round launches)
 };
 
 // ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)

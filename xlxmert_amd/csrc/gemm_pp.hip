@@ -341,24 +341,6 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
 template <bool AK, bool BKM, int EPIK, int BN>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
     int tm, tn, z;
-    if (p.persist) {
-        // Multi-round launches (N = 3072 / 2304 outputs: 768-1008 tiles on 256 CUs) as ONE workgroup per CU that walks its
-        // share of the tiles: the same schedule the dispatcher produces for a one-block-per-tile grid (XCD x owns the x-th
-        // contiguous chunk of the grouped tile order, its 32 slots take the chunk's tiles round-robin), without a workgroup
-        // teardown + dispatch + descriptor set-up between a CU's tiles.
-        const int T = p.tiles_m * p.tiles_n;
-        const int q = T >> 3, r = T & 7;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int size = q + (xcd < r ? 1 : 0);
-#pragma unroll 1
-        for (int i = slot; i < size; i += S) {
-            tile_of(p, start + i, tm, tn);
-            pp_tile<AK, BKM, EPIK, BN>(p, tm, tn, 0, p.K, true);
-            __syncthreads();              // the next tile's first DMA lands where slower waves may still read their epilogue rows
-        }
-        return;
-    }
     if (p.tail_tiles > 0) {
         // Tail split: a launch whose last round would hold only a few tiles (264 tiles on 256 CUs: a second round of 8) runs
         // those tiles as `splitk` K slices each, combined through slabs by the last arriver, which also runs the epilogue --
@@ -405,7 +387,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     p.epilogue = XL_EPI_NONE; p.out_f32 = 1; p.atomic_out = 1; p.splitk = g.splitk; p.kper = pr.kper; p.vec_epi = 0;
     p.alpha = 1.0f; p.p_drop = 0.f; p.inv_keep = 1.f; p.seed = 0; p.step_seed = nullptr;
     p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr; p.colsum_ws = nullptr;
-    p.slab = g.slab; p.tickets = g.tickets; p.vec_epi = pr.vec; p.tail_tiles = 0; p.tail_kper = 0; p.persist = 0;
+    p.slab = g.slab; p.tickets = g.tickets; p.vec_epi = pr.vec; p.tail_tiles = 0; p.tail_kper = 0;
     if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
     const int tl = t - g.tile_start[i];
     const int kbeg = z * pr.kper;

@@ -57,10 +57,6 @@ class HipOps:
         """0: 256x256 tiles only; 1: 256x192 where it shortens the launch (default); 2: whenever eligible."""
         self.lib.call("xl_set_gemm_tile192", int(mode))
 
-    def set_gemm_persistent(self, enable):
-        """multi-round ping-pong launches as one workgroup per CU walking its tiles (default on; test / tuning switch)"""
-        self.lib.call("xl_set_gemm_persistent", int(enable))
-
     # -- stream plumbing of a step as C-ABI calls (so that a recorded launch plan contains them: _lib.LaunchPlan)
     def zero(self, t):
         """t.zero_() on the current stream (t contiguous)."""
