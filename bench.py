@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="eval-parity mode (the reference trains with p=0.1)")
     ap.add_argument("--single-stream", action="store_true", help="no language/visual stream overlap (profiling)")
     ap.add_argument("--gemm-table", action="store_true", help="print the instrumented step's GEMM time by shape (stderr)")
+    ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW on the main stream, in front of the next forward (default: behind the step on a side stream)")
     ap.add_argument("--eager", action="store_true", help="enqueue every step from Python instead of replaying the recorded launch plan")
     args = ap.parse_args()
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 during the run (RCCL's
@@ -270,7 +271,8 @@ def main():
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595,
                       total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout,
                       bucket_mb=float(os.environ.get("XL_BUCKET_MB", "64")),
-                      plan=(world == 1 and not grouped and not args.eager and not args.single_stream), drop_grads=True)
+                      plan=(world == 1 and not grouped and not args.eager and not args.single_stream), drop_grads=True,
+                      overlap_optimizer=not (args.no_opt_overlap or args.single_stream))
     if args.single_stream:
         tr.engine.side = None
     g = torch.Generator().manual_seed(9595)
@@ -346,6 +348,9 @@ def main():
                                        f"({len(tr._plans)} masked-row geometries, {max(p.n_calls for p in tr._plans.values())} calls each)"
                                        if tr.plan_mode and tr._plans else "eager (every launch enqueued from Python)"),
                        "visual_losses": "obj,feat" if tr.feat_loss else "obj (scripts/pretrain.bash:15)",
+                       "optimizer_pass": ("AdamW behind the step on a side stream, group by group in forward order; the next step's forward "
+                                          "waits per group (all of it inside the timed region)") if tr.opt_stream is not None
+                                         else "AdamW in front of the next forward",
                        "inputs": "4 synthetic minibatches per rank resident in HBM before the timed region: no H2D inside it "
                                  "(a batch is ~0.5 MB of int64 ids; SURVEY 8d counts its upload, 0.5 MB over PCIe ~ 10 us)",
                        "vis_mask": "--vis_mask_predict masks, n ~ U{1..64} per image (ref lxmert_data.py:414-419)",

@@ -313,6 +313,10 @@ int  xl_memset(void* dst, int value, int64_t bytes, void* stream);
 int64_t xl_event_create(void);
 int  xl_event_destroy(int64_t event);
 int  xl_stream_fork(void* event, void* from_stream, void* to_stream);
+/* the two halves of xl_stream_fork on their own (plan-able): a consumer stream waits, at a later point of ITS queue, for a point
+ * recorded earlier on a producer stream -- the next step's forward waiting layer by layer for the optimizer pass of the step before */
+int  xl_event_record(void* event, void* stream);
+int  xl_stream_wait(void* event, void* stream);
 int  xl_plan_fn_id(const char* name);
 int  xl_plan_fn_nargs(int fn_id);
 int64_t xl_plan_create(int n_calls, const int* fn_ids, const int* n_args, const uint64_t* words);

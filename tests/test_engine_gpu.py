@@ -795,6 +795,52 @@ def test_plan_replay_equals_eager_steps_bf16(drop):
     assert losses_p[4] != losses_p[7]
 
 
+@pytest.mark.parametrize("plan", [False, True])
+def test_overlapped_optimizer_equals_plain_steps_bf16(plan):
+    """PretrainStep(overlap_optimizer=True): AdamW runs behind the step on a CU-masked stream, group by group in forward order,
+    and the next forward waits group by group.  Against the plain trainer, full architecture, bf16, dropout on, full learning
+    rate from the first update (a forward that read a not-yet-updated group would show in the loss): 8 steps, both trainers
+    started from the same state each step (see test_plan_replay_equals_eager_steps_bf16 for why) -- same loss, gradient norm
+    and updated parameters; and the state the overlapped trainer leaves behind is complete (every group updated)."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig()
+    B = 64
+    g = torch.Generator().manual_seed(2)
+    mask_feat = torch.randn(cfg.visual_feat_dim, generator=g).relu() * 0.1
+    cent = torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu()
+    batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=70 + i).items()} for i in range(2)]
+    trs = []
+    for overlap in (False, True):
+        tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=3, lr=5e-4, warmup_ratio=0.0, total_steps=100,
+                          weight_decay=0.01, train_dropout=True, plan=(plan and overlap), drop_grads=True, overlap_optimizer=overlap)
+        assert (tr.opt_stream is not None) == overlap
+        tr.store.view("mask_feat").copy_(mask_feat)
+        tr.set_centroids(cent)
+        trs.append(tr)
+    te, to = trs
+    assert sum(hi - lo for _, lo, hi in to._opt_groups) == to.store.n_used
+    n = te.store.n_used
+    for t in range(8):
+        before = te.store.master[:n].clone()
+        le = te.step(batches[t % 2])[0:1].clone()
+        lo_ = to.step(batches[t % 2])[0:1].clone()
+        to.sync()
+        assert abs(le.item() - lo_.item()) <= 2e-5 * abs(le.item()), (t, le.item(), lo_.item())
+        assert abs(te.grad_norm() - to.grad_norm()) <= 2e-4 * te.grad_norm(), (t, te.grad_norm(), to.grad_norm())
+        assert to.store.grad[:n].abs().max().item() == 0                       # every group's pass ran (it clears the gradients)
+        pe, po = te.store.master[:n], to.store.master[:n]
+        moved = (pe - before).norm().item()
+        assert moved > 0 and (pe - po).norm().item() <= 2e-3 * moved, (t, (pe - po).norm().item(), moved)
+        assert torch.equal(to.store.compute[:n], to.store.master[:n].to(torch.bfloat16))      # the compute copy follows the master
+        for name in ("master", "exp_avg", "exp_avg_sq", "compute"):
+            getattr(to.store, name).copy_(getattr(te.store, name))
+        torch.cuda.synchronize()
+    assert int(to.step_dev.item()) == 8
+    if plan:
+        assert len(to._plans) >= 1
+
+
 def test_visual_attention_mask_hidden_states_and_pooled_gradient_fp32():
     from test_engine_cpu import check_vismask, make_vismask_engine
     from xlxmert_amd.ops import HipOps

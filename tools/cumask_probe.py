@@ -1,10 +1,10 @@
-"""Can the optimizer pass hide under the next step's forward?  AdamW on a CU-masked stream (hipExtStreamCreateWithCUMask): its
-HBM rate as a function of the number of CUs it may use, and what a chip-filling GEMM loses while it runs next to it.
-Usage: python tools/cumask_probe.py"""
+"""Is the GEMM CU-bound or power-bound, and can the optimizer pass hide under the next step's forward?  Kernels on CU-masked
+streams (hipExtStreamCreateWithCUMask): (a) a chip-filling GEMM restricted to fewer CUs, (b) AdamW's HBM rate as a function of
+the CUs it may use, (c) both at once.  Usage: python tools/cumask_probe.py"""
 import ctypes, sys, time
 import torch
 sys.path.insert(0, ".")
-from xlxmert_amd.ops import HipOps, EPI_GELU_DG
+from xlxmert_amd.ops import HipOps, EPI_GELU_DG, EPI_GELU, EPI_DGELU, EPI_MULAUX
 
 hip = ctypes.CDLL("libamdhip64.so")
 ops = HipOps(torch.bfloat16)
@@ -18,11 +18,16 @@ def adam(): ops.adamw(p, g, m, v, pc, flags, ss, lrs, n, 0.9, 0.999, 1e-6, 0.01,
 
 M, N, K = 16384, 3072, 768
 A = torch.randn(M, K, device="cuda").to(torch.bfloat16); B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
+Bn = torch.randn(K, N, device="cuda").to(torch.bfloat16)
 C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16); X = torch.zeros_like(C); bias = torch.randn(N, device="cuda")
-def gemm(): ops.gemm(A, B, C, bias, None, X, M, N, K, K, K, N, ldx=N, epilogue=EPI_GELU_DG)
+def gemm(epi=EPI_GELU_DG): ops.gemm(A, B, C, bias, None, X, M, N, K, K, K, N, ldx=N, epilogue=epi)
+def gemm_nn(epi): ops.gemm(A, Bn, C, None, None, X, M, N, K, K, N, N, ldx=N, b_kmajor=0, epilogue=epi)
 
-def masked_stream(pattern_bits):
-    words = (ctypes.c_uint32 * 8)(*([pattern_bits] * 8))
+def masked(ncu, lo=0):
+    bits = [0] * 8
+    for i in range(lo, lo + ncu):
+        bits[i // 32] |= 1 << (i % 32)
+    words = (ctypes.c_uint32 * 8)(*bits)
     st = ctypes.c_void_p()
     rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
     assert rc == 0, rc
@@ -30,8 +35,7 @@ def masked_stream(pattern_bits):
 
 def timed(fn, reps, stream=None):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
-    with ctx:
+    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
         for _ in range(2): fn()
         torch.cuda.synchronize()
         s.record()
@@ -40,18 +44,15 @@ def timed(fn, reps, stream=None):
     torch.cuda.synchronize()
     return s.elapsed_time(e) / reps
 
-print(f"adamw, all CUs: {timed(adam, 5) * 1e3:.0f} us ({34 * n / timed(adam, 5) / 1e9:.2f} TB/s at 34 B/element)")
-print(f"gemm 16384x3072x768 GELU alone: {timed(gemm, 20) * 1e3:.1f} us")
-for name, bits in (("32 CUs (1 of 8)", 0x01010101), ("64 CUs (1 of 4)", 0x11111111), ("96 CUs (3 of 8)", 0x49494949 & 0xffffffff),
-                   ("128 CUs (1 of 2)", 0x55555555), ("low 64 bits = 64 CUs", None)):
-    if bits is None:
-        words = (ctypes.c_uint32 * 8)(0xffffffff, 0xffffffff, 0, 0, 0, 0, 0, 0)
-        st = ctypes.c_void_p(); assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words) == 0
-        ms = torch.cuda.ExternalStream(st.value)
-    else:
-        ms = masked_stream(bits)
+print("epilogue pairs, same shape, isolated: GELU %.1f + DGELU %.1f us | GELU_DG %.1f + MULAUX %.1f us" % (
+    timed(lambda: gemm(EPI_GELU), 20) * 1e3, timed(lambda: gemm_nn(EPI_DGELU), 20) * 1e3,
+    timed(lambda: gemm(EPI_GELU_DG), 20) * 1e3, timed(lambda: gemm_nn(EPI_MULAUX), 20) * 1e3))
+print(f"adamw, all CUs: {timed(adam, 5) * 1e3:.0f} us;  gemm 16384x3072x768 (768 tiles) alone, all CUs: {timed(gemm, 20) * 1e3:.1f} us")
+for ncu in (224, 192, 160, 128, 64):
+    print(f"gemm on a {ncu}-CU stream: {timed(gemm, 20, masked(ncu)) * 1e3:.1f} us")
+for ncu, lo in ((32, 0), (64, 0), (64, 192), (96, 0), (128, 0)):
+    ms = masked(ncu, lo)
     t = timed(adam, 5, ms)
-    # GEMM on the default stream while AdamW runs on the masked one
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -61,8 +62,8 @@ for name, bits in (("32 CUs (1 of 8)", 0x01010101), ("64 CUs (1 of 4)", 0x111111
         a1.record()
     time.sleep(0.0005)
     s.record()
-    for _ in range(20): gemm()
+    for _ in range(30): gemm()
     e.record()
     torch.cuda.synchronize()
-    print(f"{name}: adamw alone {t * 1e3:.0f} us ({34 * n / t / 1e9:.2f} TB/s); next to 20 GEMMs: adamw {a0.elapsed_time(a1) / 3 * 1e3:.0f} us, "
-          f"gemm {s.elapsed_time(e) / 20 * 1e3:.1f} us")
+    print(f"adamw on CUs [{lo},{lo + ncu}): alone {t * 1e3:.0f} us ({34 * n / t / 1e9:.2f} TB/s); next to 30 GEMMs on the default stream: "
+          f"adamw {a0.elapsed_time(a1) / 3 * 1e3:.0f} us, gemm {s.elapsed_time(e) / 30 * 1e3:.1f} us")

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from xlxmert_amd.ops import HipOps, EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU
+from xlxmert_amd.ops import HipOps, EPI_NONE, EPI_GELU_DG as EPI_GELU, EPI_RESIDUAL, EPI_MULAUX as EPI_DGELU      # the FFN pair as the step runs it
 
 ops = HipOps(torch.bfloat16)
 dev = "cuda"

@@ -2,6 +2,7 @@
 //   grad-norm (ref lxmert_pretrain.py:343-353), transformers==4.1.1 AdamW (ref :110-141), dtype casts.
 #include <stdarg.h>
 #include "common.h"
+#include <algorithm>
 
 namespace xl {
 
@@ -43,8 +44,8 @@ __device__ __forceinline__ void store4(bf16_t* dst, const float (&a)[4]) {      
 }
 
 // one thread = 4 consecutive parameters (n is padded to a multiple of 256 by the caller's layout)
-template <typename T>
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+template <typename T, int TH = 256>
+__global__ __launch_bounds__(TH) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, T* __restrict__ pc, const uint8_t* __restrict__ decay,
                                                     const int* __restrict__ chunk_steps,
                                                     const float* __restrict__ sumsq, const float* __restrict__ lrs, int64_t n4,
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         clip *= fminf(1.0f, max_norm / (norm + 1e-6f));
     }
     const float step0 = lr * sqrtf(bc2) / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * TH + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TH) {
         const uint8_t fl = decay != nullptr ? decay[i >> 6] : 0;                  // 256-element chunks: bit 0 decay, bit 1 skip
         if (fl & 2) continue;              // tensor without a gradient this step: the reference's AdamW does not touch it
         float step = step0;
@@ -153,12 +154,23 @@ extern "C" int xl_adamw(float* p, float* g, float* m, float* v, void* p_compute,
     XL_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), XL_ERR_UNALIGNED, "xl_adamw: unaligned buffer");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n4 = n >> 2;
-    if (dtype == XL_BF16)
-        hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_compute,
+    // One persistent workgroup of 1024 threads per CU (a 128 KiB LDS request keeps it at one), grid-stride: 1134 -> 1008 us for the
+    // step's 202 M parameters (6.9 GB: 6.8 TB/s) against 4096 blocks of 256 threads -- fewer, longer-lived waves keep more
+    // 16-byte loads in flight per CU and leave no tail of half-empty CUs.
+    constexpr int TH = 1024, LDS = 131072;
+    const int grid = (int)std::min<int64_t>(256, (n4 + TH - 1) / TH);
+    static bool attr_b = false, attr_f = false;
+    if (dtype == XL_BF16) {
+        auto k = adamw_kernel<bf16_t, TH>;
+        if (!attr_b) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_b = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(TH), LDS, st, p, g, m, v, (bf16_t*)p_compute,
                            decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale, zero_grad);
-    else if (dtype == XL_F32)
-        hipLaunchKernelGGL((adamw_kernel<float>), dim3(stream_grid(n4)), dim3(256), 0, st, p, g, m, v, (float*)p_compute,
+    } else if (dtype == XL_F32) {
+        auto k = adamw_kernel<float, TH>;
+        if (!attr_f) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_f = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(TH), LDS, st, p, g, m, v, (float*)p_compute,
                            decay_flags, chunk_steps, sumsq, lr_and_steps, n4, beta1, beta2, eps, weight_decay, max_norm, grad_scale, zero_grad);
+    }
     else { set_error("xl_adamw: bad dtype %d", dtype); return XL_ERR_BAD_DTYPE; }
     XL_CHECK_LAUNCH();
     return XL_OK;

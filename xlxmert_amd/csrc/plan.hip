@@ -56,7 +56,7 @@ static const PlanFn kFns[] = {
     XL_PLAN_FN(xl_ce_fwd_bwd), XL_PLAN_FN(xl_featloss_fwd_bwd), XL_PLAN_FN(xl_gather_rows), XL_PLAN_FN(xl_scatter_rows),
     XL_PLAN_FN(xl_gather_labels), XL_PLAN_FN(xl_sumsq), XL_PLAN_FN(xl_schedule_step), XL_PLAN_FN(xl_adamw),
     XL_PLAN_FN(xl_cast_from_f32), XL_PLAN_FN(xl_cast_to_f32), XL_PLAN_FN(xl_memset), XL_PLAN_FN(xl_stream_fork),
-    XL_PLAN_FN(xl_rowmax_combine),
+    XL_PLAN_FN(xl_rowmax_combine), XL_PLAN_FN(xl_event_record), XL_PLAN_FN(xl_stream_wait),
 };
 constexpr int kNumFns = sizeof(kFns) / sizeof(kFns[0]);
 
@@ -100,6 +100,20 @@ extern "C" int xl_stream_fork(void* event, void* from_stream, void* to_stream) {
     hipError_t e = hipEventRecord((hipEvent_t)event, (hipStream_t)from_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)event, 0);
     XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_stream_fork: %s", hipGetErrorString(e));
+    return XL_OK;
+}
+
+extern "C" int xl_event_record(void* event, void* stream) {
+    XL_CHECK_ARG(event != nullptr, XL_ERR_BAD_ARG, "xl_event_record: null event");
+    hipError_t e = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+    XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_event_record: %s", hipGetErrorString(e));
+    return XL_OK;
+}
+
+extern "C" int xl_stream_wait(void* event, void* stream) {
+    XL_CHECK_ARG(event != nullptr, XL_ERR_BAD_ARG, "xl_stream_wait: null event");
+    hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+    XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_stream_wait: %s", hipGetErrorString(e));
     return XL_OK;
 }
 

@@ -718,6 +718,14 @@ class Engine:
     def lang_stream(self):
         return Engine._LangStream(self)
 
+    # Set by a trainer whose optimizer pass runs behind the step on its own stream (trainer.PretrainStep overlap_optimizer): called
+    # with the key of a parameter group right before the forward first reads it, on the stream that reads it.
+    params_ready = None
+
+    def _pr(self, key):
+        if self.params_ready is not None:
+            self.params_ready(key)
+
     def fork(self):
         """language stream waits for everything queued so far on the main (visual) stream."""
         if self.side is not None:
@@ -967,6 +975,7 @@ class Engine:
         self.fork()
         with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream
             e = "bert.embeddings"
+            self._pr("emb")
             emb = getattr(self, "embeds_mode", False)
             ops.embed_ln_fwd(self._emb_ids if emb else self.ids, self.tt,
                              self._emb_tab if emb else st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
@@ -977,11 +986,13 @@ class Engine:
                 ops.dropout(self.emb_y, self.emb_y, ML, d, d, d, self.p_hid, self.seed(0))
             x = self.emb_y
             for i, (sa, ffn) in enumerate(self.lang_layers):
+                self._pr(("lang", i))
                 sa.fwd(x, self.lang_mid[i])
                 y = X0[:ML] if i == cfg.l_layers - 1 else self.lang_out[i]
                 ffn.fwd(self.lang_mid[i], y)
                 x = y
         # ---- visual feature encoder + relational stack (HF:513, 524-529) on the main stream
+        self._pr("visn")
         if self.use_codebook:
             ops.codebook_gather(self.cid, self.vmask if self.has_vmask else None, st.centroids_c, st.view("mask_feat"),
                                 self.feats, MV, self.F)
@@ -997,6 +1008,7 @@ class Engine:
             ops.dropout(self.vis0, self.vis0, MV, d, d, d, self.p_hid, self.seed(1))
         x = self.vis0
         for i, (sa, ffn) in enumerate(self.vis_layers):
+            self._pr(("vis", i))
             sa.fwd(x, self.vis_mid[i])
             y = X0[ML:] if i == cfg.r_layers - 1 else self.vis_out[i]
             ffn.fwd(self.vis_mid[i], y)
@@ -1004,6 +1016,7 @@ class Engine:
         self.join()
         for i, blk in enumerate(self.x_layers):
             Xi, Y, S, Xo = self.X[i], self.XY[i], self.XS[i], self.X[i + 1]
+            self._pr(("x", i))              # (the language stream forks from this stream after the wait and inherits it)
             blk["cross"].fwd(Xi, Y)
             if blk["lang_on"]:
                 self.fork()
@@ -1017,6 +1030,7 @@ class Engine:
                 self.join()
         Xl = self.X[-1]
         self.lang_final, self.vis_final = Xl[:ML], Xl[ML:]
+        self._pr("heads")                   # pooler and every head on top of the encoder
         if want_pooled and self.need_lang:
             # LxmertPooler (HF:566-572): tanh(dense(lang[:, 0]))
             ops.gemm(self.lang_final, st.cview("bert.pooler.dense.weight"), self.pooled, st.view("bert.pooler.dense.bias"),

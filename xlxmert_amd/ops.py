@@ -79,6 +79,18 @@ class HipOps:
         cls._ev_next += 1
         self.lib.call("xl_stream_fork", ev, from_stream.cuda_stream, to_stream.cuda_stream)
 
+    def new_event(self):
+        ev = int(self.lib.raw("xl_event_create")())
+        if not ev:
+            raise XlError("xl_event_create failed")
+        return ev
+
+    def event_record(self, ev, stream):
+        self.lib.call("xl_event_record", ev, stream.cuda_stream)
+
+    def stream_wait(self, ev, stream):
+        self.lib.call("xl_stream_wait", ev, stream.cuda_stream)
+
     def set_step_seed_ptr(self, step_seed):
         """device tensor (one int64 >= 0) holding the step part of every dropout seed, or None (xl_set_step_seed_ptr)."""
         self.lib.call("xl_set_step_seed_ptr", self._p(step_seed))

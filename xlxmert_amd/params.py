@@ -271,6 +271,46 @@ class ParamStore:
         us = [u for u in self.units if u.used and u.members[0].name.startswith(prefix)]
         return min(u.offset for u in us), max(u.offset + u.padded for u in us)
 
+    @staticmethod
+    def group_key(name):
+        """parameter group in the order the FORWARD first reads it (the optimizer pass updates group by group in that order when
+        it runs behind the step, trainer overlap_optimizer): visual feature encoder, embeddings, language / visual / cross layer
+        i, heads (everything on top of the encoder)."""
+        for prefix, kind in (("bert.encoder.layer.", "lang"), ("bert.encoder.r_layers.", "vis"), ("bert.encoder.x_layers.", "x")):
+            if name.startswith(prefix):
+                return (kind, int(name[len(prefix):].split(".")[0]))
+        if name.startswith("bert.embeddings."):
+            return "emb"
+        if name.startswith("bert.encoder.visn_fc.") or name == "mask_feat":
+            return "visn"
+        return "heads"
+
+    def forward_groups(self):
+        """[(key, lo, hi)]: contiguous element ranges of the used part of the flat buffers, one or more per group, listed in the
+        order the forward consumes the groups (language and visual stacks interleaved, as they run side by side)."""
+        runs = []
+        for u in self.units:
+            if not u.used:
+                continue
+            k = self.group_key(u.members[0].name)
+            if runs and runs[-1][0] == k and runs[-1][2] == u.offset:
+                runs[-1][2] = u.offset + u.padded
+            else:
+                runs.append([k, u.offset, u.offset + u.padded])
+        cfg = self.cfg
+        order = ["visn", "emb"]
+        li = vi = 0
+        while li < cfg.l_layers or vi < cfg.r_layers:       # ~2 language layers per visual layer: what the two streams consume
+            for _ in range(2):
+                if li < cfg.l_layers:
+                    order.append(("lang", li)); li += 1
+            if vi < cfg.r_layers:
+                order.append(("vis", vi)); vi += 1
+        order += [("x", i) for i in range(cfg.x_layers)] + ["heads"]
+        rank = {k: i for i, k in enumerate(order)}
+        assert all(r[0] in rank for r in runs), [r[0] for r in runs if r[0] not in rank]
+        return [tuple(r) for r in sorted(runs, key=lambda r: rank[r[0]])]
+
     def names(self):
         return list(self.index.keys())
 

@@ -52,7 +52,7 @@ class PretrainStep:
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
                  bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None,
-                 plan=None, drop_grads=None):
+                 plan=None, drop_grads=None, overlap_optimizer=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -77,7 +77,14 @@ class PretrainStep:
         drop_grads: the optimizer pass clears the gradient buffer itself (the reference's optim.zero_grad(),
         lxmert_pretrain.py:241, folded into xl_adamw: 4 bytes per element more in that pass instead of a separate 0.8 GB
         clear before the next backward); store.grad is then zero after step().  Default: on with `plan`, else off (the
-        gradients of the last step stay readable).  Not with task="all" (skipped tensors keep their buffers)."""
+        gradients of the last step stay readable).  Not with task="all" (skipped tensors keep their buffers).
+        overlap_optimizer: the AdamW pass (HBM-bound: 34 bytes per parameter, no matrix work) runs BEHIND the step on the language
+        stream's weight-gradient companion stream (idle until the next backward), group by group in the order the forward reads
+        the parameters, and the next step's forward waits group by group (engine.params_ready): the matrix units start the next
+        forward ~0.2 ms after the gradient norm instead of after the whole pass (-0.15...-0.4 ms per step measured; a CU-masked
+        stream for the pass, hipExtStreamCreateWithCUMask, was measured too: +14 ms per step, whatever the number of hardware
+        queues).  Same arithmetic per element.  Parameters / optimizer state read from another stream need `sync()` first.  Default off
+        (env XL_OPT_OVERLAP=1|0 overrides); HIP path only."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -126,8 +133,28 @@ class PretrainStep:
         self.plan_mode = self.plan_mode and isinstance(self.ops, HipOps) and not self.exchange and task == "vis_mask"
         self._plans, self._plan_warm = {}, False
         self.drop_grads = (self.plan_mode if drop_grads is None else bool(drop_grads)) and task != "all"
+        env = os.environ.get("XL_OPT_OVERLAP")
+        overlap = bool(int(env)) if env else bool(overlap_optimizer)
+        self.opt_stream = None
+        if overlap and isinstance(self.ops, HipOps) and self.device.type == "cuda" and self.engine._dw is not None:
+            self.opt_stream = self.engine._dw["l"]
+            self._opt_groups = self.store.forward_groups()
+            self._opt_events = {k: self.ops.new_event() for k, _, _ in self._opt_groups}
+            self._opt_last = {k: i for i, (k, _, _) in enumerate(self._opt_groups)}      # a group's last range closes it
+            self.engine.params_ready = self._wait_params
         if self.world > 1:
             self.sync_replicas()
+
+    def _wait_params(self, key):
+        """engine hook: the current stream is about to read the parameters of group `key` -- wait for the optimizer pass of
+        the previous step to have updated them (no-op before the first update: the event has never been recorded)."""
+        ev = self._opt_events.get(key)
+        if ev is not None:
+            self.ops.stream_wait(ev, torch.cuda.current_stream())
+
+    def sync(self):
+        """everything this trainer has queued (the optimizer stream included) is done."""
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
 
     def sync_replicas(self):
         """DDP's constructor broadcast (ref lxmert_pretrain.py:102-106): rank 0's parameters AND optimizer state (Adam
@@ -148,6 +175,7 @@ class PretrainStep:
     def verify_replicas(self):
         """names of the tensors (parameters, Adam moments) whose per-tensor checksum differs between ranks -- [] when the
         replicas agree.  One float64 sum per tensor and buffer, MIN / MAX all-reduced: cheap enough for every N-th step."""
+        self.sync()                              # (an optimizer pass running behind the step: finish it first)
         st = self.store
         names = [n for n in st.index if st.index[n].offset < st.n_used]
         sums = []
@@ -336,6 +364,25 @@ class PretrainStep:
         if self.chunk_steps is not None:
             flags = st.task_flags(self._step_task)
             self.chunk_steps.add_(((flags & 2) == 0).to(torch.int32))
+        if self.opt_stream is not None:
+            # behind the step, on a stream that is idle until the next backward: one launch per parameter group in forward order,
+            # an event per group
+            main = torch.cuda.current_stream()
+            ops.stream_fork(main, self.opt_stream)
+            cs = self.chunk_steps
+            with torch.cuda.stream(self.opt_stream):
+                for i, (key, lo, hi) in enumerate(self._opt_groups):
+                    c0, c1 = lo // 256, hi // 256
+                    ops.adamw(st.master[lo:hi], st.grad[lo:hi], st.exp_avg[lo:hi], st.exp_avg_sq[lo:hi],
+                              st.compute[lo:hi] if st.compute_dtype != torch.float32 else None, flags[c0:c1],
+                              self.sumsq if self.clip > 0 else None, self.lrs, hi - lo, b1, b2, self.eps, self.wd, self.clip,
+                              grad_scale=1.0 / self.world, chunk_steps=cs[c0:c1] if cs is not None else None,
+                              zero_grad=self.drop_grads)
+                    if self._opt_last[key] == i:
+                        ops.event_record(self._opt_events[key], self.opt_stream)
+            if self.drop_grads:
+                self.engine.grad_is_zero = True
+            return
         ops.adamw(st.master, st.grad, st.exp_avg, st.exp_avg_sq,
                   st.compute if st.compute_dtype != torch.float32 else None, flags,
                   self.sumsq if self.clip > 0 else None, self.lrs, n, b1, b2, self.eps, self.wd, self.clip,
