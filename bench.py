@@ -175,7 +175,7 @@ def other_workloads(cfg, dev, steps=8, warm=3):
     # N1: VQA / GQA fine-tune step (3129 answers, real 2048-d grid features in; config 3 = bs 512 over 4 GPUs -> 128 per GPU,
     # and the full 512 on one GPU)
     for B in (128, 512):
-        tr = PretrainStep(cfg, B, 20, 64, device=dev, task="vqa", num_answers=3129, train_dropout=True, total_steps=1000)
+        tr = PretrainStep(cfg, B, 20, 64, device=dev, task="vqa", num_answers=3129, train_dropout=True, total_steps=1000, overlap_optimizer=True)
         b = {k: v.to(dev) for k, v in synthetic_batch(cfg, B, 20, 8, seed=7).items()}
         tgt = torch.zeros(B, 3129)
         tgt[torch.arange(B), torch.randint(0, 3129, (B,), generator=g)] = 1.0
@@ -185,7 +185,7 @@ def other_workloads(cfg, dev, steps=8, warm=3):
         del tr, batch
     # N1: NLVR2 step (128 statements x 2 images = 256 encoder rows, ref tasks/nlvr2_model.py:50-86)
     P = 128
-    tr = PretrainStep(cfg, 2 * P, 20, 64, device=dev, task="nlvr2", train_dropout=True, total_steps=1000)
+    tr = PretrainStep(cfg, 2 * P, 20, 64, device=dev, task="nlvr2", train_dropout=True, total_steps=1000, overlap_optimizer=True)
     b = synthetic_batch(cfg, P, 20, 8, seed=8)
     batch = {"input_ids": b["input_ids"].repeat_interleave(2, 0).to(dev), "visual_pos": b["visual_pos"][:, None].expand(-1, 2, -1, -1).contiguous().to(dev),
              "visual_feats": feats(P, 2, 64), "labels": torch.randint(0, 2, (P,), generator=g).to(dev)}
@@ -195,7 +195,7 @@ def other_workloads(cfg, dev, steps=8, warm=3):
     # N3: language pretraining branches (30522-way tied decoder on the labelled rows / matched head), bs 256
     B = 256
     for task in ("word_mask", "matched"):
-        tr = PretrainStep(cfg, B, 20, 64, device=dev, task=task, train_dropout=True, total_steps=1000)
+        tr = PretrainStep(cfg, B, 20, 64, device=dev, task=task, train_dropout=True, total_steps=1000, overlap_optimizer=True)
         tr.set_centroids(cents)
         b = synthetic_batch(cfg, B, 20, 8, seed=9)
         ids, wl = random_word_batch(b["input_ids"], generator=g)

@@ -673,15 +673,18 @@ def test_word_mask_full_size_step_properties_bf16():
     assert store.gview("bert.embeddings.word_embeddings.weight")[0].abs().max().item() > 0
 
 
-def test_task_round_robin_full_size_bf16():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_task_round_robin_full_size_bf16(overlap):
     """one multi-task parameter set, full size: vis_mask / word_mask / matched steps in turn; tensors outside a step's branch
-    are bit-identical after it, everything stays finite."""
+    are bit-identical after it, everything stays finite.  overlap: the optimizer pass queued behind the step, group by group
+    (per-chunk skip flags and update counts sliced per group)."""
     from xlxmert_amd.config import XLxmertConfig
     from xlxmert_amd.trainer import PretrainStep, synthetic_batch, word_rows_of
     cfg = XLxmertConfig()
     B = 64
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=2, task="all", train_dropout=True, warmup_ratio=0.0,
-                      total_steps=100)
+                      total_steps=100, overlap_optimizer=overlap)
+    assert (tr.opt_stream is not None) == overlap
     g = torch.Generator().manual_seed(0)
     tr.store.view("mask_feat").copy_(torch.randn(cfg.visual_feat_dim, generator=g).relu())
     tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
@@ -717,8 +720,9 @@ def test_ar_sampler_fp32_matches_reference_fixture(mode):
     check_ar_sampler(g, eng, mode)
 
 
-def test_training_reduces_the_loss_full_size_bf16():
-    """end-to-end sanity at the full architecture: 40 optimisation steps on ONE fixed batch (bf16, dropout on, clip, AdamW,
+@pytest.mark.parametrize("overlap", [False, True])
+def test_training_reduces_the_loss_full_size_bf16(overlap):
+    """end-to-end sanity at the full architecture (overlap: with the optimizer pass behind the step): 40 optimisation steps on ONE fixed batch (bf16, dropout on, clip, AdamW,
     warm-up) must drive the masked-token loss down from ~ln(10000) -- every kernel, the hand-derived backward and the optimizer
     have to agree for that."""
     from xlxmert_amd.config import XLxmertConfig
@@ -726,7 +730,7 @@ def test_training_reduces_the_loss_full_size_bf16():
     cfg = XLxmertConfig()
     B = 32
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=3, lr=2e-4, warmup_ratio=0.1, total_steps=60,
-                      train_dropout=True)
+                      train_dropout=True, overlap_optimizer=overlap)
     g = torch.Generator().manual_seed(1)
     tr.store.view("mask_feat").copy_(torch.randn(cfg.visual_feat_dim, generator=g).relu() * 0.1)
     tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
