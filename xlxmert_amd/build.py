@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxlxmert_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip"]
+SOURCES = ["gemm_pp.hip", "gemm_pp_nn.hip", "gemm_pp_192.hip", "gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -51,7 +51,7 @@ def build_library(force=False, verbose=True):
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, SOURCES))
     if not force and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
         return LIB                                      # every object up to date and already linked
