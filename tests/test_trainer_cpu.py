@@ -411,3 +411,27 @@ def test_optimizer_pass_clears_the_gradients_when_asked():
     assert not drop.engine.grad_is_zero
     batch = synthetic_batch(cfg, B, L, grid, seed=300)
     assert torch.equal(keep.step(batch), drop.step(batch)) and torch.equal(keep.store.master, drop.store.master)
+
+
+@pytest.mark.parametrize("task,num_answers", [("vis_mask", 0), ("vqa", 29), ("nlvr2", 0), ("all", 0), ("word_mask", 13)])
+def test_forward_groups_tile_the_optimizer_range(task, num_answers):
+    """ParamStore.forward_groups (the order in which an optimizer pass queued behind the step updates the parameters): the ranges
+    tile [0, n_used) exactly, every range is chunk-aligned and holds tensors of ONE group, and the groups come in the order the
+    forward first reads them (feature encoder and embeddings, language / visual layers ascending, cross layers, heads last)."""
+    cfg = XLxmertConfig(**TINY)
+    st = ParamStore(cfg, "cpu", torch.float32, task=task, num_answers=num_answers)
+    groups = st.forward_groups()
+    assert sum(hi - lo for _, lo, hi in groups) == st.n_used
+    covered = sorted((lo, hi) for _, lo, hi in groups)
+    assert covered[0][0] == 0 and covered[-1][1] == st.n_used and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert all(lo % 256 == 0 and hi % 256 == 0 for _, lo, hi in groups)
+    for key, lo, hi in groups:
+        for u in st.units:
+            if u.used and lo <= u.offset < hi:
+                assert all(ParamStore.group_key(m.name) == key for m in u.members), (key, [m.name for m in u.members])
+    keys = [k for k, _, _ in groups]
+    assert keys[0] == "visn" and keys[1] == "emb" and keys[-1] == "heads"
+    for kind, n in (("lang", cfg.l_layers), ("vis", cfg.r_layers), ("x", cfg.x_layers)):
+        idx = [keys.index((kind, i)) for i in range(n)]
+        assert idx == sorted(idx)
+    assert max(keys.index(("lang", cfg.l_layers - 1)), keys.index(("vis", cfg.r_layers - 1))) < keys.index(("x", 0))
