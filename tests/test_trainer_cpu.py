@@ -110,7 +110,8 @@ def test_visual_losses_default_is_obj_only_and_feat_labels_are_used():
     assert abs(out["feat_loss"].item() - out_c["feat_loss"].item()) > 1e-3        # the targets really differ from the centroids
 
 
-def test_vqa_two_steps_match_closed_form():
+@pytest.mark.parametrize("grouped", [False, True])
+def test_vqa_two_steps_match_closed_form(grouped):
     """VQA fine-tune step semantics (BCE loss, clip 1.0, 4.1.1-AdamW incl. the decayed `logit_fc.2.weight`
     LayerNorm, linear schedule) against the oracle, two consecutive updates."""
     cfg = XLxmertConfig(**TINY)
@@ -120,7 +121,9 @@ def test_vqa_two_steps_match_closed_form():
     sd = O.make_vqa_state_dict(oc, A, 5)
     store.load_named(sd)
     tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
-                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="vqa", num_answers=A)
+                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="vqa", num_answers=A,
+                      overlap_optimizer=grouped)        # grouped: the optimizer pass issued group by group in forward order
+    assert (tr._opt_groups is not None) == grouped and tr.opt_stream is None
     names = [n for n in store.index if store.index[n] is not None and
              any(m.name == n for u in store.units if u.used for m in u.members)]
     ref = {k: v.clone() for k, v in sd.items()}
@@ -177,7 +180,8 @@ def test_nlvr2_step_matches_closed_form():
         assert (tr.store.view(k) - ref.detach()).abs().max().item() < 2e-5, k
 
 
-def test_task_round_robin_on_one_parameter_set():
+@pytest.mark.parametrize("grouped", [False, True])
+def test_task_round_robin_on_one_parameter_set(grouped):
     """vis_mask -> word_mask -> matched -> vis_mask on ONE parameter set (ref lxmert_pretrain.py:296-298).
     The reference sets .grad = None after every step, so AdamW touches only the tensors of the step's branch and each
     tensor keeps its own update count (bias correction); checked against the oracle with that per-tensor state."""
@@ -188,7 +192,8 @@ def test_task_round_robin_on_one_parameter_set():
     sd = O.make_cls_state_dict(oc, 11)
     store.load_named(sd)
     tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cpu", store=store, ops=FakeOps(torch.float32),
-                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="all", visual_losses="obj,feat")
+                      total_steps=10, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2, task="all", visual_losses="obj,feat",
+                      overlap_optimizer=grouped)      # grouped: per-chunk skip flags and update counts sliced per parameter group
     ref = {k: v.clone() for k, v in sd.items() if k != "cls.predictions.decoder.weight"}
     ref["obj_predict_head.out_cluster.weight"] = ref["vis_emb.weight"]
     m = {k: torch.zeros_like(v) for k, v in ref.items()}

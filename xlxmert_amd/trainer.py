@@ -9,6 +9,7 @@ one forward, one backward, gradient all-reduce (DDP mean), `clip_grad_norm_(1.0)
 `weight_decay` (default 0.0 = the 4.1.1 class default) and `warmup_ratio` (default 0.05, what
 scripts/pretrain.bash suggests) have no value anywhere in the reference: assumptions.
 """
+import contextlib
 import math
 import os
 
@@ -135,13 +136,16 @@ class PretrainStep:
         self.drop_grads = (self.plan_mode if drop_grads is None else bool(drop_grads)) and task != "all"
         env = os.environ.get("XL_OPT_OVERLAP")
         overlap = bool(int(env)) if env else bool(overlap_optimizer)
-        self.opt_stream = None
-        if overlap and isinstance(self.ops, HipOps) and self.device.type == "cuda" and self.engine._dw is not None:
-            self.opt_stream = self.engine._dw["l"]
+        self.opt_stream, self._opt_groups = None, None
+        if overlap:
+            # the pass is issued group by group in forward order; on the HIP path it also moves to the side stream, with an
+            # event per group (injected host ops -- the CPU test-suite -- run the same grouped pass in place)
             self._opt_groups = self.store.forward_groups()
-            self._opt_events = {k: self.ops.new_event() for k, _, _ in self._opt_groups}
             self._opt_last = {k: i for i, (k, _, _) in enumerate(self._opt_groups)}      # a group's last range closes it
-            self.engine.params_ready = self._wait_params
+            if isinstance(self.ops, HipOps) and self.device.type == "cuda" and self.engine._dw is not None:
+                self.opt_stream = self.engine._dw["l"]
+                self._opt_events = {k: self.ops.new_event() for k, _, _ in self._opt_groups}
+                self.engine.params_ready = self._wait_params
         if self.world > 1:
             self.sync_replicas()
 
@@ -364,13 +368,14 @@ class PretrainStep:
         if self.chunk_steps is not None:
             flags = st.task_flags(self._step_task)
             self.chunk_steps.add_(((flags & 2) == 0).to(torch.int32))
-        if self.opt_stream is not None:
+        if self._opt_groups is not None:
             # behind the step, on a stream that is idle until the next backward: one launch per parameter group in forward order,
             # an event per group
-            main = torch.cuda.current_stream()
-            ops.stream_fork(main, self.opt_stream)
+            side = self.opt_stream
+            if side is not None:
+                ops.stream_fork(torch.cuda.current_stream(), side)
             cs = self.chunk_steps
-            with torch.cuda.stream(self.opt_stream):
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 for i, (key, lo, hi) in enumerate(self._opt_groups):
                     c0, c1 = lo // 256, hi // 256
                     ops.adamw(st.master[lo:hi], st.grad[lo:hi], st.exp_avg[lo:hi], st.exp_avg_sq[lo:hi],
@@ -378,8 +383,8 @@ class PretrainStep:
                               self.sumsq if self.clip > 0 else None, self.lrs, hi - lo, b1, b2, self.eps, self.wd, self.clip,
                               grad_scale=1.0 / self.world, chunk_steps=cs[c0:c1] if cs is not None else None,
                               zero_grad=self.drop_grads)
-                    if self._opt_last[key] == i:
-                        ops.event_record(self._opt_events[key], self.opt_stream)
+                    if side is not None and self._opt_last[key] == i:
+                        ops.event_record(self._opt_events[key], side)
             if self.drop_grads:
                 self.engine.grad_is_zero = True
             return
