@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include "common.h"
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 namespace xl {
 
@@ -17,8 +19,15 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* out, int64_t n) {
+// Sum of squares, DETERMINISTIC: every block leaves its partial in a scratch slot, the last block to arrive (ticket) adds the
+// partials in index order and makes the single update of *out.  With one fp32 atomic per block (as before) the summation order --
+// and with it the last bit of the gradient norm, the clip factor and every parameter -- differed from rank to rank: found by the
+// two-rank test on one GPU (replicas 1 ulp apart after one step), invisible to one-rank runs and to host restatements.
+constexpr int SUMSQ_MAX_BLOCKS = 4096;
+struct SumsqScratch { float part[SUMSQ_MAX_BLOCKS]; unsigned int ticket; };
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* out, int64_t n, SumsqScratch* sc) {
     __shared__ float red[4];
+    __shared__ bool last;
     float s = 0.f;
     const int64_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -31,7 +40,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&sc->part[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int t = __hip_atomic_fetch_add(&sc->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    // fixed order: thread t sums slots t, t + 256, ...; then the same wave / block tree as above
+    float a = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(&sc->part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = wave_sum(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *out += (red[0] + red[1]) + (red[2] + red[3]);
+        __hip_atomic_store(&sc->ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
 }
 
 __device__ __forceinline__ void store4(float* dst, const float (&a)[4]) {
@@ -140,7 +166,21 @@ extern "C" int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, 
 
 extern "C" int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream) {
     XL_CHECK_ARG(g && sumsq && n > 0 && aligned16(g), XL_ERR_BAD_ARG, "xl_sumsq: bad args");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, g, sumsq, n);
+    // scratch for the block partials: a small ring, so that calls in flight on different streams do not share one
+    static SumsqScratch* ring[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static std::atomic<unsigned> next{0};
+    const unsigned slot = next.fetch_add(1) & 7u;
+    if (ring[slot] == nullptr) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (ring[slot] == nullptr) {
+            SumsqScratch* p = nullptr;
+            XL_CHECK_ARG(hipMalloc(&p, sizeof(SumsqScratch)) == hipSuccess && hipMemset(p, 0, sizeof(SumsqScratch)) == hipSuccess,
+                         XL_ERR_HIP, "xl_sumsq: scratch allocation failed");
+            ring[slot] = p;
+        }
+    }
+    hipLaunchKernelGGL(sumsq_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, g, sumsq, n, ring[slot]);
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
