@@ -941,3 +941,105 @@ def test_data_parallel_two_ranks_real_kernels_one_gpu(tmp_path, overlap):
     for k, g in zip(names, clipped):
         p, _, _ = O.adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr)
         assert (r0[k] - p).abs().max().item() < 5e-5, (k, (r0[k] - p).abs().max().item())
+
+
+def _gpu_dp_worker_full(rank, world, port, out_dir, comm):
+    import torch.distributed as dist
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import reserve_streams
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    reserve_streams("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = XLxmertConfig()
+    B = 32
+    tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda:0", seed=3, lr=2e-4, warmup_ratio=0.0, total_steps=100,
+                      train_dropout=True, overlap_optimizer=True, grad_comm_dtype=comm)
+    g = torch.Generator().manual_seed(1)
+    tr.store.view("mask_feat").copy_(torch.randn(cfg.visual_feat_dim, generator=g).relu() * 0.1)
+    tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
+    assert tr.exchange and (tr.comm_buf is not None) == (comm == torch.bfloat16)
+    losses = []
+    for t in range(3):
+        batch = {k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=900 + 10 * t + rank).items()}
+        losses.append(tr.step(batch)[0:1].clone())
+        bad = tr.verify_replicas()
+        assert bad == [], (t, len(bad), bad[:8])
+    tr.sync()
+    assert all(torch.isfinite(l).all() for l in losses) and torch.isfinite(tr.store.master).all()
+    torch.save({"norm": tr.grad_norm(), "p": tr.store.master[:4096].cpu().clone()}, os.path.join(out_dir, f"f{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm", [torch.float32, torch.bfloat16])
+def test_data_parallel_two_ranks_full_size_bf16_replicas_stay_identical(tmp_path, comm):
+    """the benchmarked architecture (bf16, ping-pong GEMMs, grouped weight gradients, deferred reductions, four streams, dropout,
+    optimizer pass behind the step) on two ranks sharing one GPU, fp32 and bf16 gradient buckets: after each of three steps every
+    parameter and Adam moment is bit-identical on both ranks (per-tensor checksums), i.e. nothing after the exchange depends on
+    the rank -- each rank's dropout masks and minibatch do differ."""
+    import torch.multiprocessing as mp
+    from test_trainer_cpu import _free_port
+    world, port = 2, _free_port()
+    mp.spawn(_gpu_dp_worker_full, args=(world, port, str(tmp_path), comm), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "f0.pt"), torch.load(tmp_path / "f1.pt")
+    assert r0["norm"] == r1["norm"] and torch.equal(r0["p"], r1["p"])
+
+
+def _gpu_dp_worker_tasks(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from test_trainer_cpu import TINY, oracle_cfg
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import reserve_streams
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    reserve_streams("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    B, L, grid = 2, 8, 4
+    cuda = lambda d: {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
+    # VQA fine-tune step and NLVR2 step
+    A = 29
+    store = ParamStore(cfg, "cuda:0", torch.float32, task="vqa", num_answers=A)
+    store.load_named(O.make_vqa_state_dict(oc, A, 5))
+    trv = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cuda:0", store=store, total_steps=10, lr=1e-2,
+                       task="vqa", num_answers=A, bucket_mb=0.05, overlap_optimizer=True)
+    trv.step(cuda(O.make_vqa_inputs(oc, A, 600 + rank, B, L, grid)))
+    assert trv.verify_replicas() == []
+    trn = PretrainStep(cfg, 2 * B, L, grid * grid, dtype=torch.float32, device="cuda:0", total_steps=10, lr=1e-2, task="nlvr2",
+                       bucket_mb=0.05, overlap_optimizer=True)
+    trn.step(cuda(O.make_nlvr2_inputs(oc, 650 + rank, B, L, grid)))
+    assert trn.verify_replicas() == []
+    # task round-robin on one parameter set with the QA head riding on every branch
+    NQ = 11
+    store = ParamStore(cfg, "cuda:0", torch.float32, task="all", num_answers=NQ)
+    store.load_named(O.make_qa_state_dict(oc, NQ, 9))
+    tra = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cuda:0", store=store, total_steps=10, lr=1e-2,
+                       task="all", num_answers=NQ, bucket_mb=0.05, visual_losses="obj,feat", overlap_optimizer=True)
+    for t, task in enumerate(["vis_mask", "word_mask", "matched", "qa"]):
+        batch = synthetic_batch(cfg, B, L, grid, seed=700 + 10 * t + rank)
+        wl, ml = O.make_lang_task_labels(oc, batch["input_ids"], 800 + 10 * t + rank)
+        batch.update(word_labels=wl, matched_labels=ml, qa_labels=O.make_qa_labels(NQ, B, 900 + 10 * t + rank))
+        tra.step(cuda(batch), task=task)
+        bad = tra.verify_replicas()
+        assert bad == [], (task, bad[:4])
+    if rank == 1:                                   # a diverged replica is caught, tensor by tensor
+        tra.store.view("bert.pooler.dense.bias")[3] += 1.0
+    assert tra.verify_replicas() == ["param:bert.pooler.dense.bias"]
+    torch.save({"ok": True}, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_other_tasks_one_gpu(tmp_path):
+    """VQA and NLVR2 fine-tune steps and the four-task round-robin (per-tensor update counts, skipped tensors) on two ranks sharing
+    one GPU, optimizer pass behind the step: replicas bit-identical after every step; a deliberately diverged tensor is named."""
+    import torch.multiprocessing as mp
+    from test_trainer_cpu import _free_port
+    world, port = 2, _free_port()
+    mp.spawn(_gpu_dp_worker_tasks, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "t0.pt").exists() and (tmp_path / "t1.pt").exists()
