@@ -233,6 +233,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="no language/visual stream overlap (profiling)")
     ap.add_argument("--gemm-table", action="store_true", help="print the instrumented step's GEMM time by shape (stderr)")
     ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW on the main stream, in front of the next forward (default: behind the step on a side stream)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: test rig for N ranks SHARING one GPU, "
+                    "which RCCL refuses -- with XL_BENCH_SHARE_GPU=1 every rank uses cuda:0)")
     ap.add_argument("--eager", action="store_true", help="enqueue every step from Python instead of replaying the recorded launch plan")
     args = ap.parse_args()
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 during the run (RCCL's
@@ -249,6 +251,8 @@ def main():
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("XL_BENCH_SHARE_GPU", "0") == "1":
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -259,7 +263,10 @@ def main():
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
         if os.environ.get("XL_GROUP_ONLY") == "1":          # (diagnostic: group initialised, exchange not used)
             os.environ["XL_FORCE_EXCHANGE"] = "0"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
