@@ -158,7 +158,8 @@ class PretrainStep:
 
     def sync(self):
         """everything this trainer has queued (the optimizer stream included) is done."""
-        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def sync_replicas(self):
         """DDP's constructor broadcast (ref lxmert_pretrain.py:102-106): rank 0's parameters AND optimizer state (Adam
