@@ -270,7 +270,11 @@ int xl_gather_labels(const int64_t* labels, const int* rows, int64_t* out, int n
 int xl_rowmax_combine(const float* ws, int n_seg, int M, float* row_maxprob, int* row_argmax, float* row_lse, void* stream);
 
 /* ---------------------------------------------------------------- optimizer side (ref lxmert_pretrain.py:343-364)
- * sumsq[0] += sum g^2 over n fp32 elements */
+ * sumsq[0] += sum g^2 over n fp32 elements.  Deterministic: block partials are added in a fixed order by the last block to
+ * arrive, so every rank of a data-parallel job derives the same clip factor from the same reduced gradients (an atomic per block
+ * left replicas 1 ulp apart after one step).  One plain update of sumsq[0] per call: do not run two calls on the same sumsq
+ * concurrently.  The 2 KiB of block partials live in library-owned scratch (a ring of 8, allocated at first use): the one
+ * exception to caller-owned memory. */
 int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream);
 /* Device-side update counter and schedule (ref lxmert_pretrain.py:138-139 get_linear_schedule_with_warmup; 4.1.1 AdamW bias
  * corrections): *step += 1 (t = the update about to be applied), lr_and_steps = {base_lr * schedule(t-1), 1-beta1^t,
