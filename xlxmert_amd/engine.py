@@ -968,29 +968,41 @@ class Engine:
         with Engine._Seeded(self):
             return self._encoder_forward(want_pooled)
 
+    def _language_stack_forward(self):
+        """embeddings + l_layers self-attention layers (HF:516-521); leaves the language rows of the first cross layer's input
+        in X[0][:ML]."""
+        cfg, st, ops, d, ML = self.cfg, self.store, self.ops, self.d, self.ML
+        X0 = self.X[0]
+        e = "bert.embeddings"
+        self._pr("emb")
+        emb = getattr(self, "embeds_mode", False)
+        ops.embed_ln_fwd(self._emb_ids if emb else self.ids, self.tt,
+                         self._emb_tab if emb else st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
+                         st.cview(e + ".token_type_embeddings.weight"), st.view(e + ".LayerNorm.weight"),
+                         st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
+                         self.B, self.L, d, self.eps)
+        if self.p_hid > 0:              # HF:213
+            ops.dropout(self.emb_y, self.emb_y, ML, d, d, d, self.p_hid, self.seed(0))
+        x = self.emb_y
+        for i, (sa, ffn) in enumerate(self.lang_layers):
+            self._pr(("lang", i))
+            sa.fwd(x, self.lang_mid[i])
+            y = X0[:ML] if i == cfg.l_layers - 1 else self.lang_out[i]
+            ffn.fwd(self.lang_mid[i], y)
+            x = y
+
     def _encoder_forward(self, want_pooled=True):
         cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
         ML, MV = self.ML, self.MV
         X0 = self.X[0]
         self.fork()
-        with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream
-            e = "bert.embeddings"
-            self._pr("emb")
-            emb = getattr(self, "embeds_mode", False)
-            ops.embed_ln_fwd(self._emb_ids if emb else self.ids, self.tt,
-                             self._emb_tab if emb else st.cview(e + ".word_embeddings.weight"), st.cview(e + ".position_embeddings.weight"),
-                             st.cview(e + ".token_type_embeddings.weight"), st.view(e + ".LayerNorm.weight"),
-                             st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
-                             self.B, self.L, d, self.eps)
-            if self.p_hid > 0:              # HF:213
-                ops.dropout(self.emb_y, self.emb_y, ML, d, d, d, self.p_hid, self.seed(0))
-            x = self.emb_y
-            for i, (sa, ffn) in enumerate(self.lang_layers):
-                self._pr(("lang", i))
-                sa.fwd(x, self.lang_mid[i])
-                y = X0[:ML] if i == cfg.l_layers - 1 else self.lang_out[i]
-                ffn.fwd(self.lang_mid[i], y)
-                x = y
+        # samplers: the text does not change between refinement steps and, without dropout, neither does the output of the
+        # language stack (embeddings + l_layers self-attention layers: it never sees the visual tokens) -- it still sits in
+        # X[0][:ML] from the loop's first pass (no later layer writes there), so the later passes skip it.  Exact.
+        skip_lang = getattr(self, "_reuse_lang_stack", False) and self.p_hid == 0 and self.p_attn == 0
+        if not skip_lang:
+            with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream
+                self._language_stack_forward()
         # ---- visual feature encoder + relational stack (HF:513, 524-529) on the main stream
         self._pr("visn")
         if self.use_codebook:
@@ -1335,7 +1347,11 @@ class Engine:
                 self.vmask.fill_(1)                                        # ref :204-206
             else:
                 ops.remask_lowest(self.row_maxprob, self.vmask, B, V, n_mask)
-            self.encoder_forward(want_pooled=False)                        # codebook_gather == where(mask, mask_feat, vis_emb(ids))
+            self._reuse_lang_stack = i > 0                                 # the text is the same in every refinement step
+            try:
+                self.encoder_forward(want_pooled=False)                    # codebook_gather == where(mask, mask_feat, vis_emb(ids))
+            finally:
+                self._reuse_lang_stack = False
             self._predict_step(fused)
             ops.sampler_update(self.row_argmax, self.vmask, self.cid, B * V)
         ops.codebook_gather(self.cid, None, st.centroids_c, st.view("mask_feat"), self.feats, self.MV, self.F)
@@ -1366,7 +1382,11 @@ class Engine:
                 self.vmask[:, cur] = 1                                     # ref :104-108 (re-visits beyond V steps)
             elif mode == "tlbr":
                 cur = i
-            self.encoder_forward(want_pooled=False)
+            self._reuse_lang_stack = i > 0
+            try:
+                self.encoder_forward(want_pooled=False)
+            finally:
+                self._reuse_lang_stack = False
             self._predict_step(fused)
             ops.sampler_ar_update(self.row_maxprob, self.row_argmax, self.visited, self.vmask, self.cid, B, V, cur)
             if trace is not None:
