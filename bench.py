@@ -216,6 +216,16 @@ def other_workloads(cfg, dev, steps=8, warm=3):
                        cluster_ids=torch.zeros(B, 64, dtype=torch.long, device=dev), vis_mask=torch.ones(B, 64, dtype=torch.bool, device=dev))
         dt = timed(lambda: eng.sample_codes_nar(4))
         out[f"sampler_T4_bs{B}"] = {"ms": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1)}
+        if B == 64:         # the autoregressive variant (ref tasks/imggen_model.py:49-153): 64 steps, one grid position per step
+            for _ in range(2):
+                eng.sample_codes_ar(mode="confidence")
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                eng.sample_codes_ar(mode="confidence")
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / 3
+            out["sampler_AR64_bs64"] = {"ms": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1)}
         del eng, store
     return out
 
