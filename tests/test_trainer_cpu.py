@@ -43,7 +43,14 @@ def oracle_grads(cfg, sd, batch):
     return {k: v.grad for k, v in sd.items() if v.grad is not None}, out
 
 
-def test_two_steps_match_closed_form():
+@pytest.mark.parametrize("head_pad", [256, 8, 4])
+def test_two_steps_match_closed_form(monkeypatch, head_pad):
+    """head_pad < 256: the masked-row head really compacts at this size, its padded row count changes from step 1 to step 2, and
+    this model flips the backward scratch generation an odd number of times per step: the head's gathered input must be the buffer
+    its forward wrote, not whatever set tmp() hands out in the backward (a latent bug found with exactly this case: the transform
+    weight's gradient was wrong from the second step on for models with an odd number of visual-side layers)."""
+    from xlxmert_amd.engine import Engine
+    monkeypatch.setattr(Engine, "ROW_PAD", head_pad)
     cfg = XLxmertConfig(**TINY)
     B, L, grid = 3, 8, 4
     tr, sd = make_step(cfg, B, L, grid, lr=1e-2, weight_decay=0.01, warmup_ratio=0.2)

@@ -1064,7 +1064,8 @@ class Engine:
         hd = self.hd
         vis = self.vis_final
         if self._hrows is not None:
-            vis = self.tmp("vis_c", self.MV, d)[:M]
+            self._hvis_buf = self.tmp("vis_c", self.MV, d)     # kept: the backward contracts over it (tmp() there may hand out the
+            vis = self._hvis_buf[:M]                           # other scratch set -- the generation flips with the layers' backward)
             ops.gather_rows(self.vis_final, self._hrows[0], vis, M, d, d, d)
         self._hvis = vis
         ops.gemm(vis, hd["wt"][0], self.t_h, hd["bt"][0], None, self.t_pre, M, d, d, d, d, d, ldx=d, epilogue=EPI_GELU)
@@ -1446,7 +1447,7 @@ class Engine:
         ops.colsum(dtp, hd["bt"][1], M, d, d, ws=self.ws)
         if Mk > M:
             ops.zero(dtp[M:Mk])
-        hv = self._hvis if self._hrows is None else self.tmp("vis_c", MV, d)
+        hv = self._hvis if self._hrows is None else self._hvis_buf
         self.wgrad_defer(dtp, hv, hd["wt"][1], d, d, Mk, d, d, d)
         self.wgrad_flush()
         if self._hrows is None:
