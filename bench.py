@@ -1,6 +1,8 @@
 """Headline benchmark: masked-visual-token pretraining step throughput (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...                     (no WORLD_SIZE in the environment: starts its own N ranks, as the reference's
+                                                      entry point does with mp.spawn, ref pretrain/lxmert_pretrain.py:865)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -146,7 +148,7 @@ class GemmTimer:
         return out
 
 
-def other_workloads(cfg, dev, steps=8, warm=3):
+def other_workloads(cfg, dev, steps=20, warm=3):
     """The SURVEY 8f rows next to the hot path, timed in the same run (one GPU, bf16, dropout on, synthetic data; after the
     headline measurement, never part of `value`): VQA fine-tune step at BASELINE config 3's per-GPU batch, NLVR2 step,
     word_mask / matched pretraining steps, T=4 Mask-Predict sampling (config 4).  Each entry: ms per step and rate."""
@@ -221,10 +223,10 @@ def other_workloads(cfg, dev, steps=8, warm=3):
                 eng.sample_codes_ar(mode="confidence")
             torch.cuda.synchronize()
             t = time.perf_counter()
-            for _ in range(3):
+            for _ in range(5):
                 eng.sample_codes_ar(mode="confidence")
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t) / 3
+            dt = (time.perf_counter() - t) / 5
             out["sampler_AR64_bs64"] = {"ms": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1)}
         del eng, store
     return out
@@ -246,7 +248,21 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: test rig for N ranks SHARING one GPU, "
                     "which RCCL refuses -- with XL_BENCH_SHARE_GPU=1 every rank uses cuda:0)")
     ap.add_argument("--eager", action="store_true", help="enqueue every step from Python instead of replaying the recorded launch plan")
+    ap.add_argument("--resident-inputs", action="store_true", help="minibatches resident in HBM before the timed region (default: "
+                    "pinned host memory, uploaded inside the timed step on a copy stream, one step ahead)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain script: launch the N ranks ourselves (one process per GPU through torch.distributed.run, the
+        # same launcher the driver uses) and pass rank 0's single JSON line through on the inherited stdout
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(cmd))
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 during the run (RCCL's
     # version banner at communicator creation, library warnings) is sent to stderr, the JSON goes to the saved descriptor
     sys.stdout.flush()
@@ -261,7 +277,8 @@ def main():
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("XL_BENCH_SHARE_GPU", "0") == "1":
+    share_gpu = os.environ.get("XL_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
         local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -288,26 +305,39 @@ def main():
     tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595,
                       total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout,
                       bucket_mb=float(os.environ.get("XL_BUCKET_MB", "64")),
-                      plan=(world == 1 and not grouped and not args.eager and not args.single_stream), drop_grads=True,
+                      plan=(not args.eager and not args.single_stream), drop_grads=True,
                       overlap_optimizer=not (args.no_opt_overlap or args.single_stream))
     if args.single_stream:
         tr.engine.side = None
     g = torch.Generator().manual_seed(9595)
     tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
-    batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=9595 + 17 * rank + i).items()}
-               for i in range(4)]                       # per-rank disjoint synthetic minibatches, resident in HBM
+    from xlxmert_amd.trainer import BatchUploader
+    host = [synthetic_batch(cfg, B, 20, 8, seed=9595 + 17 * rank + i) for i in range(4)]     # per-rank disjoint synthetic minibatches
+    if args.resident_inputs:
+        batches = [{k: v.cuda() for k, v in b.items()} for b in host]
+        up, nxt = None, None
+        get = lambda i: batches[i % 4]
+    else:
+        # SURVEY 8d counts the upload of the batch: minibatches wait in pinned host memory and every step's batch is copied to
+        # the device INSIDE the timed region (copy stream, one step ahead of the compute, trainer.BatchUploader)
+        batches = [BatchUploader.pin(b) for b in host]
+        up = BatchUploader(f"cuda:{local}")
+        get = lambda i: up.upload(batches[i % 4])
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    nxt = get(0)
     for i in range(args.warmup):
-        tr.step(batches[i % 4])
+        cur, nxt = nxt, get(i + 1)
+        tr.step(cur)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        losses = tr.step(batches[i % 4])
+        cur, nxt = nxt, get(args.warmup + i + 1)
+        losses = tr.step(cur)
     t_enqueue = time.perf_counter() - t0          # host time to queue the work (GPU-bound if << wall time)
     sync()
     dt = time.perf_counter() - t0
@@ -326,14 +356,14 @@ def main():
     for i in range(6):
         torch.cuda.synchronize()
         h0 = time.perf_counter()
-        tr.step(batches[i % 4])
+        tr.step(get(i))
         host_ms.append((time.perf_counter() - h0) * 1e3)
     torch.cuda.synchronize()
     host_ms = sorted(host_ms)[len(host_ms) // 2]
     side, tr.engine.side = tr.engine.side, None
     planned, tr.plan_mode = tr.plan_mode, False
     with GemmTimer(tr.ops) as gt:
-        tr.step(batches[0])
+        tr.step(get(0))
     tr.engine.side, tr.plan_mode = side, planned
     traffic, traffic_src = None, None
     try:        # HBM bytes per GEMM launch from the committed PMC profile of this build (cannot be collected live)
@@ -350,10 +380,11 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
+        plans = list(tr._plans.values())
         gemm_tflops = gt.flops / (gt.total_ms * 1e-3) / 1e12
         out = {
             "metric": "pretrain examples/sec (20 text tok x 64 vis tok, bs=256)", "value": round(value, 1),
-            "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "examples/s", "n_gpus": 1 if share_gpu else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]+[2]: full X-LXMERT encoder 9L/5R/5X d=768 + obj_predict_head over 10k codebook, "
@@ -361,15 +392,19 @@ def main():
                        "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}",
                        "dropout": "off (eval-parity mode)" if args.no_dropout else "0.1 hidden + 0.1 attention (training mode, 94 sites)",
                        "loss": round(loss_val, 4),
-                       "step_launch": (f"launch plan: one xl_plan_run per step replays the step's recorded C-ABI calls "
-                                       f"({len(tr._plans)} masked-row geometries, {max(p.n_calls for p in tr._plans.values())} calls each)"
-                                       if tr.plan_mode and tr._plans else "eager (every launch enqueued from Python)"),
+                       "step_launch": (f"launch plan: the step's recorded C-ABI calls replayed by xl_plan_run ({len(plans)} masked-row "
+                                       f"geometries, {max(p.n_calls for p in plans)} calls in {max(p.n_segments for p in plans)} segment(s) each"
+                                       + (f", {max(p.n_host_ops for p in plans)} host operations = the gradient exchange's all-reduce issue "
+                                          "points + one wait, between segments" if max(p.n_host_ops for p in plans) else "") + ")"
+                                       if tr.plan_mode and plans else "eager (every launch enqueued from Python)"),
                        "visual_losses": "obj,feat" if tr.feat_loss else "obj (scripts/pretrain.bash:15)",
                        "optimizer_pass": ("AdamW behind the step on a side stream, group by group in forward order; the next step's forward "
                                           "waits per group (all of it inside the timed region)") if tr.opt_stream is not None
                                          else "AdamW in front of the next forward",
-                       "inputs": "4 synthetic minibatches per rank resident in HBM before the timed region: no H2D inside it "
-                                 "(a batch is ~0.5 MB of int64 ids; SURVEY 8d counts its upload, 0.5 MB over PCIe ~ 10 us)",
+                       "inputs": ("4 synthetic minibatches per rank resident in HBM before the timed region: no H2D inside it (--resident-inputs)"
+                                  if args.resident_inputs else
+                                  "4 synthetic minibatches per rank in pinned host memory; every step's batch (~0.6 MB of ids / masks / labels / "
+                                  "row list) is uploaded INSIDE the timed region, on a copy stream one step ahead of the compute (SURVEY 8d)"),
                        "vis_mask": "--vis_mask_predict masks, n ~ U{1..64} per image (ref lxmert_data.py:414-419)",
                        "head_rows": "codebook head + both losses on the masked rows only (exact: the reference's losses read "
                                     "nothing else); all rows with XL_COMPACT_HEAD=0"},
@@ -391,9 +426,16 @@ def main():
                          "algorithmic_gflop_per_step": round(gt.flops / 1e9, 1),
                          "contract_gflop_per_step": round(GFLOP_PER_EXAMPLE * B, 1)},
         }
+        if share_gpu:
+            # N ranks on ONE device (test rig for the exchange with a real second rank; RCCL refuses it, gloo does not): this is
+            # NOT a scaling result -- every rank competes for the same GPU
+            out["shared_gpu"] = True
+            out["n_ranks"] = world
+            out["config"]["parallelism"] = f"dp{world} ranks sharing ONE GPU (exchange test rig, not a scaling measurement)"
         if world > 1 or grouped:
             out["config"]["gradient_exchange"] = {
-                "collective": "RCCL all-reduce (sum; 1/N folded into AdamW) per finished slice of the flat gradient buffer",
+                "backend": args.backend + (" (= RCCL over xGMI)" if args.backend == "nccl" else " (host-staged: test rig)"),
+                "collective": "all-reduce (sum; 1/N folded into AdamW) per finished slice of the flat gradient buffer",
                 "element_type": "bf16" if tr.comm_buf is not None else "fp32",
                 "bucket_mb": round(tr.bucket_elems * (2 if tr.comm_buf is not None else 4) / (1 << 20), 1),
                 "bytes_per_step": int(tr.store.n_used * (2 if tr.comm_buf is not None else 4)),

@@ -16,6 +16,12 @@
  *     config, fp32 FMA / fp32 accumulate); XL_BF16 = bf16 operands, fp32 accumulate on MFMA.
  *     LayerNorm statistics, softmax, losses, gradients of parameters, optimizer state: always fp32.
  *   - "ld*" are leading dimensions in ELEMENTS.
+ *   - threading / state: the library keeps NO process-global mutable state.  Everything a caller can
+ *     set -- the dropout step-seed pointer, the deferred-reduction switch and its pending lists, the per-stream slab
+ *     workspaces, the kernel-choice / debug switches -- belongs to a CONTEXT (xl_ctx_create); a thread binds the context it
+ *     works for with xl_ctx_bind and every xl_* call it makes afterwards reads that context.  Calls are re-entrant across
+ *     streams and across contexts; a context bound by several threads serialises only its own two small maps.  A caller that
+ *     never creates a context works in the default one (handle 0).  xl_last_error() is per thread.
  */
 #ifndef XLXMERT_HIP_H
 #define XLXMERT_HIP_H
@@ -53,6 +59,14 @@ extern "C" {
 
 const char* xl_last_error(void);
 int  xl_version(void);
+/* Contexts: xl_ctx_create() -> handle (>= 1); xl_ctx_bind(handle) makes it the calling thread's current context (0 = the
+ * default context; plan-able, so a recorded launch plan re-establishes its owner's context when replayed);
+ * xl_ctx_destroy(handle) frees it (threads that still have it bound must bind another first).  One per host-side driver
+ * object: the reference's counterpart is one nn.Module / one Trainer (ref lxmert_pretrain.py:47-108). */
+int64_t xl_ctx_create(void);
+int  xl_ctx_bind(int64_t ctx);
+int  xl_ctx_destroy(int64_t ctx);
+/* The setters below (xl_set_*, xl_gemm_trace, xl_gemm_set_workspace) write the BOUND context. */
 /* 1: GEMM/SDPA transposed operands use ds_read_b64_tr_b16; 0: 16-bit LDS gathers (debug switch) */
 int  xl_set_lds_transpose_read(int enable);
 /* Step part of every dropout seed, in DEVICE memory: with a non-null pointer registered, each dropout site (xl_gemm
@@ -273,9 +287,11 @@ int xl_rowmax_combine(const float* ws, int n_seg, int M, float* row_maxprob, int
  * sumsq[0] += sum g^2 over n fp32 elements.  Deterministic: block partials are added in a fixed order by the last block to
  * arrive, so every rank of a data-parallel job derives the same clip factor from the same reduced gradients (an atomic per block
  * left replicas 1 ulp apart after one step).  One plain update of sumsq[0] per call: do not run two calls on the same sumsq
- * concurrently.  The 2 KiB of block partials live in library-owned scratch (a ring of 8, allocated at first use): the one
- * exception to caller-owned memory. */
-int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream);
+ * concurrently.  `scratch`: caller-owned device memory of xl_sumsq_scratch_bytes() bytes (16-byte aligned), ZERO before its
+ * first use and left zero-ticketed by every call; it holds the block partials and the arrival ticket, so two calls that may
+ * run concurrently (different streams, different devices) need one each. */
+int64_t xl_sumsq_scratch_bytes(void);
+int xl_sumsq(const float* g, float* sumsq, int64_t n, void* scratch, void* stream);
 /* Device-side update counter and schedule (ref lxmert_pretrain.py:138-139 get_linear_schedule_with_warmup; 4.1.1 AdamW bias
  * corrections): *step += 1 (t = the update about to be applied), lr_and_steps = {base_lr * schedule(t-1), 1-beta1^t,
  * 1-beta2^t, t}.  Stream-ordered before xl_adamw, so the host never writes step scalars into memory a queued step reads. */

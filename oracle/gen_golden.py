@@ -556,9 +556,51 @@ def gen_embeds(name, cfg, seed, B, L, grid):
     print(name, "loss", float(loss), "n_grads", len(grads))
 
 
+def gen_ckpt(name, cfg, seed, B, L, grid):
+    """a checkpoint as the REFERENCE writes it -- `torch.save(self.model.state_dict(), "%s_LXRT.pth")` of the
+    DDP-wrapped model (ref pretrain/lxmert_pretrain.py:675-677, :102-106), i.e. the reference model's own `state_dict()` with
+    every key behind `module.` -- for the tiny pretraining model with both language heads (`cls.*`, decoder tied to the word
+    embeddings as transformers 4.1.1 builds it), plus the model's outputs on seeded inputs so that a loader can be checked
+    end to end: `{name}_LXRT.pth` (tensors only: data) and `{name}_io.npz`."""
+    hf = LxmertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                      num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                      max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                      l_layers=cfg.l_layers, x_layers=cfg.x_layers, r_layers=cfg.r_layers,
+                      visual_feat_dim=cfg.visual_feat_dim, visual_pos_dim=cfg.visual_pos_dim,
+                      visual_attr_loss=False, task_qa=False, task_mask_lm=True, task_matched=True)
+    m = Shim(hf, num_clusters=cfg.num_clusters)
+    sd = O.make_cls_state_dict(cfg, seed)
+    m.set_visual_embedding(sd["vis_emb.weight"].clone())
+    m.config.n_centroids = cfg.num_clusters
+    res = m.load_state_dict({k: v for k, v in sd.items() if k not in ("vis_emb.weight", "obj_predict_head.out_cluster.weight",
+                                                                      "cls.predictions.decoder.weight")}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    m.cls.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight          # 4.1.1 constructor behaviour
+    m.eval()
+    ddp = torch.nn.Module()                    # what DDP's wrapper does to the key names: the model sits under `.module`
+    ddp.module = m
+    written = {k: v.detach().clone() for k, v in ddp.state_dict().items()}
+    assert all(k.startswith("module.") for k in written)
+    torch.save(written, os.path.join(OUT, name + "_LXRT.pth"))
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    out, _, bo, head = run_reference(m, inp, with_grad=False)
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp), keys=np.array(sorted(written.keys())))
+    d.update(lang=bo.language_output.numpy(), vis=bo.vision_output.numpy(), pooled=bo.pooled_output.numpy(),
+             feat=head["feat"].detach().numpy(), obj=head["obj"].detach().numpy())
+    for k in ("obj_loss", "feat_loss", "total_loss"):
+        d[k] = out[k].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name + "_io.npz"), **d)
+    print(name, "keys", len(written), {k: float(out[k]) for k in ("obj_loss", "feat_loss")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
+    if only == ["ckpt"]:
+        gen_ckpt("ckpt_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
+                 num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
+                 num_clusters=50), seed=3141, B=3, L=8, grid=4)
+        sys.exit(0)
     if only == ["embeds"]:
         gen_embeds("embeds_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
                    num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
@@ -598,3 +640,4 @@ if __name__ == "__main__":
     gen_vismask("vismask_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=6420, B=3, L=8, grid=4)
     gen_nlvr2("nlvr2_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, P=3, L=8, grid=4)
     gen_embeds("embeds_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=8024, B=3, L=8, grid=4)
+    gen_ckpt("ckpt_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=3141, B=3, L=8, grid=4)

@@ -362,7 +362,7 @@ class FakeOps:
         g = rows.view(-1)[:n_rows].long()
         out.view(-1)[:n_rows].copy_(torch.where(g >= 0, labels.view(-1)[g.clamp(min=0)], torch.full_like(g, -100)))
 
-    def sumsq(self, g, out, n):
+    def sumsq(self, g, out, n, scratch=None):
         out[0] += (g[:n].double() ** 2).sum().float()
 
     def schedule_step(self, step, base_lr, warmup_steps, total_steps, beta1, beta2, lr_and_steps):

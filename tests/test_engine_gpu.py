@@ -1043,3 +1043,149 @@ def test_data_parallel_two_ranks_other_tasks_one_gpu(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_gpu_dp_worker_tasks, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "t0.pt").exists() and (tmp_path / "t1.pt").exists()
+
+
+def test_benchmark_geometry_bs256_step_matches_oracle():
+    """The geometry bench.py times, against the oracle AT THAT SIZE: bs 256, 9/5/5, d = 768, 20 x 64 tokens, 10k codebook, bf16,
+    launch plan, codebook head on the masked rows, four streams, tail split, two-layer grouped weight gradients, optimizer pass
+    behind the step (64 row tiles per GEMM, 3-5 tile rounds: what the B = 8 reference fixture cannot reach).  Dropout off and
+    lr = 0, so the third step -- a plan REPLAY -- sees the initial parameters; its loss and every gradient are compared with the
+    CPU oracle's fp32 step on the same batch (~20 s of host time).  Tolerances: the bf16 yardstick of the full_955 fixture test."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig()
+    oc = O.OracleConfig(**{k: getattr(cfg, k) for k in CFG_KEYS})
+    sd = O.make_state_dict(oc, 2718)
+    B = 256
+    store = ParamStore(cfg, "cuda", torch.bfloat16)
+    store.load_named(sd)
+    tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", store=store, lr=0.0, total_steps=1000, plan=True,
+                      drop_grads=False, overlap_optimizer=True, train_dropout=False)
+    assert tr.plan_mode and tr.engine.compact_head and tr.engine.side is not None
+    batch = synthetic_batch(cfg, B, 20, 8, seed=31)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    for _ in range(3):                              # eager (allocates), eager + record, replay
+        losses = tr.step(dev)
+    tr.sync()
+    assert len(tr._plans) == 1 and 0 < tr.engine.n_mrows < tr.engine.MV
+    assert tr.t == 3
+    # oracle step (fp32, CPU) on the same parameters and batch; canonical recipe: obj loss only (scripts/pretrain.bash:15)
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    leaf = {k: v.clone().requires_grad_(v.is_floating_point() and k != "vis_emb.weight") for k, v in sd.items()}
+    leaf["obj_predict_head.out_cluster.weight"] = leaf["vis_emb.weight"]
+    ref = O.xlxmert_vis_mask_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                     batch["cluster_ids"], batch["vis_mask"], batch["obj_labels"])
+    ref["obj_loss"].backward()
+    rel_loss = abs(losses[0].item() - ref["obj_loss"].item()) / ref["obj_loss"].item()
+    worst_n, worst_t, rels = ("", 0.0), ("", 0.0), []
+    n_checked = 0
+    for k, v in leaf.items():
+        if v.grad is None or k == "obj_predict_head.out_cluster.weight":
+            continue
+        assert store.index[k].offset < store.n_used, k
+        got, want = store.gview(k).cpu().double(), v.grad.double()
+        wn = want.norm().item()
+        if wn < 1e-7:                               # key biases: analytically zero gradient
+            assert got.norm().item() < 1e-4, k
+            continue
+        n_checked += 1
+        en = abs(got.norm().item() - wn) / wn
+        et = (got - want).norm().item() / wn
+        rels.append(et)
+        if en > worst_n[1]:
+            worst_n = (k, en)
+        if et > worst_t[1]:
+            worst_t = (k, et)
+    rels.sort()
+    med = rels[len(rels) // 2]
+    print(f"bs-256 bench geometry vs oracle: loss rel err {rel_loss:.5f}; {n_checked} gradients: worst norm error {worst_n}, "
+          f"worst tensor relative L2 {worst_t}, median {med:.4f}")
+    assert n_checked > 400
+    assert rel_loss < 5e-3
+    assert worst_n[1] < 4.5e-2 and worst_t[1] < 0.154 and med < 4e-2, (worst_n, worst_t, med)
+
+
+def test_bench_two_ranks_sharing_the_gpu_end_to_end():
+    """`python bench.py --gpus 2` started as a plain script (no WORLD_SIZE: it launches its own two ranks, as the reference's
+    entry point does with mp.spawn, ref lxmert_pretrain.py:865) with both ranks on this GPU and gloo carrying the exchange: ONE
+    JSON line, the exchange filled in, the step replayed from a SEGMENTED launch plan (collectives between the segments)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XL_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4",
+                        "--warmup", "3", "--batch", "64", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["shared_gpu"] is True and out["n_ranks"] == 2 and out["n_gpus"] == 1
+    ex = out["config"]["gradient_exchange"]
+    assert ex["bytes_per_step"] > 5e8 and ex["backend"].startswith("gloo") and ex["exposed_comm_ms_per_step"] >= 0.0
+    assert out["config"]["step_launch"].startswith("launch plan") and "host operations" in out["config"]["step_launch"]
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0.05
+    print("2 ranks on one GPU:", out["ms_per_step"], "ms/step, host", out["host_enqueue_ms_per_step"], ex)
+
+
+def test_two_library_contexts_interleaved_in_one_process():
+    """SURVEY 8b 'no global mutable state except the handle': a trainer (dropout step-seed pointer, deferred column reductions,
+    launch plan) and a sampler engine (no dropout, other GEMM kernel choice) in ONE process, their calls interleaved: each
+    object's settings live in its own library context (xl_ctx_*), so neither sees the other's -- the trainer's losses, gradient
+    norm and parameters equal those of the same trainer running alone, the sampler's codes those of the sampler alone."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import Engine
+    from xlxmert_amd.ops import HipOps
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import PretrainStep, init_reference_weights, synthetic_batch
+    cfg = XLxmertConfig(vocab_size=200, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        max_position_embeddings=32, visual_feat_dim=64, num_clusters=96, l_layers=2, x_layers=2, r_layers=2)
+    g = torch.Generator().manual_seed(3)
+    cents = torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu()
+    B = 8
+    batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=40 + i).items()} for i in range(4)]
+
+    def trainer():
+        tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=5, lr=1e-3, total_steps=100, train_dropout=True,
+                          plan=True, drop_grads=False)
+        tr.set_centroids(cents)
+        return tr
+
+    def sampler():
+        store = ParamStore(cfg, "cuda", torch.bfloat16)
+        init_reference_weights(store, 9)
+        store.set_centroids(cents)
+        ops = HipOps(torch.bfloat16)
+        ops.set_gemm_pingpong(0)                    # a setting of ITS context only
+        eng = Engine(cfg, store, ops, B, 20, 64, need_lang=False)
+        eng.sync_compute_weights()
+        b = batches[0]
+        eng.set_inputs(b["input_ids"], b["attention_mask"], None, b["visual_pos"],
+                       cluster_ids=torch.zeros(B, 64, dtype=torch.long, device="cuda"), vis_mask=torch.ones(B, 64, dtype=torch.bool, device="cuda"))
+        return eng
+
+    tr = trainer()
+    alone = []
+    for i in range(4):
+        alone.append(tr.step(batches[i]).clone())
+    tr.sync()
+    alone_p, alone_n = tr.store.master.clone(), tr.grad_norm()
+    sm = sampler()
+    codes_alone = sm.sample_codes_nar(3)[0].clone()
+    del tr, sm
+    tr, sm = trainer(), sampler()
+    assert tr.ops.ctx != sm.ops.ctx
+    mixed = []
+    for i in range(4):
+        mixed.append(tr.step(batches[i]).clone())
+        codes = sm.sample_codes_nar(3)[0].clone()           # between two trainer steps (eager, recording and replaying ones)
+        assert torch.equal(codes, codes_alone)
+    tr.sync()
+    for a, b in zip(alone, mixed):
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-6), (a, b)        # (fp32 atomics: not bit-identical run to run)
+    assert abs(tr.grad_norm() - alone_n) < 2e-4 * alone_n
+    assert (tr.store.master - alone_p).abs().max().item() < 2e-5

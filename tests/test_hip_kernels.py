@@ -14,9 +14,16 @@ pytestmark = pytest.mark.gpu
 DT = [torch.float32, torch.bfloat16]
 
 
+_HIP = {}
+
+
 def hip(dtype):
+    """ONE HipOps (= one library context, xl_ctx_*) per dtype for the whole module: the kernel-choice switches a fixture sets
+    belong to the context, so the op under test must run through the same object."""
     from xlxmert_amd.ops import HipOps
-    return HipOps(dtype)
+    if dtype not in _HIP:
+        _HIP[dtype] = HipOps(dtype)
+    return _HIP[dtype]
 
 
 def run_both(dtype, name, args, kwargs=None):
@@ -250,7 +257,7 @@ def test_gemm_tail_split_exact(M, N, K, epi, bk, of32, slab_ws):
         ref = acc
     Ag, Bg, bg = A.cuda(), B.cuda(), bias.cuda()
     rg = res.cuda() if res is not None else None
-    ops.lib.call("xl_set_gemm_tail_split", 64, 1024)           # (default depth threshold: 4096)
+    ops.set_gemm_tail_split(64, 1024)           # (default depth threshold: 4096)
     for rep in range(2):
         C = torch.full((M, N), 7.0, dtype=torch.float32 if of32 else torch.bfloat16, device="cuda")
         xg = aux.cuda() if aux is not None else None
@@ -264,7 +271,7 @@ def test_gemm_tail_split_exact(M, N, K, epi, bk, of32, slab_ws):
             assert (C.float().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
         if epi == 1:
             assert torch.equal(xg.float().cpu(), ref_aux.to(torch.bfloat16).float())
-    ops.lib.call("xl_set_gemm_tail_split", 64, 4096)
+    ops.set_gemm_tail_split(64, 4096)
 
 
 @pytest.mark.parametrize("K", [4096, 1000])
@@ -592,7 +599,7 @@ def test_sumsq_adamw_cast(dtype):
     p, gr = rnd(g, n), rnd(g, n) * 3
     m, v = rnd(g, n).abs() * 0.1, rnd(g, n).abs() * 0.1
     ss = torch.zeros(1)
-    cpu, gpu = run_both(dtype, "sumsq", [gr, ss, n])
+    cpu, gpu = run_both(dtype, "sumsq", [gr, ss, n, hip(dtype).sumsq_scratch("cpu")])
     close(gpu[1], cpu[1], torch.float32, "sumsq", f32_tol=1e-5)
     flags = (torch.rand(n // 256, generator=g) < 0.5).to(torch.uint8)
     pc = torch.zeros(n, dtype=dtype)

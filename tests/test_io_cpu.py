@@ -79,3 +79,46 @@ def test_grid_feature_h5_reader_against_a_stand_in_for_h5py(monkeypatch):
     monkeypatch.setitem(sys.modules, "h5py", None)
     with pytest.raises(ImportError, match="h5py"):
         xio.load_grid_features_h5("feats.h5")
+
+
+def test_reference_written_checkpoint_loads_key_for_key_and_reproduces_the_reference_outputs(tmp_path):
+    """tests/golden/ckpt_tiny_LXRT.pth is the reference model's own `state_dict()` saved behind DDP's `module.` prefix
+    (oracle/gen_golden.py::gen_ckpt, ref lxmert_pretrain.py:675-677); ckpt_tiny_io.npz holds that model's outputs.  The loader
+    + parameter store must take every key (both aliases of tied tensors included), leave none over, and the oracle evaluated on
+    the loaded tensors must reproduce the reference's outputs; save_checkpoint must write a file the reference's own loader
+    semantics (utils.py:42-49) reads back completely."""
+    import os
+    import lxmert_oracle as O
+    from _util import GOLDEN, golden_cfg, golden_inputs, load_golden, maxdiff
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.params import ParamStore
+    g = load_golden("ckpt_tiny_io")
+    path = os.path.join(GOLDEN, "ckpt_tiny_LXRT.pth")
+    raw = torch.load(path)
+    assert sorted(raw.keys()) == [str(k) for k in g["keys"]] and all(k.startswith("module.") for k in raw)
+    sd = xio.load_state_dict(path)
+    assert sd.keys() == xio.load_state_dict_reference_semantics(path).keys()
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "l_layers", "x_layers",
+                                                      "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+    store = ParamStore(cfg, "cpu", torch.float32, task="all")
+    missing = store.load_named(sd, strict=True)
+    assert missing == []
+    ours = store.named_state()
+    assert set(ours) == set(sd), set(ours) ^ set(sd)                # key sets equal both ways, aliases included
+    for k, v in sd.items():
+        assert torch.equal(ours[k].cpu(), v), k
+    assert torch.equal(sd["cls.predictions.decoder.weight"], sd["bert.embeddings.word_embeddings.weight"])      # tied in 4.1.1
+    assert ours["cls.predictions.decoder.weight"].data_ptr() == ours["bert.embeddings.word_embeddings.weight"].data_ptr()
+    assert ours["vis_emb.weight"].data_ptr() == ours["obj_predict_head.out_cluster.weight"].data_ptr()
+    inp = golden_inputs(g)
+    out = O.xlxmert_vis_mask_forward({k: v.clone() for k, v in ours.items()}, oc, inp["input_ids"], inp["visual_pos"],
+                                     inp["attention_mask"], inp["cluster_ids"], inp["vis_mask"], inp["obj_labels"])
+    assert abs(out["obj_loss"].item() - g["obj_loss"].item()) < 2e-5 and abs(out["feat_loss"].item() - g["feat_loss"].item()) < 2e-5
+
+    class M:
+        def state_dict(self):
+            return ours
+    back = xio.load_state_dict_reference_semantics(xio.save_checkpoint(M(), str(tmp_path), "Epoch01"))
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)

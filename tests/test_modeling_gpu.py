@@ -342,3 +342,45 @@ def test_bert_inputs_embeds_through_autograd():
     assert (emb.grad.double() - ref).norm().item() <= 1e-4 * ref.norm().item()
     with pytest.raises(ValueError):
         m.bert(input_ids=t("in_input_ids"), inputs_embeds=emb, visual_feats=t("in_visual_feats"), visual_pos=t("in_visual_pos"))
+
+
+def test_reference_written_checkpoint_through_the_module_api(tmp_path):
+    """SURVEY 8f N4 on the device: tests/golden/ckpt_tiny_LXRT.pth (the reference model's own state_dict() behind `module.`,
+    oracle/gen_golden.py::gen_ckpt) -> io.load_state_dict -> XLxmertForPretraining.load_state_dict(strict=True): nothing
+    missing, nothing unexpected, the reference's outputs reproduced; state_dict() -> save_checkpoint -> the reference's own
+    loader semantics gives the same tensors back."""
+    import os
+    from _util import GOLDEN
+    from xlxmert_amd import io as xio
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.modeling import XLxmertForPretraining
+    g = load_golden("ckpt_tiny_io")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in CFG_KEYS})
+    cfg.task_mask_lm, cfg.task_matched = True, True
+    m = XLxmertForPretraining(cfg, device="cuda", dtype=torch.float32)
+    path = os.path.join(GOLDEN, "ckpt_tiny_LXRT.pth")
+    sd = xio.load_state_dict(path)
+    missing, unexpected = m.load_state_dict(torch.load(path), strict=True)        # the raw file: `module.` keys
+    assert missing == [] and unexpected == []
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.eval()
+    inp = {k: v.cuda() for k, v in golden_inputs(g).items()}
+    with torch.no_grad():
+        feats = torch.where(inp["vis_mask"][..., None], m.mask_feat.view(1, 1, -1), m.vis_emb(inp["cluster_ids"]))
+        lang, vis, pooled = m.bert(input_ids=inp["input_ids"], visual_feats=feats, visual_pos=inp["visual_pos"],
+                                   attention_mask=inp["attention_mask"], token_type_ids=inp["token_type_ids"])
+        head = m.obj_predict_head(vis, out_keys=["obj", "feat"])
+    real = inp["attention_mask"].reshape(-1).bool().cpu()
+    B, L = inp["input_ids"].shape
+    assert maxdiff(lang.float().cpu().view(B * L, -1)[real], torch.from_numpy(g["lang"]).view(B * L, -1)[real]) < 1e-4
+    assert maxdiff(vis.float().cpu(), g["vis"]) < 1e-4 and maxdiff(pooled.float().cpu(), g["pooled"]) < 1e-4
+    assert maxdiff(head["obj"].cpu(), g["obj"]) < 2e-4 and maxdiff(head["feat"].cpu(), g["feat"]) < 1e-4
+    out = m(input_ids=inp["input_ids"], visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+            cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], token_type_ids=inp["token_type_ids"],
+            label_dict={"obj_labels": inp["obj_labels"], "feat_labels": m.vis_emb(inp["cluster_ids"])}, task="vis_mask")
+    assert abs(out["obj_loss"].item() - g["obj_loss"].item()) < 1e-4 and abs(out["feat_loss"].item() - g["feat_loss"].item()) < 1e-4
+    back = xio.load_state_dict_reference_semantics(xio.save_checkpoint(m, str(tmp_path), "Epoch01"))
+    assert set(back) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(back[k], v), k

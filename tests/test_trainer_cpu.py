@@ -447,3 +447,91 @@ def test_forward_groups_tile_the_optimizer_range(task, num_answers):
         idx = [keys.index((kind, i)) for i in range(n)]
         assert idx == sorted(idx)
     assert max(keys.index(("lang", cfg.l_layers - 1)), keys.index(("vis", cfg.r_layers - 1))) < keys.index(("x", 0))
+
+
+def test_gradient_accumulation_update_freq():
+    """--update_freq (ref tasks/vqa.py:152-159, 189-198): backward of several minibatches accumulates, ONE clip + AdamW step on
+    the summed gradient, gradients dropped afterwards.  step(update=False) twice + step(update=True) == one AdamW update of the
+    oracle on the SUM of the three minibatches' gradients; the next window starts from a clean buffer."""
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 3, 8, 4
+    tr, sd = make_step(cfg, B, L, grid, lr=1e-2, warmup_ratio=0.0)
+    batches = [synthetic_batch(cfg, B, L, grid, seed=300 + i) for i in range(4)]
+    for i in range(3):
+        tr.step(batches[i], update=(i == 2))
+        assert tr.t == (1 if i == 2 else 0)
+    gs = [oracle_grads(cfg, sd, b)[0] for b in batches[:3]]
+    names = sorted(gs[0])
+    total = [gs[0][k] + gs[1][k] + gs[2][k] for k in names]
+    norm, clipped = O.clip_grad_norm(total, 1.0)
+    assert abs(tr.grad_norm() - norm.item()) < 1e-4 * max(1.0, norm.item())
+    ref = {}
+    for k, g in zip(names, clipped):
+        ref[k], _, _ = O.adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-2)
+        assert (tr.store.view(k) - ref[k]).abs().max().item() < 2e-5, k
+    # the following plain step clears the accumulated gradients first (they are not added to)
+    tr.step(batches[3])
+    ref_sd = {k: (ref[k].detach() if k in ref else v) for k, v in sd.items()}
+    g4 = oracle_grads(cfg, ref_sd, batches[3])[0]
+    for k in names:
+        assert (tr.store.gview(k) - g4[k]).abs().max().item() < 3e-5, k
+
+
+def test_hyper_parameters_and_codebook_changes_drop_recorded_plans():
+    """launch plans freeze the step scalars and the codebook pointer: assigning lr / weight decay / clip / schedule
+    length, or set_centroids, drops them; set_centroids also keeps the store's device buffers (views stay valid)."""
+    cfg = XLxmertConfig(**TINY)
+    tr, sd = make_step(cfg, 3, 8, 4, lr=1e-2)
+    ptr, ptr_c = tr.store.centroids.data_ptr(), tr.store.centroids_c.data_ptr()
+    for attr, val in (("lr", 5e-3), ("wd", 0.1), ("clip", 0.5), ("total_steps", 77), ("warmup_steps", 3)):
+        tr._plans[("fake",)] = object()
+        setattr(tr, attr, getattr(tr, attr))          # same value: plans stay
+        assert tr._plans
+        setattr(tr, attr, val)
+        assert not tr._plans and getattr(tr, attr) == val, attr
+    tr._plans[("fake",)] = object()
+    new = torch.rand(cfg.num_clusters, cfg.visual_feat_dim)
+    tr.set_centroids(new)
+    assert not tr._plans
+    assert tr.store.centroids.data_ptr() == ptr and tr.store.centroids_c.data_ptr() == ptr_c and torch.equal(tr.store.centroids, new)
+
+
+def test_segmented_plan_alternates_segments_and_host_operations():
+    """_lib.SegmentedPlan (the data-parallel step's launch plan): host operations recorded between C-ABI calls cut the record
+    into segments; replay runs segment, host operation, segment ... in order.  Host-only entry points, no GPU."""
+    from xlxmert_amd._lib import SegmentedPlan, get_lib
+    lib = get_lib()
+    log = []
+    with lib.record() as calls:
+        lib.call("xl_set_deferred_reduce", 1)
+        lib.record_host(lambda: log.append("a"))
+        lib.call("xl_set_deferred_reduce", 0)
+        lib.call("xl_set_step_seed_ptr", None)
+        lib.record_host(lambda: log.append("b"))
+        lib.record_host(lambda: log.append("c"))
+    lib.record_host(lambda: log.append("never"))         # outside a recording: ignored
+    plan = lib.make_plan(calls)
+    assert isinstance(plan, SegmentedPlan) and plan.n_calls == 3 and plan.n_segments == 2 and plan.n_host_ops == 3
+    plan.run()
+    plan.run()
+    assert log == ["a", "b", "c", "a", "b", "c"]
+
+
+def _metrics_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = XLxmertConfig(**TINY)
+    tr, _ = make_step(cfg, 2, 8, 4)
+    got = tr.reduce_metrics({"obj_loss": torch.tensor(1.5 + rank), "n": 10 * (rank + 1), "feat_loss": 0.25})
+    torch.save(got, os.path.join(out_dir, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_metrics_world2_gloo(tmp_path):
+    """ref x-lxmert/src/utils.py:11-39 reduce_dict: per-rank epoch metrics are SUMMED onto rank 0 by one reduce of the key-sorted
+    vector; the other ranks get None."""
+    world, port = 2, _free_port()
+    mp.spawn(_metrics_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert torch.load(tmp_path / "m0.pt") == {"feat_loss": 0.5, "n": 30.0, "obj_loss": 4.0}
+    assert torch.load(tmp_path / "m1.pt") is None

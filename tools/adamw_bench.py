@@ -11,7 +11,8 @@ pc = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
 flags = torch.ones(n // 256, dtype=torch.uint8, device="cuda")
 ss = torch.zeros(1, device="cuda"); lrs = torch.tensor([1e-4, 0.1, 0.001, 0.0], device="cuda")
 def adam(): ops.adamw(p, g, m, v, pc, flags, ss, lrs, n, 0.9, 0.999, 1e-6, 0.01, 1.0)
-def sumsq(): ops.sumsq(g, ss, n)
+sc = ops.sumsq_scratch("cuda")
+def sumsq(): ops.sumsq(g, ss, n, sc)
 for name, f, byts in (("adamw", adam, 30 * n), ("sumsq", sumsq, 4 * n)):
     for _ in range(3): f()
     torch.cuda.synchronize()

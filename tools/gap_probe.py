@@ -12,8 +12,8 @@ for _ in range(3): run()
 torch.cuda.synchronize()
 bufs = [torch.zeros(4 * 8192 + 12 * 8192, dtype=torch.int64, device="cuda") for _ in range(4)]
 for b in bufs:
-    ops.lib.call("xl_gemm_trace", b.data_ptr()); run()
-ops.lib.call("xl_gemm_trace", 0)
+    ops.gemm_trace(b); run()
+ops.gemm_trace(None)
 torch.cuda.synchronize()
 ts = [b[:4 * 8192].view(-1, 4).cpu() for b in bufs]
 ts = [t[t[:, 0] > 0].double() / 100.0 for t in ts]

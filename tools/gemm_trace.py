@@ -24,10 +24,10 @@ def run():
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-ops.lib.call("xl_gemm_trace", trace.data_ptr())
+ops.gemm_trace(trace)
 run()
 torch.cuda.synchronize()
-ops.lib.call("xl_gemm_trace", 0)
+ops.gemm_trace(None)
 sec = trace[4 * 8192:].view(-1, 2, 6).cpu()
 t = trace[:4 * 8192].view(-1, 4).cpu()
 t = t[t[:, 0] > 0].double() / 100.0          # us

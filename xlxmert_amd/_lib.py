@@ -88,13 +88,56 @@ class Lib:
 
         return _Rec()
 
+    def record_host(self, fn):
+        """While recording: mark a point of the step at which the HOST has to act between two C-ABI calls -- `fn()` is run there
+        on every replay (a torch.distributed collective of the gradient exchange: it is not an entry point of this library, so
+        it cannot be a plan entry; the plan is cut into segments around it).  No-op outside record()."""
+        if self.recorder is not None:
+            self.recorder.append((HOST_OP, fn))
+
     def make_plan(self, calls):
         """[(name, args)] -> LaunchPlan.  Arguments become 64-bit words: pointers / integers by value, floats as their bit
-        pattern; ctypes arrays (host arrays a call reads at launch) are kept alive by the plan."""
+        pattern; ctypes arrays (host arrays a call reads at launch) are kept alive by the plan.  A record that contains host
+        operations (record_host) becomes a SegmentedPlan: one LaunchPlan per run of C-ABI calls, the host operations between."""
+        if any(name is HOST_OP for name, _ in calls):
+            return SegmentedPlan(self, calls)
         return LaunchPlan(self, calls)
 
 
+HOST_OP = object()          # recorder entry (HOST_OP, callable): see Lib.record_host
+
+
+class SegmentedPlan:
+    """A recorded step with host operations inside: [LaunchPlan | callable]...; run() replays them in order.  The data-parallel
+    step is the user: ~15 all-reduce issue points cut its ~600 calls into as many segments (one xl_plan_run each)."""
+
+    def __init__(self, lib, calls):
+        self.items, seg = [], []
+        for name, args in calls:
+            if name is HOST_OP:
+                if seg:
+                    self.items.append(LaunchPlan(lib, seg))
+                    seg = []
+                self.items.append(args)
+            else:
+                seg.append((name, args))
+        if seg:
+            self.items.append(LaunchPlan(lib, seg))
+        self.n_calls = sum(it.n_calls for it in self.items if isinstance(it, LaunchPlan))
+        self.n_segments = sum(1 for it in self.items if isinstance(it, LaunchPlan))
+        self.n_host_ops = len(self.items) - self.n_segments
+
+    def run(self):
+        for it in self.items:
+            if isinstance(it, LaunchPlan):
+                it.run()
+            else:
+                it()
+
+
 class LaunchPlan:
+    n_segments, n_host_ops = 1, 0
+
     def __init__(self, lib, calls):
         import struct
         self.lib, self.keep = lib, []

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 #include "../../include/xlxmert_hip.h"
 
 namespace xl {
@@ -212,9 +215,31 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t row, uint
 __device__ __forceinline__ uint64_t with_step_seed(uint64_t site_seed, const uint64_t* __restrict__ step) {
     return step != nullptr ? site_seed + *step * 1000003ull : site_seed;
 }
-extern const uint64_t* g_step_seed;
+// ------------------------------------------------------------------ library context (include/xlxmert_hip.h xl_ctx_*)
+// Everything a caller can SET on the library lives in a context object, never in a process global: the dropout step-seed
+// pointer, the deferred-reduction switch and its per-stream pending lists, the slab workspaces registered per stream, and the
+// kernel-choice / debug switches.  A host object that drives the library (one trainer, one sampler engine, one nn.Module) owns
+// one context and binds it to its thread before it calls (xl_ctx_bind; a recorded launch plan carries the bind as its first
+// entry): two of them interleaved in one process cannot see each other's settings.  Callers that never create a context share
+// the default one.
+struct SlabWs { uint8_t* ptr; size_t bytes; };
+struct ReduceOuts { float* p[16]; int stride[16]; };
+struct PendingReduce { const float* ws; int G, nvec, N, gy; ReduceOuts outs; };
+struct Ctx {
+    const uint64_t* step_seed = nullptr;      // xl_set_step_seed_ptr
+    int use_tr_read = 1;                      // xl_set_lds_transpose_read
+    int gemm_pp = -1;                         // xl_set_gemm_pingpong; -1 = XL_GEMM_PP (default 1) at first use
+    int gemm_bn192 = -1;                      // xl_set_gemm_tile192;  -1 = XL_GEMM_BN192 (default 1)
+    int tail_max = -1, tail_min_k = 4096;     // xl_set_gemm_tail_split; -1 = XL_GEMM_TAIL_MAX (64) / XL_GEMM_TAIL_MIN_K (4096)
+    int wgrad_slabs = -1;                     // xl_set_gemm_wgrad_slabs; -1 = XL_GEMM_WGRAD_SLABS (default 0)
+    int defer_reduce = 0;                     // xl_set_deferred_reduce
+    unsigned long long* gemm_trace = nullptr; // xl_gemm_trace
+    std::mutex mu;                            // guards the two maps (a context may be bound by more than one thread)
+    std::unordered_map<hipStream_t, SlabWs> slab_ws;                          // xl_gemm_set_workspace
+    std::unordered_map<hipStream_t, std::vector<PendingReduce>> pending;      // deferred second stages, per stream
+};
+Ctx& ctx();                 // the context bound to the calling thread (optim.hip)
 
-extern int g_use_tr_read;   // set by xl_set_lds_transpose_read
 // out[n] += sum_g ws[g*N + n] (second stage of the two-stage column reductions; rowops.hip)
 void launch_colsum_reduce(const float* ws, int G, int N, float* out, hipStream_t st);
 

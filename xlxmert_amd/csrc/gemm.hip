@@ -212,7 +212,7 @@ static void launch_one(const GemmParams& p, int nblk, hipStream_t st) {
 // through atomics and everything else through the generic epilogue
 template <bool AK, bool BKM>
 static void launch_mfma(const GemmParams& p, int epik, int nblk, hipStream_t st) {
-    if (!g_use_tr_read) return launch_one<AK, BKM, false, -1>(p, nblk, st);
+    if (!ctx().use_tr_read) return launch_one<AK, BKM, false, -1>(p, nblk, st);
     if constexpr (AK) {
         switch (epik) {
             case XL_EPI_NONE: return launch_one<AK, BKM, true, XL_EPI_NONE>(p, nblk, st);
@@ -236,21 +236,14 @@ static int env_int(const char* name, int dflt) {
     return s ? atoi(s) : dflt;
 }
 
-unsigned long long* g_gemm_trace = nullptr;   // xl_gemm_trace
-int g_gemm_pp = -1;      // 0 / 1 / 2, see xl_set_gemm_pingpong; -1 = read XL_GEMM_PP (default 1)
-int g_gemm_bn192 = -1;   // 0 / 1 / 2, see xl_set_gemm_tile192; -1 = read XL_GEMM_BN192 (default 1)
-int g_tail_max = -1, g_tail_min_k = 4096;   // tail split: at most this many tiles in the last round, contraction at least this deep (xl_set_gemm_tail_split)
-int g_wgrad_slabs = -1;  // weight-gradient K splits through slabs instead of atomics (xl_set_gemm_wgrad_slabs); -1 = read XL_GEMM_WGRAD_SLABS (default 0)
-
-// split-K slab workspaces, one per stream (xl_gemm_set_workspace): caller-owned memory, [16 KiB of tickets | slabs]
-struct SlabWs { uint8_t* ptr; size_t bytes; };
-static std::mutex g_slab_mu;
-static std::unordered_map<hipStream_t, SlabWs> g_slab_ws;
+// The kernel-choice switches, the trace buffer and the split-K slab workspaces (one per stream, xl_gemm_set_workspace:
+// caller-owned memory, [16 KiB of tickets | slabs]) live in the calling thread's context (common.h Ctx).
 // -> true and the pointers when the stream has a workspace for `slabs` partial tiles
 static bool slab_workspace(hipStream_t st, long tiles, long slabs, float** slab, int** tickets) {
-    std::lock_guard<std::mutex> lk(g_slab_mu);
-    auto it = g_slab_ws.find(st);
-    if (it == g_slab_ws.end() || tiles * (long)sizeof(int) > (long)SLAB_TICKET_BYTES ||
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.slab_ws.find(st);
+    if (it == c.slab_ws.end() || tiles * (long)sizeof(int) > (long)SLAB_TICKET_BYTES ||
         SLAB_TICKET_BYTES + (size_t)slabs * SLAB_FLOATS * sizeof(float) > it->second.bytes) return false;
     *tickets = reinterpret_cast<int*>(it->second.ptr);
     *slab = reinterpret_cast<float*>(it->second.ptr + SLAB_TICKET_BYTES);
@@ -265,12 +258,12 @@ using namespace xl;
 extern "C" int xl_set_gemm_tail_split(int max_tail_tiles, int min_k) {
     XL_CHECK_ARG(max_tail_tiles >= 0 && max_tail_tiles < 256 && min_k >= 1024, XL_ERR_BAD_ARG,
                  "xl_set_gemm_tail_split: max_tail_tiles %d (0..255), min_k %d (>= 1024)", max_tail_tiles, min_k);
-    g_tail_max = max_tail_tiles; g_tail_min_k = min_k;
+    ctx().tail_max = max_tail_tiles; ctx().tail_min_k = min_k;
     return XL_OK;
 }
 
 extern "C" int xl_set_gemm_wgrad_slabs(int on) {
-    g_wgrad_slabs = on ? 1 : 0;
+    ctx().wgrad_slabs = on ? 1 : 0;
     return XL_OK;
 }
 
@@ -280,30 +273,31 @@ extern "C" int64_t xl_gemm_workspace_bytes(int slabs) {
 
 extern "C" int xl_gemm_set_workspace(void* ws, int64_t bytes, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    std::lock_guard<std::mutex> lk(g_slab_mu);
-    if (ws == nullptr || bytes <= 0) { g_slab_ws.erase(st); return XL_OK; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (ws == nullptr || bytes <= 0) { c.slab_ws.erase(st); return XL_OK; }
     XL_CHECK_ARG(aligned16(ws) && bytes >= (int64_t)SLAB_TICKET_BYTES, XL_ERR_BAD_ARG,
                  "xl_gemm_set_workspace: workspace must be 16-byte aligned and hold the 16 KiB ticket block");
     hipError_t e = hipMemsetAsync(ws, 0, SLAB_TICKET_BYTES, st);          // tickets are zero between launches
     XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm_set_workspace: memset failed: %s", hipGetErrorString(e));
-    g_slab_ws[st] = SlabWs{reinterpret_cast<uint8_t*>(ws), (size_t)bytes};
+    c.slab_ws[st] = SlabWs{reinterpret_cast<uint8_t*>(ws), (size_t)bytes};
     return XL_OK;
 }
 
 extern "C" int xl_gemm_trace(void* buffer) {
-    g_gemm_trace = reinterpret_cast<unsigned long long*>(buffer);
+    ctx().gemm_trace = reinterpret_cast<unsigned long long*>(buffer);
     return XL_OK;
 }
 
 extern "C" int xl_set_gemm_pingpong(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_pingpong: mode %d", mode);
-    g_gemm_pp = mode;
+    ctx().gemm_pp = mode;
     return XL_OK;
 }
 
 extern "C" int xl_set_gemm_tile192(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_tile192: mode %d", mode);
-    g_gemm_bn192 = mode;
+    ctx().gemm_bn192 = mode;
     return XL_OK;
 }
 
@@ -314,6 +308,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
                        int epilogue, float alpha, int accumulate,
                        float p_drop, uint64_t seed, float* colsum_out, float* colsum_ws, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Ctx& cx = ctx();
     XL_CHECK_ARG(M > 0 && N > 0 && K > 0, XL_ERR_BAD_SHAPE, "xl_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     XL_CHECK_ARG(in_dtype == XL_F32 || in_dtype == XL_BF16, XL_ERR_BAD_DTYPE, "xl_gemm: bad in_dtype %d", in_dtype);
     XL_CHECK_ARG(out_dtype == in_dtype || out_dtype == XL_F32, XL_ERR_BAD_DTYPE, "xl_gemm: bad out_dtype %d", out_dtype);
@@ -324,7 +319,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     if (epilogue == XL_EPI_ROWMAX)
         XL_CHECK_ARG(in_dtype == XL_BF16 && a_kmajor && b_kmajor && M % 256 == 0 && N % 256 == 0 && K % 8 == 0 && lda % 8 == 0 &&
                      ldb % 8 == 0 && aux && aligned16(aux) && aligned16(A) && aligned16(B) && (!bias || aligned16(bias)) &&
-                     !accumulate && !colsum_out && g_use_tr_read, XL_ERR_BAD_SHAPE,
+                     !accumulate && !colsum_out && cx.use_tr_read, XL_ERR_BAD_SHAPE,
                      "xl_gemm: XL_EPI_ROWMAX takes bf16 K-major operands with M, N multiples of 256 (M=%d N=%d) and a 16-byte aligned aux", M, N);
     if (epilogue == XL_EPI_RESIDUAL) XL_CHECK_ARG(residual && ldr >= N, XL_ERR_BAD_ARG, "xl_gemm: residual missing");
     if (epilogue == XL_EPI_GELU || epilogue == XL_EPI_DGELU || epilogue == XL_EPI_GELU_DG || epilogue == XL_EPI_MULAUX)
@@ -339,8 +334,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux = aux;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldx = ldx;
     p.epilogue = epilogue; p.out_f32 = (out_dtype == XL_F32); p.alpha = alpha;
-    p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.step_seed = g_step_seed; p.ablate = ablate;
-    p.trace = g_gemm_trace;
+    p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.step_seed = cx.step_seed; p.ablate = ablate;
+    p.trace = cx.gemm_trace;
     p.colsum_ws = nullptr;
     p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0;
     if (colsum_out != nullptr)
@@ -350,11 +345,11 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     const bool mfma_ok = in_dtype == XL_BF16 && (lda % 8 == 0) && (ldb % 8 == 0) && aligned16(A) && aligned16(B);
     const bool may_split = mfma_ok && out_dtype == XL_F32 && epilogue == XL_EPI_NONE;
     // kernel choice.  Ping-pong 256x256 kernel (one workgroup per CU): XL_GEMM_PP = 0 never, 1 by shape, 2 whenever eligible
-    if (g_gemm_pp < 0) g_gemm_pp = env_int("XL_GEMM_PP", 1);
-    const int pp_mode = g_gemm_pp;
+    if (cx.gemm_pp < 0) cx.gemm_pp = env_int("XL_GEMM_PP", 1);
+    const int pp_mode = cx.gemm_pp;
     static const int pp_min_tiles = env_int("XL_GEMM_PP_MIN_TILES", 48);
     const long t256n = (long)((M + 255) / 256) * ((N + 255) / 256);
-    const bool pp_ok = mfma_ok && g_use_tr_read && K % 8 == 0 && (double)(a_kmajor ? M : K) * lda < 1e9 &&
+    const bool pp_ok = mfma_ok && cx.use_tr_read && K % 8 == 0 && (double)(a_kmajor ? M : K) * lda < 1e9 &&
                        (double)(b_kmajor ? N : K) * ldb < 1e9;      // 32-bit byte offsets below 2^31 inside the kernel
     // by shape: >= 48 tiles of 256x256 (x K splits for weight gradients).  In isolation the 128x128 kernel (two workgroups
     // per CU, 4x the tiles) is faster below ~128 tiles (tools/gemm_bench.py), but the language stream's 60-tile contractions
@@ -369,8 +364,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // estimated as rounds over the 256 CUs x relative tile cost (a 256x192 tile does 3/4 of the MFMA work plus the same
     // fixed prologue / epilogue latency: ~0.8).  N = 768: 64 row tiles give 192 tiles of 256x256 (a quarter of the chip
     // idle) or 256 of 256x192; N = 2304: 576 (2.25 rounds) or 768 (3 rounds of 0.8); N = 3072 stays at 256x256.
-    if (g_gemm_bn192 < 0) g_gemm_bn192 = env_int("XL_GEMM_BN192", 1);     // 0 never, 1 by cost, 2 whenever eligible
-    const int bn192_mode = g_gemm_bn192;
+    if (cx.gemm_bn192 < 0) cx.gemm_bn192 = env_int("XL_GEMM_BN192", 1);     // 0 never, 1 by cost, 2 whenever eligible
+    const int bn192_mode = cx.gemm_bn192;
     int bn = 256;
     if (use_pp && bn192_mode && a_kmajor && M % 256 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate &&
         colsum_out == nullptr && epilogue != XL_EPI_TANH && epilogue != XL_EPI_ROWMAX) {
@@ -379,7 +374,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         if (bn192_mode == 2 || c192 < c256) bn = 192;
     }
     p.tiles_n = bn == 192 ? N / 192 : (N + tile - 1) / tile;
-    const int tiles = p.tiles_m * p.tiles_n;
+    int tiles = p.tiles_m * p.tiles_n;
     // split-K only for the weight-gradient shape (fp32 out, plain epilogue): few output tiles, deep K
     int splitk = 1;
     const int want = use_pp ? 256 : 768;
@@ -397,8 +392,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.atomic_out = (accumulate || splitk > 1) ? 1 : 0;
     // split-K of the ping-pong kernel meets in slabs when the stream has a workspace (xl_gemm_set_workspace): one
     // read-modify-write pass over C by the last arriver of every tile instead of a pass of fp32 atomics per split
-    if (g_wgrad_slabs < 0) g_wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
-    if (use_pp && splitk > 1 && g_wgrad_slabs) slab_workspace(st, tiles, (long)tiles * splitk, &p.slab, &p.tickets);
+    if (cx.wgrad_slabs < 0) cx.wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
+    if (use_pp && splitk > 1 && cx.wgrad_slabs) slab_workspace(st, tiles, (long)tiles * splitk, &p.slab, &p.tickets);
     if (splitk > 1 && !accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: memset failed: %s", hipGetErrorString(e));
@@ -420,7 +415,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     if (bn == 192 && epik < 0) {          // the 256x192 tile has the fast epilogue only: back to 256x256
         bn = 256;
         p.tiles_n = (N + tile - 1) / tile;
-    }
+        tiles = p.tiles_m * p.tiles_n;    // (the tail split below and the grid size count THESE tiles; the K split above was sized
+    }                                     //  for an fp32-output launch, which never takes the 192-wide tile)
     // column sums of C ride in the fast epilogue when every tile takes it; otherwise a separate pass over C follows
     const bool colsum_fused = colsum_out != nullptr && mfma_ok && epik >= 0 && splitk == 1 && a_kmajor && M % tile == 0 &&
                               N % tile == 0;
@@ -430,8 +426,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // workspace on this stream (xl_gemm_set_workspace)
     // (measured at the masked-row head, 8448 rows: d(feat) = d(logits) C, K = 10000, 264 tiles: 466 -> 332 us; the logits
     // contraction, K = 2048, 1320 tiles, does not gain -- 338 -> 368 us -- hence the depth threshold)
-    if (g_tail_max < 0) { g_tail_max = env_int("XL_GEMM_TAIL_MAX", 64); g_tail_min_k = env_int("XL_GEMM_TAIL_MIN_K", 4096); }
-    const int tail_max = g_tail_max, tail_min_k = g_tail_min_k;
+    if (cx.tail_max < 0) { cx.tail_max = env_int("XL_GEMM_TAIL_MAX", 64); cx.tail_min_k = env_int("XL_GEMM_TAIL_MIN_K", 4096); }
+    const int tail_max = cx.tail_max, tail_min_k = cx.tail_min_k;
     if (use_pp && splitk == 1 && !p.atomic_out && tiles > 256 && tiles % 256 <= tail_max && tiles % 256 > 0 && K >= tail_min_k) {
         const int rem = tiles % 256;
         int S = std::min(std::min(256 / rem, K / 512), 8);          // >= 8 K tiles per slice, <= 7 slabs for the last arriver to add
@@ -475,8 +471,9 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
     XL_CHECK_ARG(count >= 1 && count <= 8, XL_ERR_BAD_ARG, "xl_gemm_wgrad_group: count %d (1..8)", count);
     XL_CHECK_ARG(A && B && C && M && N && K && lda && ldb && ldc, XL_ERR_BAD_ARG, "xl_gemm_wgrad_group: null argument");
     XL_CHECK_ARG(dtype == XL_F32 || dtype == XL_BF16, XL_ERR_BAD_DTYPE, "xl_gemm_wgrad_group: bad dtype %d", dtype);
-    if (g_gemm_pp < 0) g_gemm_pp = env_int("XL_GEMM_PP", 1);
-    bool grouped = dtype == XL_BF16 && g_gemm_pp != 0 && g_use_tr_read && count > 1;
+    Ctx& cx = ctx();
+    if (cx.gemm_pp < 0) cx.gemm_pp = env_int("XL_GEMM_PP", 1);
+    bool grouped = dtype == XL_BF16 && cx.gemm_pp != 0 && cx.use_tr_read && count > 1;
     long total = 0;
     int max_split = 1 << 20;
     for (int i = 0; i < count; ++i) {
@@ -512,8 +509,8 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
             const char* b1 = b0 + ((size_t)(M[j] - 1) * ldc[j] + N[j]) * sizeof(float);
             if (a0 < b1 && b0 < a1) { disjoint = false; break; }
         }
-    if (g_wgrad_slabs < 0) g_wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
-    if (disjoint && g_wgrad_slabs) slab_workspace(st, total, total * splitk, &g.slab, &g.tickets);
+    if (cx.wgrad_slabs < 0) cx.wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
+    if (disjoint && cx.wgrad_slabs) slab_workspace(st, total, total * splitk, &g.slab, &g.tickets);
     g.rmw = (disjoint && splitk == 1) ? 1 : 0;      // one workgroup per output tile: it owns the tile (two layers' weight gradients in
                                                     // one launch: 216 tiles, no K split, no atomics)
     int acc = 0;

@@ -4,14 +4,19 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
-#include <atomic>
 #include <mutex>
+#include <vector>
 
 namespace xl {
 
 static thread_local char g_err[512] = "";
-int g_use_tr_read = 1;
-const uint64_t* g_step_seed = nullptr;
+
+// contexts: handle = index + 1 into the registry, 0 = the default context; the binding is per thread
+static std::mutex g_ctx_mu;
+static std::vector<Ctx*> g_ctxs;
+static Ctx g_default_ctx;
+static thread_local Ctx* t_ctx = nullptr;
+Ctx& ctx() { return t_ctx != nullptr ? *t_ctx : g_default_ctx; }
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -167,8 +172,36 @@ using namespace xl;
 
 extern "C" const char* xl_last_error(void) { return g_err; }
 extern "C" int xl_version(void) { return 1; }
-extern "C" int xl_set_lds_transpose_read(int enable) { g_use_tr_read = enable ? 1 : 0; return XL_OK; }
-extern "C" int xl_set_step_seed_ptr(const uint64_t* step_seed) { g_step_seed = step_seed; return XL_OK; }
+extern "C" int xl_set_lds_transpose_read(int enable) { ctx().use_tr_read = enable ? 1 : 0; return XL_OK; }
+extern "C" int xl_set_step_seed_ptr(const uint64_t* step_seed) { ctx().step_seed = step_seed; return XL_OK; }
+
+extern "C" int64_t xl_ctx_create(void) {
+    Ctx* c = new Ctx();
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctxs.push_back(c);
+    return (int64_t)g_ctxs.size();
+}
+
+extern "C" int xl_ctx_bind(int64_t handle) {
+    if (handle == 0) { t_ctx = nullptr; return XL_OK; }
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    XL_CHECK_ARG(handle >= 1 && handle <= (int64_t)g_ctxs.size() && g_ctxs[handle - 1] != nullptr, XL_ERR_BAD_ARG,
+                 "xl_ctx_bind: unknown context %lld", (long long)handle);
+    t_ctx = g_ctxs[handle - 1];
+    return XL_OK;
+}
+
+extern "C" int xl_ctx_destroy(int64_t handle) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    XL_CHECK_ARG(handle >= 1 && handle <= (int64_t)g_ctxs.size(), XL_ERR_BAD_ARG, "xl_ctx_destroy: unknown context %lld", (long long)handle);
+    Ctx* c = g_ctxs[handle - 1];
+    if (c != nullptr) {
+        if (t_ctx == c) t_ctx = nullptr;          // (other threads that still have it bound must rebind first: caller's contract)
+        delete c;
+        g_ctxs[handle - 1] = nullptr;
+    }
+    return XL_OK;
+}
 
 extern "C" int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, int total_steps, float beta1, float beta2,
                                 float* lr_and_steps, void* stream) {
@@ -179,26 +212,14 @@ extern "C" int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, 
     return XL_OK;
 }
 
-extern "C" int xl_sumsq(const float* g, float* sumsq, int64_t n, void* stream) {
-    XL_CHECK_ARG(g && sumsq && n > 0 && aligned16(g), XL_ERR_BAD_ARG, "xl_sumsq: bad args");
-    // scratch for the block partials: a small ring, so that calls in flight on different streams do not share one
-    static SumsqScratch* ring[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    static std::atomic<unsigned> next{0};
-    const unsigned slot = next.fetch_add(1) & 7u;
-    if (ring[slot] == nullptr) {
-        static std::mutex mu;
-        std::lock_guard<std::mutex> lk(mu);
-        if (ring[slot] == nullptr) {
-            SumsqScratch* p = nullptr;
-            XL_CHECK_ARG(hipMalloc(&p, sizeof(SumsqScratch)) == hipSuccess && hipMemset(p, 0, sizeof(SumsqScratch)) == hipSuccess,
-                         XL_ERR_HIP, "xl_sumsq: scratch allocation failed");
-            ring[slot] = p;
-        }
-    }
+extern "C" int64_t xl_sumsq_scratch_bytes(void) { return (int64_t)sizeof(SumsqScratch); }
+
+extern "C" int xl_sumsq(const float* g, float* sumsq, int64_t n, void* scratch, void* stream) {
+    XL_CHECK_ARG(g && sumsq && scratch && n > 0 && aligned16(g) && aligned16(scratch), XL_ERR_BAD_ARG, "xl_sumsq: bad args");
     // few, long-lived blocks: every block ends with one ticket on a shared address (4096 of them cost more than the whole pass)
     // (202 M elements: 139 us = 5.8 TB/s with 512 blocks -- the rate of the atomic version -- 189 us with 1024, 341 us with 4096)
     const int grid = std::min(stream_grid(n >> 2), 512);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, sumsq, n, ring[slot]);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, sumsq, n, reinterpret_cast<SumsqScratch*>(scratch));
     XL_CHECK_LAUNCH();
     return XL_OK;
 }

@@ -110,7 +110,6 @@ __device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out
     }
 }
 
-struct ReduceOuts { float* p[16]; int stride[16]; };
 // out[v][n*stride] += sum_g ws[(g*nvec + v)*N + n].  grid = (column blocks, G-slices): each block sums one slice of the
 // partial slabs and adds it with one atomic per column (<= 16 atomics per output element).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int G, int nvec, int N, ReduceOuts outs) {
@@ -1157,10 +1156,7 @@ extern "C" int xl_layernorm_fwd(const void* x, const float* gamma, const float* 
 // (or the gradient exchange of its layer), so a caller may DEFER the second stages (xl_set_deferred_reduce) and have all of a
 // layer's pending ones combined by ONE launch (xl_flush_reductions): ~110 five-microsecond launches per step become ~35.
 // Each deferred producer must have been given its own workspace region.
-struct PendingReduce { const float* ws; int G, nvec, N, gy; ReduceOuts outs; };
-static std::mutex g_pend_mu;
-static std::unordered_map<hipStream_t, std::vector<PendingReduce>> g_pending;
-static int g_defer_reduce = 0;
+// (switch and per-stream pending lists: the calling thread's context, common.h Ctx)
 constexpr int kBatch = 6;
 struct BatchArgs { int n; PendingReduce e[kBatch]; };
 
@@ -1188,16 +1184,17 @@ __global__ __launch_bounds__(256) void reduce_partials_batched_kernel(BatchArgs 
 static void launch_reduce(const float* ws, int G, int nvec, int N, ReduceOuts outs, hipStream_t st) {
     for (int v = 0; v < 16; ++v) if (outs.stride[v] == 0) outs.stride[v] = 1;
     const int gy = G >= 256 ? 16 : (G >= 64 ? 8 : (G >= 16 ? 4 : 1));
-    if (g_defer_reduce) {
-        std::lock_guard<std::mutex> lk(g_pend_mu);
-        g_pending[st].push_back(PendingReduce{ws, G, nvec, N, gy, outs});
+    Ctx& c = ctx();
+    if (c.defer_reduce) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.pending[st].push_back(PendingReduce{ws, G, nvec, N, gy, outs});
         return;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((nvec * N + 255) / 256, gy), dim3(256), 0, st, ws, G, nvec, N, outs);
 }
 
 extern "C" int xl_set_deferred_reduce(int on) {
-    g_defer_reduce = on ? 1 : 0;
+    ctx().defer_reduce = on ? 1 : 0;
     return XL_OK;
 }
 
@@ -1205,9 +1202,10 @@ extern "C" int xl_flush_reductions(void* stream) {
     hipStream_t st = (hipStream_t)stream;
     std::vector<PendingReduce> todo;
     {
-        std::lock_guard<std::mutex> lk(g_pend_mu);
-        auto it = g_pending.find(st);
-        if (it == g_pending.end() || it->second.empty()) return XL_OK;
+        Ctx& c = ctx();
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.pending.find(st);
+        if (it == c.pending.end() || it->second.empty()) return XL_OK;
         todo.swap(it->second);
     }
     for (size_t i = 0; i < todo.size(); i += kBatch) {
@@ -1246,7 +1244,7 @@ extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamm
     DISPATCH_T(dtype, DISPATCH_NIT(T, N,
         hipLaunchKernelGGL((ln_bwd_kernel<T, NIT, LNB_W>), dim3(grid), dim3(LNB_W * 64), 0, st,
                            (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace,
-                           (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed, xl::g_step_seed);));
+                           (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed, xl::ctx().step_seed);));
     XL_CHECK_LAUNCH();
     if (workspace) {
         ReduceOuts o = {};
@@ -1458,7 +1456,7 @@ extern "C" int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy
     if (grid > 4096) grid = 4096;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((dropout_kernel<T>), dim3((int)grid), dim3(256), 0, st, (const T*)x, (T*)y, M, N, ldx, ldy, p_drop,
-                           1.0f / (1.0f - p_drop), seed, xl::g_step_seed););
+                           1.0f / (1.0f - p_drop), seed, xl::ctx().step_seed););
     XL_CHECK_LAUNCH();
     return XL_OK;
 }

@@ -501,7 +501,7 @@ template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_fwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(NQF * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk,
-                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed, g_step_seed);
+                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed, ctx().step_seed);
 }
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
@@ -509,18 +509,18 @@ static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP, NW>), dim3(a.B * a.H), dim3(NW * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq,
                        (bf16_t*)a.dk, (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv,
-                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws, g_step_seed);
+                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws, ctx().step_seed);
 }
 template <int DH, int NQF, int NKF>
 static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
     const bool drop = a.p_drop > 0.f;
-    if (g_use_tr_read) { if (drop) launch_fwd2<DH, NQF, NKF, true, true>(a, st); else launch_fwd2<DH, NQF, NKF, true, false>(a, st); }
+    if (ctx().use_tr_read) { if (drop) launch_fwd2<DH, NQF, NKF, true, true>(a, st); else launch_fwd2<DH, NQF, NKF, true, false>(a, st); }
     else { if (drop) launch_fwd2<DH, NQF, NKF, false, true>(a, st); else launch_fwd2<DH, NQF, NKF, false, false>(a, st); }
 }
 template <int DH, int NQF, int NKF>
 static void launch_bwd(const SdpaArgs& a, hipStream_t st) {
     const bool drop = a.p_drop > 0.f;
-    if (g_use_tr_read) { if (drop) launch_bwd2<DH, NQF, NKF, true, true>(a, st); else launch_bwd2<DH, NQF, NKF, true, false>(a, st); }
+    if (ctx().use_tr_read) { if (drop) launch_bwd2<DH, NQF, NKF, true, true>(a, st); else launch_bwd2<DH, NQF, NKF, true, false>(a, st); }
     else { if (drop) launch_bwd2<DH, NQF, NKF, false, true>(a, st); else launch_bwd2<DH, NQF, NKF, false, false>(a, st); }
 }
 
@@ -579,11 +579,11 @@ extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const ui
     } else if (dtype == XL_BF16) {
         hipLaunchKernelGGL((sdpa_fwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, key_mask, (bf16_t*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
-                           a.inv_keep, seed, g_step_seed);
+                           a.inv_keep, seed, ctx().step_seed);
     } else {
         hipLaunchKernelGGL((sdpa_fwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, key_mask, (float*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
-                           a.inv_keep, seed, g_step_seed);
+                           a.inv_keep, seed, ctx().step_seed);
     }
     XL_CHECK_LAUNCH();
     return XL_OK;
@@ -621,11 +621,11 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
     } else if (dtype == XL_BF16) {
         hipLaunchKernelGGL((sdpa_bwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, key_mask, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, H, nq,
-                           nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, g_step_seed);
+                           nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, ctx().step_seed);
     } else {
         hipLaunchKernelGGL((sdpa_bwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, key_mask, (const float*)dout, lse, (float*)dq, (float*)dk, (float*)dv, H, nq, nk,
-                           dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, g_step_seed);
+                           dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, ctx().step_seed);
     }
     XL_CHECK_LAUNCH();
     if (bias_grad != nullptr) {          // no fused partials on this path: column sums of the stored gradients

@@ -1401,11 +1401,13 @@ class Engine:
         self.clear_grads()
         self.begin_backward()
 
+    accumulate = False      # set by the trainer for the 2nd.. micro-batch of a gradient-accumulation window (--update_freq)
+
     def clear_grads(self):
         """gradient buffer := 0 before a step's backward -- skipped when the optimizer pass of the previous step has already
         cleared it (trainer drop_grads: xl_adamw zero_grad) and nothing has accumulated since."""
         st = self.store
-        if not self.grad_is_zero:
+        if not self.grad_is_zero and not self.accumulate:
             self.ops.zero(st.grad[st.n_mat:st.n_used])
         self.grad_is_zero = False
 

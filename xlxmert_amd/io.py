@@ -16,6 +16,13 @@ def load_state_dict(state_dict_path, loc="cpu"):
     return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
 
 
+def load_state_dict_reference_semantics(state_dict_path, loc="cpu"):
+    """exactly ref x-lxmert/src/utils.py:42-49: keys WITHOUT the `module.` prefix are dropped (what a reference-side reader
+    would see of a file; used to check that save_checkpoint's output is complete for it)."""
+    sd = torch.load(state_dict_path, map_location=loc)
+    return {k[len("module."):]: v for k, v in sd.items() if k.startswith("module.")}
+
+
 def save_checkpoint(model, output_dir, name, ddp_prefix=True):
     """`{output}/{name}_LXRT.pth` (ref lxmert_pretrain.py:675-677); `ddp_prefix` writes the `module.` keys the reference's
     own loader insists on."""

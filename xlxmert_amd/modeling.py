@@ -95,7 +95,17 @@ class LxmertModel(_Named):
                                   train_dropout=self.training)
             self._geom = (B, L, V, self.training)
         self._engine.sync_compute_weights()
+        self._advance_seed(self._engine)
         return self._engine
+
+    _train_calls = 0
+
+    def _advance_seed(self, eng):
+        """training mode: every forward draws fresh dropout masks -- the step part of the seeds (device memory, read by the
+        kernels of this forward AND of its backward) advances once per call, as torch's generator state does in the reference."""
+        if eng.p_hid > 0 or eng.p_attn > 0:
+            self._train_calls += 1
+            eng.set_step_seed(self._train_calls)
 
     def forward(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,
                 visual_attention_mask=None, token_type_ids=None, inputs_embeds=None, output_attentions=None,
@@ -387,6 +397,7 @@ class XLxmertForPretraining(nn.Module):
                                        need_lang=self._store.task != "vis_mask", train_dropout=self.training)
             self.bert._geom = key
         self.bert._engine.sync_compute_weights()
+        self.bert._advance_seed(self.bert._engine)
         return self.bert._engine
 
 
@@ -474,6 +485,7 @@ class VQAModel(nn.Module):
             self.bert._geom = key
         eng = self.bert._engine
         eng.sync_compute_weights()
+        self.bert._advance_seed(eng)
         eng.set_inputs(input_ids, attention_mask, token_type_ids, visual_pos, visual_feats=visual_feats,
                        visual_attention_mask=visual_attention_mask, inputs_embeds=inputs_embeds)
         logit = _VqaFn.apply(self, self._anchor) if torch.is_grad_enabled() else eng.vqa_forward().clone()

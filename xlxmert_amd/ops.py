@@ -32,6 +32,35 @@ class HipOps:
         self.dtype = dtype
         self.dt = xl_dtype(dtype)
         self.block = ""              # label of the model block issuing the current calls (set by the engine; bench.py's per-block table)
+        # this object's library context (include/xlxmert_hip.h xl_ctx_*): step-seed pointer, deferred reductions, slab
+        # workspaces and kernel switches set through it are invisible to every other HipOps of the process
+        self._slab_registered = set()
+        self.ctx = int(self.lib.raw("xl_ctx_create")())
+        if self.ctx <= 0:
+            raise XlError("xl_ctx_create failed")
+
+    _bound = None                    # context currently bound to this (the only calling) thread
+
+    def _call(self, name, *args):
+        if HipOps._bound != self.ctx:
+            self.lib.call("xl_ctx_bind", self.ctx)
+            HipOps._bound = self.ctx
+        return self.lib.call(name, *args)
+
+    def rebind(self):
+        """bind this object's context unconditionally (first entry of a recorded launch plan; after a plan replay, whose last
+        recorded bind -- possibly another object's -- is the one in effect)."""
+        HipOps._bound = None
+        self._call("xl_ctx_bind", self.ctx)
+
+    def __del__(self):
+        try:
+            if HipOps._bound == self.ctx:
+                self.lib.call("xl_ctx_bind", 0)
+                HipOps._bound = None
+            self.lib.call("xl_ctx_destroy", self.ctx)
+        except Exception:
+            pass
 
     # -- plumbing
     @staticmethod
@@ -47,21 +76,28 @@ class HipOps:
         return torch.cuda.current_stream().cuda_stream
 
     def set_lds_transpose_read(self, enable):
-        self.lib.call("xl_set_lds_transpose_read", int(enable))
+        self._call("xl_set_lds_transpose_read", int(enable))
 
     def set_gemm_pingpong(self, mode):
         """0: 128x128 GEMM kernel only; 1: by shape (default); 2: 256x256 ping-pong kernel whenever eligible."""
-        self.lib.call("xl_set_gemm_pingpong", int(mode))
+        self._call("xl_set_gemm_pingpong", int(mode))
+
+    def set_gemm_tail_split(self, max_tail_tiles, min_k):
+        self._call("xl_set_gemm_tail_split", int(max_tail_tiles), int(min_k))
+
+    def gemm_trace(self, buffer):
+        """device tensor for the ping-pong kernel's per-workgroup time stamps, or None (xl_gemm_trace)."""
+        self._call("xl_gemm_trace", self._p(buffer))
 
     def set_gemm_tile192(self, mode):
         """0: 256x256 tiles only; 1: 256x192 where it shortens the launch (default); 2: whenever eligible."""
-        self.lib.call("xl_set_gemm_tile192", int(mode))
+        self._call("xl_set_gemm_tile192", int(mode))
 
     # -- stream plumbing of a step as C-ABI calls (so that a recorded launch plan contains them: _lib.LaunchPlan)
     def zero(self, t):
         """t.zero_() on the current stream (t contiguous)."""
         assert t.is_contiguous()
-        self.lib.call("xl_memset", self._p(t), 0, t.numel() * t.element_size(), self._stream())
+        self._call("xl_memset", self._p(t), 0, t.numel() * t.element_size(), self._stream())
 
     _events, _ev_next = [], 0
 
@@ -77,7 +113,7 @@ class HipOps:
         else:
             ev = cls._events[cls._ev_next % 512]
         cls._ev_next += 1
-        self.lib.call("xl_stream_fork", ev, from_stream.cuda_stream, to_stream.cuda_stream)
+        self._call("xl_stream_fork", ev, from_stream.cuda_stream, to_stream.cuda_stream)
 
     def new_event(self):
         ev = int(self.lib.raw("xl_event_create")())
@@ -86,26 +122,26 @@ class HipOps:
         return ev
 
     def event_record(self, ev, stream):
-        self.lib.call("xl_event_record", ev, stream.cuda_stream)
+        self._call("xl_event_record", ev, stream.cuda_stream)
 
     def stream_wait(self, ev, stream):
-        self.lib.call("xl_stream_wait", ev, stream.cuda_stream)
+        self._call("xl_stream_wait", ev, stream.cuda_stream)
 
     def set_step_seed_ptr(self, step_seed):
         """device tensor (one int64 >= 0) holding the step part of every dropout seed, or None (xl_set_step_seed_ptr)."""
-        self.lib.call("xl_set_step_seed_ptr", self._p(step_seed))
+        self._call("xl_set_step_seed_ptr", self._p(step_seed))
 
     def set_deferred_reduce(self, on):
-        self.lib.call("xl_set_deferred_reduce", int(on))
+        self._call("xl_set_deferred_reduce", int(on))
 
     def flush_reductions(self):
-        self.lib.call("xl_flush_reductions", self._stream())
+        self._call("xl_flush_reductions", self._stream())
 
     # -- dense contractions
     def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
              out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0, colsum=None, ws=None):
         """colsum: optional fp32 [N] that receives += the column sums of C (bias gradient), with workspace `ws`."""
-        self.lib.call("xl_gemm", self._p(A), self._p(B), self._p(C), self._p(bias), self._p(residual), self._p(aux),
+        self._call("xl_gemm", self._p(A), self._p(B), self._p(C), self._p(bias), self._p(residual), self._p(aux),
                       M, N, K, lda, ldb, ldc, ldr, ldx, int(a_kmajor), int(b_kmajor), self.dt,
                       XL_F32 if out_f32 else self.dt, epilogue, float(alpha), int(accumulate), float(p_drop),
                       int(seed), self._p(colsum), self._p(ws if colsum is not None else None), self._stream())
@@ -118,26 +154,27 @@ class HipOps:
         cols = list(zip(*problems))
         ptrs = [vp(*[self._p(t) for t in cols[j]]) for j in range(3)]
         ints = [ia(*[int(v) for v in cols[j]]) for j in range(3, 9)]
-        self.lib.call("xl_gemm_wgrad_group", *ptrs, *ints, n, self.dt, self._stream())
+        self._call("xl_gemm_wgrad_group", *ptrs, *ints, n, self.dt, self._stream())
 
     def set_gemm_wgrad_slabs(self, on):
         """weight-gradient K splits through the slab workspace (fixed summation order) instead of fp32 atomics."""
-        self.lib.call("xl_set_gemm_wgrad_slabs", int(on))
+        self._call("xl_set_gemm_wgrad_slabs", int(on))
 
     def gemm_workspace(self, slabs=256, stream=None):
         """allocate and register the slab workspace of `stream` (default: the current one): xl_gemm_set_workspace."""
         st = stream if stream is not None else torch.cuda.current_stream()
         key = (st.device_index, st.cuda_stream, int(slabs))
-        if key not in _SLAB_WS:               # one per stream for the life of the process: the library keeps the pointer
-            nbytes = int(self.lib.raw("xl_gemm_workspace_bytes")(int(slabs)))
-            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=torch.device("cuda", st.device_index))
-            self.lib.call("xl_gemm_set_workspace", ws.data_ptr(), nbytes, st.cuda_stream)
-            _SLAB_WS[key] = ws
+        nbytes = int(self.lib.raw("xl_gemm_workspace_bytes")(int(slabs)))
+        if key not in _SLAB_WS:               # the memory: one per stream for the life of the process (launches on one stream run
+            _SLAB_WS[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=torch.device("cuda", st.device_index))   # in order)
+        if key not in self._slab_registered:  # the registration: per context
+            self._call("xl_gemm_set_workspace", _SLAB_WS[key].data_ptr(), nbytes, st.cuda_stream)
+            self._slab_registered.add(key)
         return _SLAB_WS[key]
 
     # -- LayerNorm family
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, N, eps):
-        self.lib.call("xl_layernorm_fwd", self._p(x), self._p(gamma), self._p(beta), self._p(y), self._p(mean),
+        self._call("xl_layernorm_fwd", self._p(x), self._p(gamma), self._p(beta), self._p(y), self._p(mean),
                       self._p(rstd), M, N, float(eps), self.dt, self._stream())
 
     def workspace_floats(self, N):
@@ -145,128 +182,133 @@ class HipOps:
 
     def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, ws=None, dx_dropped=None,
                       p_drop=0.0, seed=0):
-        self.lib.call("xl_layernorm_bwd", self._p(dy), self._p(x), self._p(gamma), self._p(mean), self._p(rstd),
+        self._call("xl_layernorm_bwd", self._p(dy), self._p(x), self._p(gamma), self._p(mean), self._p(rstd),
                       self._p(dx), self._p(dgamma), self._p(dbeta), self._p(dbias_prev), M, N, self._p(ws),
                       self._p(dx_dropped), float(p_drop), int(seed), self.dt, self._stream())
 
     def visn_ln_fwd(self, xv, pos, wbox, bbox, gv, bv, gb, bb, y, mean_v, rstd_v, mean_b, rstd_b, M, N, P, eps):
-        self.lib.call("xl_visn_ln_fwd", self._p(xv), self._p(pos), self._p(wbox), self._p(bbox), self._p(gv),
+        self._call("xl_visn_ln_fwd", self._p(xv), self._p(pos), self._p(wbox), self._p(bbox), self._p(gv),
                       self._p(bv), self._p(gb), self._p(bb), self._p(y), self._p(mean_v), self._p(rstd_v),
                       self._p(mean_b), self._p(rstd_b), M, N, P, float(eps), self.dt, self._stream())
 
     def visn_ln_bwd(self, dy, xv, pos, wbox, bbox, gv, gb, mean_v, rstd_v, mean_b, rstd_b, dxv, dgv, dbv, dgb, dbb,
                     dwbox, dbbox, dbias_visn, M, N, P, ws=None):
-        self.lib.call("xl_visn_ln_bwd", self._p(dy), self._p(xv), self._p(pos), self._p(wbox), self._p(bbox),
+        self._call("xl_visn_ln_bwd", self._p(dy), self._p(xv), self._p(pos), self._p(wbox), self._p(bbox),
                       self._p(gv), self._p(gb), self._p(mean_v), self._p(rstd_v), self._p(mean_b), self._p(rstd_b),
                       self._p(dxv), self._p(dgv), self._p(dbv), self._p(dgb), self._p(dbb), self._p(dwbox),
                       self._p(dbbox), self._p(dbias_visn), M, N, P, self._p(ws), self.dt, self._stream())
 
     # -- embeddings / codebook
     def embed_ln_fwd(self, ids, tt, word, pos, type_, gamma, beta, y, pre, mean, rstd, B, L, N, eps):
-        self.lib.call("xl_embed_ln_fwd", self._p(ids), self._p(tt), self._p(word), self._p(pos), self._p(type_),
+        self._call("xl_embed_ln_fwd", self._p(ids), self._p(tt), self._p(word), self._p(pos), self._p(type_),
                       self._p(gamma), self._p(beta), self._p(y), self._p(pre), self._p(mean), self._p(rstd), B, L, N,
                       float(eps), self.dt, self._stream())
 
     def embed_bwd(self, dpre, ids, tt, dword, dpos, dtype_tab, B, L, N):
-        self.lib.call("xl_embed_bwd", self._p(dpre), self._p(ids), self._p(tt), self._p(dword), self._p(dpos),
+        self._call("xl_embed_bwd", self._p(dpre), self._p(ids), self._p(tt), self._p(dword), self._p(dpos),
                       self._p(dtype_tab), B, L, N, self.dt, self._stream())
 
     def codebook_gather(self, cluster_ids, vis_mask, centroids, mask_feat, feats, M, F):
-        self.lib.call("xl_codebook_gather", self._p(cluster_ids), self._p(vis_mask), self._p(centroids),
+        self._call("xl_codebook_gather", self._p(cluster_ids), self._p(vis_mask), self._p(centroids),
                       self._p(mask_feat), self._p(feats), M, F, self.dt, self._stream())
 
     def masked_colsum(self, x, mask, out, M, N, ldx, ws=None):
-        self.lib.call("xl_masked_colsum", self._p(x), self._p(mask), self._p(out), M, N, ldx, self._p(ws), self.dt,
+        self._call("xl_masked_colsum", self._p(x), self._p(mask), self._p(out), M, N, ldx, self._p(ws), self.dt,
                       self._stream())
 
     def colsum(self, x, out, M, N, ldx, ws=None):
-        self.lib.call("xl_colsum", self._p(x), self._p(out), M, N, ldx, self._p(ws), self.dt, self._stream())
+        self._call("xl_colsum", self._p(x), self._p(out), M, N, ldx, self._p(ws), self.dt, self._stream())
 
     def dropout(self, x, y, M, N, ldx, ldy, p_drop, seed):
-        self.lib.call("xl_dropout", self._p(x), self._p(y), M, N, ldx, ldy, float(p_drop), int(seed), self.dt,
+        self._call("xl_dropout", self._p(x), self._p(y), M, N, ldx, ldy, float(p_drop), int(seed), self.dt,
                       self._stream())
 
     def gelu_bwd(self, dy, pre, dx, n):
-        self.lib.call("xl_gelu_bwd", self._p(dy), self._p(pre), self._p(dx), n, self.dt, self._stream())
+        self._call("xl_gelu_bwd", self._p(dy), self._p(pre), self._p(dx), n, self.dt, self._stream())
 
     def tanh_bwd(self, dy, y, dx, n):
-        self.lib.call("xl_tanh_bwd", self._p(dy), self._p(y), self._p(dx), n, self.dt, self._stream())
+        self._call("xl_tanh_bwd", self._p(dy), self._p(y), self._p(dx), n, self.dt, self._stream())
 
     def bce_logits_fwd_bwd(self, logits, targets, dlogits, loss, M, N, ld_logits, ld_targets, ld_dlogits):
-        self.lib.call("xl_bce_logits_fwd_bwd", self._p(logits), self._p(targets), self._p(dlogits), self._p(loss), M, N,
+        self._call("xl_bce_logits_fwd_bwd", self._p(logits), self._p(targets), self._p(dlogits), self._p(loss), M, N,
                       ld_logits, ld_targets, ld_dlogits, self.dt, self._stream())
 
     def remask_lowest(self, prob, vis_mask, B, V, n_mask):
-        self.lib.call("xl_remask_lowest", self._p(prob), self._p(vis_mask), B, V, int(n_mask), self._stream())
+        self._call("xl_remask_lowest", self._p(prob), self._p(vis_mask), B, V, int(n_mask), self._stream())
 
     def sampler_update(self, pred_ids, vis_mask, code_ids, n):
-        self.lib.call("xl_sampler_update", self._p(pred_ids), self._p(vis_mask), self._p(code_ids), n, self._stream())
+        self._call("xl_sampler_update", self._p(pred_ids), self._p(vis_mask), self._p(code_ids), n, self._stream())
 
     def sampler_ar_update(self, prob, pred_ids, visited, vis_mask, code_ids, B, V, fixed_pos=-1):
-        self.lib.call("xl_sampler_ar_update", self._p(prob), self._p(pred_ids), self._p(visited), self._p(vis_mask),
+        self._call("xl_sampler_ar_update", self._p(prob), self._p(pred_ids), self._p(visited), self._p(vis_mask),
                       self._p(code_ids), B, V, int(fixed_pos), self._stream())
 
     # -- attention core
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
-        self.lib.call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),
+        self._call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),
                       B, H, nq, nk, dh, ldq, ldk, ldv, ldo, float(scale), float(p_drop), int(seed), self.dt,
                       self._stream())
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
                  lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None):
-        self.lib.call("xl_sdpa_bwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(dout),
+        self._call("xl_sdpa_bwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(dout),
                       self._p(lse), self._p(dq), self._p(dk), self._p(dv), B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq,
                       lddk, lddv, float(scale), float(p_drop), int(seed), self._p(bias_grad), self._p(ws), self.dt,
                       self._stream())
 
     # -- head losses
     def mask_counts(self, labels, vis_mask, counts, nmask, B, V):
-        self.lib.call("xl_mask_counts", self._p(labels), self._p(vis_mask), self._p(counts), self._p(nmask), B, V,
+        self._call("xl_mask_counts", self._p(labels), self._p(vis_mask), self._p(counts), self._p(nmask), B, V,
                       self._stream())
 
     def ce_fwd_bwd(self, logits, labels, counts, dlogits, loss_out, row_lse, row_argmax, row_maxprob, M, K, ldl, lddl,
                    grad_scale=1.0):
-        self.lib.call("xl_ce_fwd_bwd", self._p(logits), self._p(labels), self._p(counts), self._p(dlogits),
+        self._call("xl_ce_fwd_bwd", self._p(logits), self._p(labels), self._p(counts), self._p(dlogits),
                       self._p(loss_out), self._p(row_lse), self._p(row_argmax), self._p(row_maxprob), M, K, ldl, lddl,
                       float(grad_scale), self.dt, self._stream())
 
     def featloss_fwd_bwd(self, pred, centroids, cluster_ids, vis_mask, nmask, dpred, loss_out, B, V, F,
                          grad_scale=1.0, rows=None, n_rows=0, targets=None):
         """targets: optional [B*V, F] regression targets (label_dict['feat_labels']); default = centroids[cluster_ids]."""
-        self.lib.call("xl_featloss_fwd_bwd", self._p(pred), self._p(centroids), self._p(cluster_ids),
+        self._call("xl_featloss_fwd_bwd", self._p(pred), self._p(centroids), self._p(cluster_ids),
                       self._p(vis_mask), self._p(nmask), self._p(dpred), self._p(loss_out), B, V, F, float(grad_scale),
                       self._p(rows), int(n_rows), self._p(targets), self.dt, self._stream())
 
     def gather_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
-        self.lib.call("xl_gather_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
+        self._call("xl_gather_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
 
     def scatter_rows(self, src, rows, dst, n_rows, N, ld_src, ld_dst):
-        self.lib.call("xl_scatter_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
+        self._call("xl_scatter_rows", self._p(src), self._p(rows), self._p(dst), n_rows, N, ld_src, ld_dst, self.dt, self._stream())
 
     def rowmax_combine(self, ws, n_seg, M, row_maxprob, row_argmax, row_lse=None):
         """second half of gemm(epilogue=EPI_ROWMAX, aux=ws): per-row argmax / max softmax probability / log-sum-exp."""
-        self.lib.call("xl_rowmax_combine", self._p(ws), n_seg, M, self._p(row_maxprob), self._p(row_argmax), self._p(row_lse),
+        self._call("xl_rowmax_combine", self._p(ws), n_seg, M, self._p(row_maxprob), self._p(row_argmax), self._p(row_lse),
                       self._stream())
 
     def gather_labels(self, labels, rows, out, n_rows):
-        self.lib.call("xl_gather_labels", self._p(labels), self._p(rows), self._p(out), n_rows, self._stream())
+        self._call("xl_gather_labels", self._p(labels), self._p(rows), self._p(out), n_rows, self._stream())
 
-    def sumsq(self, g, out, n):
-        self.lib.call("xl_sumsq", self._p(g), self._p(out), n, self._stream())
+    def sumsq_scratch(self, device):
+        """zeroed scratch for xl_sumsq (block partials + ticket): one per call site that may run concurrently with another."""
+        n = int(self.lib.raw("xl_sumsq_scratch_bytes")())
+        return torch.zeros((n + 3) // 4, dtype=torch.float32, device=device)
+
+    def sumsq(self, g, out, n, scratch):
+        self._call("xl_sumsq", self._p(g), self._p(out), n, self._p(scratch), self._stream())
 
     def schedule_step(self, step, base_lr, warmup_steps, total_steps, beta1, beta2, lr_and_steps):
         """device-side: step[0] += 1; lr_and_steps = {lr(t), 1-beta1^t, 1-beta2^t, t} (stream-ordered before adamw)."""
-        self.lib.call("xl_schedule_step", self._p(step), float(base_lr), int(warmup_steps), int(total_steps), float(beta1),
+        self._call("xl_schedule_step", self._p(step), float(base_lr), int(warmup_steps), int(total_steps), float(beta1),
                       float(beta2), self._p(lr_and_steps), self._stream())
 
     def adamw(self, p, g, m, v, p_compute, decay_flags, sumsq, lr_and_steps, n, beta1, beta2, eps, weight_decay,
               max_norm, grad_scale=1.0, chunk_steps=None, zero_grad=False):
-        self.lib.call("xl_adamw", self._p(p), self._p(g), self._p(m), self._p(v), self._p(p_compute),
+        self._call("xl_adamw", self._p(p), self._p(g), self._p(m), self._p(v), self._p(p_compute),
                       self._p(decay_flags), self._p(chunk_steps), self._p(sumsq), self._p(lr_and_steps), n, float(beta1), float(beta2),
                       float(eps), float(weight_decay), float(max_norm), float(grad_scale), int(zero_grad), self.dt, self._stream())
 
     def cast_from_f32(self, src, dst, n):
-        self.lib.call("xl_cast_from_f32", self._p(src), self._p(dst), n, self.dt, self._stream())
+        self._call("xl_cast_from_f32", self._p(src), self._p(dst), n, self.dt, self._stream())
 
     def cast_to_f32(self, src, dst, n):
-        self.lib.call("xl_cast_to_f32", self._p(src), self._p(dst), n, self.dt, self._stream())
+        self._call("xl_cast_to_f32", self._p(src), self._p(dst), n, self.dt, self._stream())

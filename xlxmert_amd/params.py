@@ -317,6 +317,13 @@ class ParamStore:
     def set_centroids(self, centroids):
         c = torch.as_tensor(centroids, dtype=torch.float32).to(self.device).contiguous()
         assert c.shape == (self.cfg.num_clusters, self.cfg.visual_feat_dim), c.shape
+        if self.centroids is not None:
+            # keep the device buffers (kernels recorded in a launch plan, engines' views and the modules' tied
+            # vis_emb.weight / out_cluster.weight all hold their addresses): overwrite in place
+            self.centroids.copy_(c)
+            if self.centroids_c is not self.centroids:
+                self.centroids_c.copy_(c)
+            return
         self.centroids = c
         self.centroids_c = c if self.compute_dtype == torch.float32 else c.to(self.compute_dtype)
 

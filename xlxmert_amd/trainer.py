@@ -73,7 +73,10 @@ class PretrainStep:
         _lib.LaunchPlan), one per launch geometry -- instead of enqueueing it from Python (13 ms of host time per step).
         Everything a step varies lives in device memory: inputs in the engine's static buffers, the dropout step seed
         (engine.seed_dev), the schedule scalars (xl_schedule_step), the masked-row list padded to the GEMM row tile.
-        Single-process runs only (a gradient exchange keeps the eager path); default off, env XL_PLAN=1|0 overrides.
+        With a gradient exchange (world > 1) the plan is SEGMENTED: torch.distributed's all-reduce is not an entry point of the
+        library, so every issue point of a bucket cuts the record and the replay alternates xl_plan_run(segment) with the
+        collective (_lib.SegmentedPlan: ~15 segments per step).  Plans freeze the step's scalars (lr, weight decay, clip, schedule
+        length) and the codebook pointer: changing one of them drops the recorded plans.  Default off, env XL_PLAN=1|0 overrides.
         (A hipGraph of the same step was measured and rejected: see csrc/plan.hip.)
         drop_grads: the optimizer pass clears the gradient buffer itself (the reference's optim.zero_grad(),
         lxmert_pretrain.py:241, folded into xl_adamw: 4 bytes per element more in that pass instead of a separate 0.8 GB
@@ -103,6 +106,7 @@ class PretrainStep:
                              train_dropout=train_dropout)
         self.engine.sync_compute_weights()
         self.store.ensure_adam_state()
+        self._plans, self._plan_warm = {}, False
         self.lr, self.wd, self.clip = lr, weight_decay, clip_grad_norm
         self.betas, self.eps = betas, eps
         self.total_steps, self.warmup_steps = total_steps, int(total_steps * warmup_ratio)
@@ -113,6 +117,8 @@ class PretrainStep:
         self.chunk_steps = (torch.zeros(self.store.n_total // 256, dtype=torch.int32, device=self.device)
                             if task == "all" else None)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.sumsq_scratch = (self.ops.sumsq_scratch(self.device) if hasattr(self.ops, "sumsq_scratch")
+                              else torch.zeros(1, dtype=torch.float32, device=self.device))     # (xl_sumsq block partials + ticket)
         # update counter, learning rate and bias corrections live on the device and are advanced by a kernel queued in front
         # of AdamW (xl_schedule_step): the host, which runs several steps ahead of the GPU, never writes step scalars into
         # memory a queued step still has to read
@@ -131,8 +137,8 @@ class PretrainStep:
         self.exposed_comm_ms = []              # per step: time the main stream waited for collectives after backward
         env = os.environ.get("XL_PLAN")
         self.plan_mode = bool(int(env)) if env else bool(plan)
-        self.plan_mode = self.plan_mode and isinstance(self.ops, HipOps) and not self.exchange and task == "vis_mask"
-        self._plans, self._plan_warm = {}, False
+        self.plan_mode = self.plan_mode and isinstance(self.ops, HipOps) and task == "vis_mask"
+        self._accum_pending = False            # gradient accumulation (step(update=False)): the buffer holds earlier micro-batches
         self.drop_grads = (self.plan_mode if drop_grads is None else bool(drop_grads)) and task != "all"
         env = os.environ.get("XL_OPT_OVERLAP")
         overlap = bool(int(env)) if env else bool(overlap_optimizer)
@@ -148,6 +154,25 @@ class PretrainStep:
                 self.engine.params_ready = self._wait_params
         if self.world > 1:
             self.sync_replicas()
+
+    # Step scalars a recorded launch plan has frozen into its argument words: assigning one drops the plans (they are re-recorded
+    # on the next step of each geometry).  Eager steps read them at every call anyway.
+    def _hyper(name):
+        attr = "_" + name
+
+        def get(self):
+            return getattr(self, attr)
+
+        def set_(self, value):
+            if getattr(self, attr, None) != value and getattr(self, "_plans", None):
+                self._plans.clear()
+            setattr(self, attr, value)
+        return property(get, set_)
+
+    lr, wd, clip = _hyper("lr"), _hyper("wd"), _hyper("clip")
+    total_steps, warmup_steps = _hyper("total_steps"), _hyper("warmup_steps")
+    betas, eps = _hyper("betas"), _hyper("eps")
+    del _hyper
 
     def _wait_params(self, key):
         """engine hook: the current stream is about to read the parameters of group `key` -- wait for the optimizer pass of
@@ -200,7 +225,22 @@ class PretrainStep:
         return [f"{kinds[i // len(names)]}:{names[i % len(names)]}" for i in bad]
 
     def set_centroids(self, centroids):
+        """new codebook (ref lxrt/modeling.py:140-151 set_visual_embedding).  The store keeps the device buffers it already has
+        (same shape: copied in place), and the recorded launch plans -- which hold raw pointers -- are dropped either way."""
         self.store.set_centroids(centroids)
+        self._plans.clear()
+
+    def reduce_metrics(self, results, dst=0):
+        """ref x-lxmert/src/utils.py:11-39 `reduce_dict`: the per-rank values of an epoch's metric dict (losses, counts: python
+        numbers or 0-d tensors) are summed onto rank `dst` with ONE reduce of the stacked, key-sorted vector; returns
+        {name: float} on `dst` and None elsewhere (a single process gets its own values back)."""
+        names = sorted(results.keys())
+        vals = torch.stack([torch.as_tensor(results[k]).detach().float().reshape(()).to(self.device) for k in names])
+        if self.world > 1:
+            dist.reduce(vals, dst=dst)
+            if self.rank != dst:
+                return None
+        return {k: v for k, v in zip(names, vals.tolist())}
 
     # ---- gradient exchange (DDP semantics: SUM over ranks here, the 1/world factor is folded into the optimizer kernel).
     # The flat gradient buffer is laid out in backward-completion order, so the engine reports growing finished ranges
@@ -211,12 +251,26 @@ class PretrainStep:
     def _begin_exchange(self):
         self._lanes, self._works, self._slices = {}, [], []
 
+    def _host_op(self, fn):
+        """run `fn` now and, while a launch plan is being recorded, make it a host operation of the plan (replayed between
+        two segments: _lib.Lib.record_host)."""
+        fn()
+        lib = getattr(self.ops, "lib", None)
+        if lib is not None:
+            lib.record_host(fn)
+
     def _send(self, lo, hi):
         buf = self.store.grad
         if self.comm_buf is not None:           # bf16 bucket, filled on the stream that just finished the slice
             self._comm_ops.cast_from_f32(self.store.grad[lo:hi], self.comm_buf[lo:hi], hi - lo)
             buf = self.comm_buf
-        self._works.append(dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        piece = buf[lo:hi]
+        stream = torch.cuda.current_stream() if self.device.type == "cuda" else None      # the stream that finished the slice
+
+        def issue():
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+        self._host_op(issue)
         self._slices.append((lo, hi))
 
     def _on_grad_ready(self, lo, hi, flush=False, lane="v"):
@@ -240,15 +294,18 @@ class PretrainStep:
             pos = hi
         assert pos == self.store.n_used, (pos, self.store.n_used)
         timed = self.device.type == "cuda"
-        if timed:
-            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0.record()
-        for w in self._works:
-            w.wait()
-        if timed:
-            t1.record()
-            self.exposed_comm_ms.append((t0, t1))
-            del self.exposed_comm_ms[:-64]
+
+        def wait_all():                         # the compute stream waits for every bucket (a host operation of a recorded plan)
+            if timed:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+            for w in self._works:
+                w.wait()
+            if timed:
+                t1.record()
+                self.exposed_comm_ms.append((t0, t1))
+                del self.exposed_comm_ms[:-64]
+        self._host_op(wait_all)
         if self.comm_buf is not None:           # summed bf16 buckets back into the fp32 gradient buffer (norm + AdamW read it)
             n = self.store.n_used
             self._comm_ops.cast_to_f32(self.comm_buf[:n], self.store.grad[:n], n)
@@ -259,10 +316,19 @@ class PretrainStep:
         ts = [a.elapsed_time(b) for a, b in self.exposed_comm_ms]
         return sum(ts) / len(ts) if ts else 0.0
 
-    def step(self, batch, task=None):
+    def step(self, batch, task=None, update=True):
         """batch: dict with input_ids, attention_mask (optional), token_type_ids (optional), visual_pos,
-        cluster_ids, vis_mask, obj_labels (optional: derived from cluster_ids/vis_mask as the reference does)."""
+        cluster_ids, vis_mask, obj_labels (optional: derived from cluster_ids/vis_mask as the reference does).
+        update=False: gradient accumulation (the reference's --update_freq, tasks/vqa.py:152-159,189-198): forward + backward
+        only, the gradients stay in the buffer and the next call adds to them; the call with update=True exchanges the SUM of
+        the micro-batches' gradients (DDP reduces every backward: the same sum), clips, steps and drops them."""
         eng, st, ops = self.engine, self.store, self.ops
+        if batch.get("_ready") is not None:           # staged by a BatchUploader: the copies must have landed
+            torch.cuda.current_stream().wait_event(batch["_ready"])
+        eng.accumulate = self._accum_pending          # earlier micro-batches are in the gradient buffer: do not clear it
+        accumulating = self._accum_pending or not update
+        self._accum_pending = not update
+        exchange = self.exchange and update
         run = self.task if self.task != "all" else task           # a multi-task step object is told which branch to run
         assert run in ("vis_mask", "word_mask", "matched", "qa", "vqa", "nlvr2"), "PretrainStep(task='all').step(batch, task=...)"
         # a model built with task_qa (ParamStore num_answers > 0 on a pretraining task): batch["qa_labels"] [B] (-100 = no
@@ -280,7 +346,9 @@ class PretrainStep:
             # word_rows_of(word_labels), the masked-row decoder) | matched_labels
             eng.set_step_seed(self.t * self.world + self.rank)
             eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"])
-            if self.exchange:
+            self._mark_consumed(batch)
+            eng.grad_ready = None
+            if exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
             if run == "word_mask":
@@ -289,9 +357,10 @@ class PretrainStep:
                 loss = eng.matched_forward_backward(batch["matched_labels"], qa_labels=qa_labels)
             else:
                 loss = eng.qa_forward_backward(qa_labels)
-            if self.exchange:
+            if exchange:
                 self._finish_exchange()
-            self.optimizer_step()
+            if update:
+                self.optimizer_step()
             return loss
         if run in ("vqa", "nlvr2"):
             # vqa: input_ids (word_ids), visual_feats [B,V,F] (vis_feats), visual_pos (boxes), targets [B,A] soft scores
@@ -302,13 +371,16 @@ class PretrainStep:
                 feats, pos = feats.reshape(-1, *feats.shape[2:]), pos.reshape(-1, *pos.shape[2:])
             eng.set_step_seed(self.t * self.world + self.rank)
             eng.set_inputs(ids, am, batch.get("token_type_ids"), pos, visual_feats=feats)
-            if self.exchange:
+            self._mark_consumed(batch)
+            eng.grad_ready = None
+            if exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
             loss = eng.vqa_forward_backward(batch["targets"]) if run == "vqa" else eng.nlvr2_forward_backward(batch["labels"])
-            if self.exchange:
+            if exchange:
                 self._finish_exchange()
-            self.optimizer_step()
+            if update:
+                self.optimizer_step()
             return loss
         labels = batch.get("obj_labels")
         if labels is None:
@@ -318,15 +390,28 @@ class PretrainStep:
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                        vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"),
                        feat_labels=batch.get("feat_labels") if self.feat_loss else None)
-        if self.plan_mode and qa_labels is None:
+        self._mark_consumed(batch)
+        if self.plan_mode and qa_labels is None and not accumulating:
             return self._planned_step()
-        if self.exchange:
+        return self._eager_vis_mask(exchange, update, qa_labels)
+
+    @staticmethod
+    def _mark_consumed(batch):
+        """the engine's static buffers hold the batch (set_inputs is queued): a BatchUploader may refill the staging slot."""
+        if batch.get("_consumed") is not None:
+            batch["_consumed"].record()
+
+    def _eager_vis_mask(self, exchange, update=True, qa_labels=None):
+        eng = self.engine
+        eng.grad_ready = None
+        if exchange:
             self._begin_exchange()
             eng.grad_ready = self._on_grad_ready
         losses = eng.vis_mask_forward_backward(self.feat_loss, qa_labels=qa_labels)
-        if self.exchange:
+        if exchange:
             self._finish_exchange()
-        self.optimizer_step()
+        if update:
+            self.optimizer_step()
         return losses
 
     def _planned_step(self):
@@ -339,17 +424,18 @@ class PretrainStep:
         key = (eng.n_mrows if use_rows else -1, bool(self.feat_loss), eng.feat_tgt is not None, eng.has_vmask, eng.use_codebook)
         plan = self._plans.get(key)
         if plan is not None:
+            if self.exchange:
+                self._begin_exchange()          # (the recorded host operations append to this replay's work list)
             plan.run()
+            HipOps._bound = None                # (the replay ends in whichever context its last recorded bind named)
             self.t += 1
             return eng.losses
         if not self._plan_warm:
             self._plan_warm = True
-            losses = eng.vis_mask_forward_backward(self.feat_loss)
-            self.optimizer_step()
-            return losses
+            return self._eager_vis_mask(self.exchange)
         with self.ops.lib.record() as calls:
-            eng.vis_mask_forward_backward(self.feat_loss)
-            self.optimizer_step()
+            self.ops.rebind()                   # first entry of the plan: this trainer's library context
+            self._eager_vis_mask(self.exchange)
         self._plans[key] = self.ops.lib.make_plan(calls)
         return eng.losses
 
@@ -364,7 +450,7 @@ class PretrainStep:
         n = st.n_used
         if self.clip > 0:
             ops.zero(self.sumsq)
-            ops.sumsq(st.grad, self.sumsq, n)
+            ops.sumsq(st.grad, self.sumsq, n, self.sumsq_scratch)
         flags = st.decay_flags
         if self.chunk_steps is not None:
             flags = st.task_flags(self._step_task)
@@ -398,6 +484,49 @@ class PretrainStep:
 
     def grad_norm(self):
         return math.sqrt(float(self.sumsq.item())) / self.world
+
+
+class BatchUploader:
+    """Host -> device hand-over of minibatches (the reference's `.cuda()` calls at the top of every step, ref
+    lxmert_pretrain.py:145-160), one step ahead of the compute: `upload(host_batch)` queues the copies of the NEXT batch from
+    pinned host memory into one of two device staging slots on a copy stream of its own and returns the staged batch;
+    PretrainStep.step() makes the compute stream wait for that upload (`_ready`) before it moves the tensors into the engine's
+    static input buffers, and marks the slot free afterwards (`_consumed`).  The copy stream never waits for anything younger than
+    two steps, so it does not hold up a hardware queue it may share with a compute stream (engine.reserve_streams)."""
+
+    def __init__(self, device, slots=2):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.slots = [{} for _ in range(slots)]
+        self.ready = [torch.cuda.Event() for _ in range(slots)]
+        self.consumed = [None] * slots
+        self.n = 0
+
+    @staticmethod
+    def pin(batch):
+        """a host batch in page-locked memory (what a DataLoader(pin_memory=True) hands over, ref lxmert_data.py:666-671)."""
+        return {k: (v.pin_memory() if torch.is_tensor(v) and not v.is_cuda else v) for k, v in batch.items()}
+
+    def upload(self, batch):
+        k = self.n % len(self.slots)
+        self.n += 1
+        slot = self.slots[k]
+        with torch.cuda.stream(self.stream):
+            if self.consumed[k] is not None:
+                self.stream.wait_event(self.consumed[k])       # the step that read this slot (two uploads ago) has taken its copy
+            for name, v in batch.items():
+                if not torch.is_tensor(v):
+                    slot[name] = v
+                    continue
+                buf = slot.get(name)
+                if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
+                    buf = slot[name] = torch.empty(v.shape, dtype=v.dtype, device=self.device)
+                buf.copy_(v, non_blocking=True)
+            self.ready[k].record(self.stream)
+        out = {name: slot[name] for name in batch}
+        out["_ready"] = self.ready[k]
+        self.consumed[k] = out["_consumed"] = torch.cuda.Event()
+        return out
 
 
 def synthetic_batch(cfg, B, L=20, grid=8, seed=9595, device="cpu", ragged=True):
