@@ -251,6 +251,9 @@ def main():
     ap.add_argument("--resident-inputs", action="store_true", help="minibatches resident in HBM before the timed region (default: "
                     "pinned host memory, uploaded inside the timed step on a copy stream, one step ahead)")
     args = ap.parse_args()
+    if os.environ.get("XL_BENCH_FAULT_TIMEOUT"):        # debugging aid: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["XL_BENCH_FAULT_TIMEOUT"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain script: launch the N ranks ourselves (one process per GPU through torch.distributed.run, the
         # same launcher the driver uses) and pass rank 0's single JSON line through on the inherited stdout

@@ -234,16 +234,25 @@ int xl_sampler_ar_update(const float* prob, const int* pred_ids, void* visited, 
  * q/k/v/o are [B, n, H*dh]-shaped views with row strides ldq/ldk/ldv/ldo (elements); head h
  * occupies columns [h*dh, (h+1)*dh).  key_mask: uint8 [B,nk] or NULL.  lse: fp32 [B,H,nq]
  * (log-sum-exp of the scaled scores) saved for backward.  Probability dropout (HF:258):
- * p_drop with mask hash(seed, row = (b*H+h)*nq+q, column = key). */
+ * p_drop with mask hash(seed, row = (b*H+h)*nq+q, column = key).
+ * PACKED rows (q_rowoff / k_rowoff, int32 device arrays [B+1], ascending; NULL = the dense [B, n] layout): the rows of batch
+ * element b on that side are [off[b], off[b+1]) of the matrix -- the language rows of a batch with the [PAD] positions removed
+ * (the additive mask of HF:238-266 excludes exactly those keys, and no loss reads a [PAD] query's output: dropping the rows is
+ * exact).  nq / nk stay the per-example CAPACITY (<= 64; lse and the dropout counters keep their [B, H, n] indexing); a packed
+ * key side needs no key_mask.  Rows [off[B], *_rows_padded) -- the tail that rounds the packed row count up to the GEMM row
+ * tile -- are written as ZEROS (o; dq on the query side; dk, dv on the key side), so the contractions over all rows that
+ * follow (out-projection, weight gradients) read zeros there. */
 int xl_sdpa_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
                 void* o, float* lse, int B, int H, int nq, int nk, int dh,
                 int ldq, int ldk, int ldv, int ldo, float scale,
-                float p_drop, uint64_t seed, int dtype, void* stream);
+                float p_drop, uint64_t seed, const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded,
+                int dtype, void* stream);
 int xl_sdpa_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
                 const void* dout, const float* lse,
                 void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
                 int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
-                float p_drop, uint64_t seed, float* bias_grad, float* workspace, int dtype, void* stream);
+                float p_drop, uint64_t seed, float* bias_grad, float* workspace,
+                const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded, int dtype, void* stream);
 /* bias_grad (optional, fp32 [3*H*dh]): bias_grad[q | k | v] += column sums of dq / dk / dv over all B*n rows - the bias
  * gradients of the query/key/value projections (HF:232-239 nn.Linear) - from per-token scalars inside the kernel, without
  * re-reading dq/dk/dv; `workspace` as for xl_colsum (the second stage obeys xl_set_deferred_reduce). */

@@ -259,33 +259,71 @@ class FakeOps:
         row = torch.arange(B * H * nq).view(B, H, nq, 1)                # (b*H+h)*nq+q
         return keep_scale(seed, row, torch.arange(nk).view(1, 1, 1, nk), p_drop)
 
-    def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
-        Q, K_, V_ = (self._heads(t, B, n, H, dh, ld).float() for t, n, ld in ((q, nq, ldq), (k, nk, ldk), (v, nk, ldv)))
+    # packed rows (include/xlxmert_hip.h xl_sdpa_*: q_rowoff / k_rowoff): unpack into the dense [B, H, n, dh] layout (zeros beyond
+    # an example's length), compute as ever with the missing keys masked, store the real rows back, zero the pad tail
+    def _load(self, t, B, n, H, dh, ld, off):
+        if off is None:
+            return self._heads(t, B, n, H, dh, ld).float(), None
+        off = [int(x) for x in off.view(-1)[:B + 1]]
+        mat = torch.as_strided(t, (off[B], H * dh), (ld, 1)).float()
+        out, valid = torch.zeros(B, n, H * dh), torch.zeros(B, n, dtype=torch.bool)
+        for b_ in range(B):
+            m = min(n, off[b_ + 1] - off[b_])
+            out[b_, :m] = mat[off[b_]:off[b_] + m]
+            valid[b_, :m] = True
+        return out.view(B, n, H, dh).permute(0, 2, 1, 3), valid
+
+    def _store(self, dst, val, B, n, H, dh, ld, off, pad):
+        if off is None:
+            self._heads(dst, B, n, H, dh, ld).copy_(val)
+            return
+        off = [int(x) for x in off.view(-1)[:B + 1]]
+        mat = torch.as_strided(dst, (max(pad, off[B]), H * dh), (ld, 1))
+        rows = val.permute(0, 2, 1, 3).reshape(B, n, H * dh)
+        for b_ in range(B):
+            m = min(n, off[b_ + 1] - off[b_])
+            mat[off[b_]:off[b_] + m].copy_(rows[b_, :m])
+        if pad > off[B]:
+            mat[off[B]:pad].zero_()
+
+    def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0,
+                 q_off=None, k_off=None, q_pad=0, k_pad=0):
+        (Q, qv), (K_, kv), (V_, _) = (self._load(t, B, n, H, dh, ld, off)
+                                      for t, n, ld, off in ((q, nq, ldq, q_off), (k, nk, ldk, k_off), (v, nk, ldv, k_off)))
         s = Q @ K_.transpose(-1, -2) * scale
         if key_mask is not None:
             s = s.masked_fill(key_mask.view(B, 1, 1, nk) == 0, float("-inf"))
+        if kv is not None:
+            s = s.masked_fill(~kv.view(B, 1, 1, nk), float("-inf"))
         lse.view(B, H, nq).copy_(torch.logsumexp(s, -1))
-        self._heads(o, B, nq, H, dh, ldo).copy_((torch.softmax(s, -1) * self._pmask(B, H, nq, nk, p_drop, self._seed(seed))) @ V_)
+        out = (torch.softmax(s, -1) * self._pmask(B, H, nq, nk, p_drop, self._seed(seed))) @ V_
+        self._store(o, out, B, nq, H, dh, ldo, q_off, q_pad)
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
-                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None):
-        Q, K_, V_, dO = (self._heads(t, B, n, H, dh, ld).float()
-                         for t, n, ld in ((q, nq, ldq), (k, nk, ldk), (v, nk, ldv), (dout, nq, ldo)))
+                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None, q_off=None, k_off=None, q_pad=0, k_pad=0):
+        (Q, qv), (K_, kv), (V_, _), (dO, _) = (self._load(t, B, n, H, dh, ld, off) for t, n, ld, off in
+                                               ((q, nq, ldq, q_off), (k, nk, ldk, k_off), (v, nk, ldv, k_off), (dout, nq, ldo, q_off)))
         s = Q @ K_.transpose(-1, -2) * scale
         p = torch.exp(s - lse.view(B, H, nq, 1))
         if key_mask is not None:
             p = p.masked_fill(key_mask.view(B, 1, 1, nk) == 0, 0.0)
+        if kv is not None:
+            p = p.masked_fill(~kv.view(B, 1, 1, nk), 0.0)
+        if qv is not None:                                   # queries beyond an example's length do not exist
+            p = p.masked_fill(~qv.view(B, 1, nq, 1), 0.0)
+        p = torch.nan_to_num(p, nan=0.0, posinf=0.0)
         msk = self._pmask(B, H, nq, nk, p_drop, self._seed(seed))
         dp = (dO @ V_.transpose(-1, -2)) * msk
         delta = (p * dp).sum(-1, keepdim=True)
         ds = p * (dp - delta) * scale
         p = p * msk
-        self._heads(dq, B, nq, H, dh, lddq).copy_(ds @ K_)
-        self._heads(dk, B, nk, H, dh, lddk).copy_(ds.transpose(-1, -2) @ Q)
-        self._heads(dv, B, nk, H, dh, lddv).copy_(p.transpose(-1, -2) @ dO)
+        gq, gk, gv = ds @ K_, ds.transpose(-1, -2) @ Q, p.transpose(-1, -2) @ dO
+        self._store(dq, gq, B, nq, H, dh, lddq, q_off, q_pad)
+        self._store(dk, gk, B, nk, H, dh, lddk, k_off, k_pad)
+        self._store(dv, gv, B, nk, H, dh, lddv, k_off, k_pad)
         if bias_grad is not None:
             HD = H * dh
-            for i, g in enumerate((ds @ K_, ds.transpose(-1, -2) @ Q, p.transpose(-1, -2) @ dO)):
+            for i, g in enumerate((gq, gk, gv)):
                 bias_grad[i * HD:(i + 1) * HD] += g.sum(dim=(0, 2)).reshape(HD)       # [B,H,n,dh] -> [H*dh]
 
     def mask_counts(self, labels, vis_mask, counts, nmask, B, V):

@@ -83,7 +83,7 @@ def test_need_lang_engine_gives_same_vis_grads():
     eng.store.grad.zero_()
     eng.losses_forward_backward(True)
     eng.GA.zero_()
-    eng.head_backward(eng.GA[eng.ML:])
+    eng.head_backward(eng.vr(eng.GA))
     eng.encoder_backward(have_lang_grad=True)
     for k in [str(n) for n in g["grad_names"]]:
         assert maxdiff(eng.store.gview(k), g["grad:" + k]) < 3e-5, k
@@ -518,3 +518,56 @@ def check_inputs_embeds(g, ops, device="cpu", dtype=torch.float32, tol=5e-5, gto
 
 def test_inputs_embeds_vs_reference_fixture():
     check_inputs_embeds(load_golden("embeds_tiny"), FakeOps(torch.float32))
+
+
+@pytest.mark.parametrize("row_pad", [1, 8, 256])
+def test_packed_language_rows_equal_the_dense_path(monkeypatch, row_pad):
+    """Engine(pack_lang=True): the language side runs on the real tokens only (row list + per-example offsets, the packed count
+    rounded up to `row_pad` with zero rows) -- outputs of the real rows, losses and EVERY gradient equal the dense path's and
+    the reference fixture's; the [PAD] rows of language_output come back as zeros."""
+    monkeypatch.setattr(Engine, "ROW_PAD", row_pad)
+    g = load_golden("tiny_222")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "l_layers", "x_layers",
+                                                      "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    inp = golden_inputs(g)
+    B, L = inp["input_ids"].shape
+    V = inp["cluster_ids"].shape[1]
+    am = inp["attention_mask"].bool()
+    n_real = int(am.sum())
+    assert n_real < B * L                                        # the fixture has [PAD] positions
+    res = {}
+    for pack in (False, True):
+        store = ParamStore(cfg, "cpu", torch.float32, task="all")
+        store.load_named(sd)
+        eng = Engine(cfg, store, FakeOps(torch.float32), B, L, V, need_lang=True, pack_lang=pack)
+        eng.sync_compute_weights()
+        kw = dict(lang_rows=am.reshape(-1).nonzero().reshape(-1),
+                  lang_off=torch.cat([torch.zeros(1, dtype=torch.int64), am.sum(1).cumsum(0)]).to(torch.int32)) if pack else {}
+        eng.set_inputs(inp["input_ids"], inp["attention_mask"], inp["token_type_ids"], inp["visual_pos"],
+                       cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], obj_labels=inp["obj_labels"], **kw)
+        assert eng.packed == pack
+        if pack:
+            assert eng.ML == min(eng.MLc, (n_real + row_pad - 1) // row_pad * row_pad) and eng.MX == eng.MV + eng.ML
+            assert (eng.lrows[n_real:eng.ML] == -1).all()
+        lang, vis, pooled = eng.encoder_forward()
+        lang, vis, pooled = lang.clone(), vis.clone(), pooled.clone()
+        lh, vh = eng.hidden_states()
+        lh = [t.clone() for t in lh]
+        eng.store.grad.zero_()
+        eng.vis_mask_forward_backward()
+        # a gradient for the language output too (as the language tasks produce): d_lang random at real rows
+        gl = torch.randn(B * L, cfg.hidden_size, generator=torch.Generator().manual_seed(1)) * am.reshape(-1, 1)
+        eng.backward_from_outputs(d_lang=gl.view(B, L, -1), d_vis=None, d_pooled=torch.ones(B, cfg.hidden_size))
+        res[pack] = (lang, vis, pooled, lh, eng.losses.clone(), eng.store.grad.clone())
+    (l0, v0, p0, h0, ls0, g0), (l1, v1, p1, h1, ls1, g1) = res[False], res[True]
+    real = am.reshape(-1)
+    assert maxdiff(l0[real], l1[real]) < 2e-6 and maxdiff(v0, v1) < 2e-6 and maxdiff(p0, p1) < 2e-6
+    assert l1[~real].abs().max().item() == 0.0                   # [PAD] rows of language_output: zeros
+    assert maxdiff(l1.view(B * L, -1)[real], torch.from_numpy(g["lang"]).view(B * L, -1)[real]) < 5e-5
+    for a, b in zip(h0, h1):
+        assert maxdiff(a[real], b[real]) < 2e-6 and b[~real].abs().max().item() == 0.0
+    assert maxdiff(ls0, ls1) < 1e-6
+    assert maxdiff(g0, g1) < 5e-6, maxdiff(g0, g1)

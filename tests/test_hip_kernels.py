@@ -544,6 +544,77 @@ def test_sdpa_fwd_bwd(nq, nk, dh, masked, dtype, tr):
         ops.set_lds_transpose_read(1)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("nq,nk,pack_q,pack_k", [(20, 20, True, True), (20, 64, True, False), (64, 20, False, True), (7, 7, True, True)])
+def test_sdpa_packed_rows(nq, nk, pack_q, pack_k, p_drop, dtype):
+    """xl_sdpa_fwd / _bwd with q_rowoff / k_rowoff: the rows of an example on a packed side are [off[b], off[b+1]) (ragged
+    lengths 1..n, one of them 1, one of them n), the rows between off[B] and the padded row count are written as zeros, nothing
+    beyond is touched; dropout counters keep the capacity indexing.  Against the host restatement on the same packed buffers."""
+    g = torch.Generator().manual_seed(nq * 131 + nk + int(p_drop * 10))
+    B, H, dh = 5, 4, 64
+    d = H * dh
+    ld = 3 * d
+
+    def offsets(n, packed):
+        if not packed:
+            return None, B * n, B * n
+        lens = torch.randint(1, n + 1, (B,), generator=g)
+        lens[0], lens[1] = 1, n
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(torch.int32)
+        real = int(off[-1])
+        return off, real, (real + 31) // 32 * 32 + 32            # padded count: at least one whole pad row group
+
+    qoff, q_real, q_pad = offsets(nq, pack_q)
+    koff, k_real, k_pad = (qoff, q_real, q_pad) if (pack_q and pack_k and nq == nk) else offsets(nk, pack_k)
+    guard = 5                                                     # rows beyond the padded count: must stay untouched
+    qbuf = rnd(g, q_pad + guard, ld, dtype=dtype)
+    kbuf = qbuf if (pack_q and pack_k and nq == nk) else rnd(g, k_pad + guard, ld, dtype=dtype)
+    o = torch.full((q_pad + guard, d), 7.0, dtype=dtype)
+    lse = torch.zeros(B * H * nq)
+    scale = 1.0 / math.sqrt(dh)
+    fo, go = FakeOps(dtype), hip(dtype)
+    kw = dict(q_off=qoff, k_off=koff, q_pad=q_pad if pack_q else 0, k_pad=k_pad if pack_k else 0)
+    gkw = dict(kw, q_off=qoff.cuda() if qoff is not None else None, k_off=koff.cuda() if koff is not None else None)
+    co, cl = o.clone(), lse.clone()
+    fo.sdpa_fwd(qbuf, kbuf[:, d:], kbuf[:, 2 * d:], None, co, cl, B, H, nq, nk, dh, ld, ld, ld, d, scale, p_drop, 77, **kw)
+    gq, gk = qbuf.cuda(), kbuf.cuda()
+    go_, gl = o.cuda(), lse.cuda()
+    go.sdpa_fwd(gq, gk[:, d:], gk[:, 2 * d:], None, go_, gl, B, H, nq, nk, dh, ld, ld, ld, d, scale, p_drop, 77, **gkw)
+    torch.cuda.synchronize()
+    close(go_.cpu()[:q_real], co[:q_real], dtype, f"packed sdpa o {nq}x{nk}")
+    if pack_q:
+        assert go_.cpu()[q_real:q_pad].abs().max().item() == 0.0 and (go_.cpu()[q_pad:] == 7.0).all()
+        valid = torch.zeros(B, nq, dtype=torch.bool)
+        for b in range(B):
+            valid[b, :int(qoff[b + 1] - qoff[b])] = True
+        vmask = valid[:, None, :].expand(B, H, nq).reshape(-1)
+    else:
+        vmask = torch.ones(B * H * nq, dtype=torch.bool)
+    close(gl.cpu()[vmask], cl[vmask], torch.float32, "packed sdpa lse", f32_tol=1e-5 if dtype == torch.float32 else 2e-2)
+    dout = rnd(g, q_pad + guard, d, dtype=dtype)
+    cdq = torch.full((q_pad + guard, ld), 3.0, dtype=dtype)
+    cdk = cdq if kbuf is qbuf else torch.full((k_pad + guard, ld), 3.0, dtype=dtype)
+    gdq = cdq.cuda()
+    gdk = gdq if kbuf is qbuf else cdk.cuda()
+    cbg = rnd(g, 3 * d)
+    gbg, gws = cbg.cuda(), torch.zeros(go.workspace_floats(d), device="cuda")
+    fo.sdpa_bwd(qbuf, kbuf[:, d:], kbuf[:, 2 * d:], None, dout, cl, cdq, cdk[:, d:], cdk[:, 2 * d:], B, H, nq, nk, dh,
+                ld, ld, ld, d, ld, ld, ld, scale, p_drop, 77, bias_grad=cbg, **kw)
+    go.sdpa_bwd(gq, gk[:, d:], gk[:, 2 * d:], None, dout.cuda(), gl, gdq, gdk[:, d:], gdk[:, 2 * d:], B, H, nq, nk, dh,
+                ld, ld, ld, d, ld, ld, ld, scale, p_drop, 77, bias_grad=gbg, ws=gws, **gkw)
+    torch.cuda.synchronize()
+    close(gbg.cpu(), cbg, torch.float32, "packed sdpa bias grads", f32_tol=1e-4 if dtype == torch.float32 else 3e-2)
+    hq, hk = gdq.cpu(), gdk.cpu()
+    close(hq[:q_real, :d], cdq[:q_real, :d], dtype, "packed dq", bf16_tol=2.5e-2)
+    close(hk[:k_real, d:2 * d], cdk[:k_real, d:2 * d], dtype, "packed dk", bf16_tol=2.5e-2)
+    close(hk[:k_real, 2 * d:], cdk[:k_real, 2 * d:], dtype, "packed dv", bf16_tol=2.5e-2)
+    if pack_q:
+        assert hq[q_real:q_pad, :d].abs().max().item() == 0.0 and (hq[q_pad:, :d] == 3.0).all()
+    if pack_k:
+        assert hk[k_real:k_pad, d:].abs().max().item() == 0.0 and (hk[k_pad:, d:] == 3.0).all()
+
+
 # ---------------------------------------------------------------- head losses
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("K,padded", [(10000, True), (1024, True), (30522, True), (1003, True), (50, True), (50, False)])

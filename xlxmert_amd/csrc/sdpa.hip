@@ -16,6 +16,34 @@ namespace xl {
 
 constexpr int MAXN = 64;   // nq, nk <= 64 (8x8 grid, <=20 text tokens)
 
+// Packed (variable-length) sequences: with q_off / k_off (int32 [B+1], ascending) the rows of batch element b on that side
+// are [off[b], off[b+1]) of the matrix instead of [b*n, (b+1)*n) -- the language rows of a batch with the [PAD] positions
+// removed (a third of B x 20 at sentence lengths U{6..20}).  n stays the capacity (per-example maximum, <= 64): the
+// log-sum-exp buffer and the dropout counters keep their [B, H, n] indexing.  Rows [off[B], pad) -- the tail that rounds the
+// packed row count up to the GEMM row tile -- are written as ZEROS by the workgroups of the last batch element, so that every
+// consumer of the outputs (the out-projection, and above all the weight-gradient contractions over all rows) reads zeros there.
+struct VarLen {
+    const int* q_off; const int* k_off; int q_pad, k_pad;
+    __device__ __forceinline__ int row0_q(int b, int nq) const { return q_off != nullptr ? q_off[b] : b * nq; }
+    __device__ __forceinline__ int row0_k(int b, int nk) const { return k_off != nullptr ? k_off[b] : b * nk; }
+    __device__ __forceinline__ int len_q(int b, int nq) const { return q_off != nullptr ? min(nq, q_off[b + 1] - q_off[b]) : nq; }
+    __device__ __forceinline__ int len_k(int b, int nk) const { return k_off != nullptr ? min(nk, k_off[b + 1] - k_off[b]) : nk; }
+};
+template <typename T>
+__device__ __forceinline__ void zero_pad_rows(const int* off, int pad, int b, int B, T* __restrict__ out, int ld, int c0, int ncols,
+                                              int tid, int nthr) {
+    if (off == nullptr || b != B - 1) return;
+    const int r0 = off[B];
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int cpr = ncols / VEC;                       // (16-byte stores on the MFMA path; the generic kernels may step by element)
+    if (ncols % VEC == 0 && ld % VEC == 0 && c0 % VEC == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+        for (int i = tid; i < (pad - r0) * cpr; i += nthr)
+            *reinterpret_cast<uint4*>(out + (size_t)(r0 + i / cpr) * ld + c0 + (i % cpr) * VEC) = make_uint4(0, 0, 0, 0);
+    } else {
+        for (int i = tid; i < (pad - r0) * ncols; i += nthr) out[(size_t)(r0 + i / ncols) * ld + c0 + i % ncols] = (T)0;
+    }
+}
+
 // ================================================================== generic (fp32 math)
 template <typename T>
 __global__ __launch_bounds__(64) void sdpa_fwd_generic(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
@@ -23,37 +51,41 @@ __global__ __launch_bounds__(64) void sdpa_fwd_generic(const T* __restrict__ q, 
                                                        float* __restrict__ lse, int H, int nq, int nk, int dh,
                                                        int ldq, int ldk, int ldv, int ldo, float scale,
                                                        float p_drop, float inv_keep, uint64_t seed,
-                                                       const uint64_t* __restrict__ step_seed) {
+                                                       const uint64_t* __restrict__ step_seed, VarLen vl) {
     seed = with_step_seed(seed, step_seed);
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int qi = threadIdx.x;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    zero_pad_rows<T>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, o, ldo, h * dh, dh, threadIdx.x, 64);
     if (qi >= nq) return;
-    const T* qr = q + (size_t)(b * nq + qi) * ldq + h * dh;
+    const T* qr = q + (size_t)(q0 + qi) * ldq + h * dh;
     float qv[MAXN], s[MAXN], acc[MAXN];
     for (int d = 0; d < dh; ++d) { qv[d] = Elem<T>::ld(qr + d); acc[d] = 0.f; }
     float mx = -INFINITY;
     for (int j = 0; j < nk; ++j) {
-        const T* kr = k + (size_t)(b * nk + j) * ldk + h * dh;
+        const T* kr = k + (size_t)(k0 + j) * ldk + h * dh;
         float d0 = 0.f;
         for (int d = 0; d < dh; ++d) d0 = fmaf(qv[d], Elem<T>::ld(kr + d), d0);
         d0 *= scale;
-        if (key_mask && !key_mask[b * nk + j]) d0 = -INFINITY;
+        if (key_mask && !key_mask[b * nk_cap + j]) d0 = -INFINITY;
         s[j] = d0;
         mx = fmaxf(mx, d0);
     }
     if (mx == -INFINITY) mx = 0.f;
     float sum = 0.f;
     for (int j = 0; j < nk; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
-    const float inv = 1.0f / sum;
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;          // (an example without a single key: zero output, no NaN)
     for (int j = 0; j < nk; ++j) {
         float p = s[j] * inv;
-        if (p_drop > 0.f) p *= dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)j, p_drop, inv_keep);
-        const T* vr = v + (size_t)(b * nk + j) * ldv + h * dh;
+        if (p_drop > 0.f) p *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)j, p_drop, inv_keep);
+        const T* vr = v + (size_t)(k0 + j) * ldv + h * dh;
         for (int d = 0; d < dh; ++d) acc[d] = fmaf(p, Elem<T>::ld(vr + d), acc[d]);
     }
-    T* orow = o + (size_t)(b * nq + qi) * ldo + h * dh;
+    T* orow = o + (size_t)(q0 + qi) * ldo + h * dh;
     for (int d = 0; d < dh; ++d) Elem<T>::st(orow + d, acc[d]);
-    lse[(size_t)bh * nq + qi] = mx + logf(sum);
+    lse[(size_t)bh * nq_cap + qi] = mx + logf(sum);
 }
 
 template <typename T>
@@ -63,30 +95,36 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
                                                        T* __restrict__ dv, int H, int nq, int nk, int dh,
                                                        int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                                                        float scale, float p_drop, float inv_keep, uint64_t seed,
-                                                       const uint64_t* __restrict__ step_seed) {
+                                                       const uint64_t* __restrict__ step_seed, VarLen vl) {
     seed = with_step_seed(seed, step_seed);
     __shared__ float sdk[MAXN * MAXN];
     __shared__ float sdv[MAXN * MAXN];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int qi = threadIdx.x;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    zero_pad_rows<T>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, dq, lddq, h * dh, dh, threadIdx.x, 64);
+    zero_pad_rows<T>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dk, lddk, h * dh, dh, threadIdx.x, 64);
+    zero_pad_rows<T>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dv, lddv, h * dh, dh, threadIdx.x, 64);
     for (int i = threadIdx.x; i < nk * dh; i += 64) { sdk[i] = 0.f; sdv[i] = 0.f; }
     __syncthreads();
     if (qi < nq) {
-        const T* qr = q + (size_t)(b * nq + qi) * ldq + h * dh;
-        const T* dor = dout + (size_t)(b * nq + qi) * ldo + h * dh;
+        const T* qr = q + (size_t)(q0 + qi) * ldq + h * dh;
+        const T* dor = dout + (size_t)(q0 + qi) * ldo + h * dh;
         float qv[MAXN], dov[MAXN], dqv[MAXN], p[MAXN], dp[MAXN];
         for (int d = 0; d < dh; ++d) { qv[d] = Elem<T>::ld(qr + d); dov[d] = Elem<T>::ld(dor + d); dqv[d] = 0.f; }
-        const float l = lse[(size_t)bh * nq + qi];
+        const float l = lse[(size_t)bh * nq_cap + qi];
         float delta = 0.f;
         for (int j = 0; j < nk; ++j) {
-            const T* kr = k + (size_t)(b * nk + j) * ldk + h * dh;
-            const T* vr = v + (size_t)(b * nk + j) * ldv + h * dh;
+            const T* kr = k + (size_t)(k0 + j) * ldk + h * dh;
+            const T* vr = v + (size_t)(k0 + j) * ldv + h * dh;
             float s0 = 0.f, g = 0.f;
             for (int d = 0; d < dh; ++d) { s0 = fmaf(qv[d], Elem<T>::ld(kr + d), s0); g = fmaf(dov[d], Elem<T>::ld(vr + d), g); }
             float pj = expf(s0 * scale - l);
-            if (key_mask && !key_mask[b * nk + j]) pj = 0.f;
+            if (key_mask && !key_mask[b * nk_cap + j]) pj = 0.f;
             float msk = 1.f;
-            if (p_drop > 0.f) msk = dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)j, p_drop, inv_keep);
+            if (p_drop > 0.f) msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)j, p_drop, inv_keep);
             p[j] = pj;
             dp[j] = g * msk;                 // d(p) through the dropout mask
             delta += pj * dp[j];
@@ -95,20 +133,20 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
         }
         for (int j = 0; j < nk; ++j) {
             const float ds = p[j] * (dp[j] - delta) * scale;
-            const T* kr = k + (size_t)(b * nk + j) * ldk + h * dh;
+            const T* kr = k + (size_t)(k0 + j) * ldk + h * dh;
             for (int d = 0; d < dh; ++d) {
                 dqv[d] = fmaf(ds, Elem<T>::ld(kr + d), dqv[d]);
                 atomicAdd(&sdk[j * dh + d], ds * qv[d]);
             }
         }
-        T* dqr = dq + (size_t)(b * nq + qi) * lddq + h * dh;
+        T* dqr = dq + (size_t)(q0 + qi) * lddq + h * dh;
         for (int d = 0; d < dh; ++d) Elem<T>::st(dqr + d, dqv[d]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nk * dh; i += 64) {
         const int j = i / dh, d = i % dh;
-        Elem<T>::st(dk + (size_t)(b * nk + j) * lddk + h * dh + d, sdk[i]);
-        Elem<T>::st(dv + (size_t)(b * nk + j) * lddv + h * dh + d, sdv[i]);
+        Elem<T>::st(dk + (size_t)(k0 + j) * lddk + h * dh + d, sdk[i]);
+        Elem<T>::st(dv + (size_t)(k0 + j) * lddv + h * dh + d, sdv[i]);
     }
 }
 
@@ -231,15 +269,19 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
                                                     bf16_t* __restrict__ o, float* __restrict__ lse, int H, int nq, int nk,
                                                     int ldq, int ldk, int ldv, int ldo, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed,
-                                                    const uint64_t* __restrict__ step_seed) {
+                                                    const uint64_t* __restrict__ step_seed, VarLen vl) {
     if (DROP) seed = with_step_seed(seed, step_seed);
     // one wave per 32-query fragment (NQF waves share the staged V tile of the (batch, head) problem)
     __shared__ __attribute__((aligned(16))) uint8_t vt[NKF * 32 * Tile<DH>::PITCH];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const bf16_t* qb = q + (size_t)b * nq * ldq;
-    const bf16_t* kb = k + (size_t)b * nk * ldk;
-    const bf16_t* vb = v + (size_t)b * nk * ldv;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    zero_pad_rows<bf16_t>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, o, ldo, h * DH, DH, tid, NQF * 64);
+    const bf16_t* qb = q + (size_t)q0 * ldq;
+    const bf16_t* kb = k + (size_t)k0 * ldk;
+    const bf16_t* vb = v + (size_t)k0 * ldv;
     stage_tile<DH, NKF * 32>(vt, vb, ldv, nk, h * DH, tid, NQF * 64);
 
     // S^T[key][q] for this wave's queries
@@ -260,7 +302,7 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
         for (int r = 0; r < 16; ++r) {
             const int key = i * 32 + acc_row(r, hi);
             bool ok = key < nk;
-            if (key_mask != nullptr) ok = ok && key_mask[b * nk + min(key, nk - 1)] != 0;
+            if (key_mask != nullptr) ok = ok && key_mask[b * nk_cap + min(key, nk_cap - 1)] != 0;
             const float sv = ok ? st[i][r] * scale : -INFINITY;
             st[i][r] = sv;
             mx = fmaxf(mx, sv);
@@ -273,14 +315,14 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float e = __expf(st[i][r] - mx); st[i][r] = e; sum += e; }
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (hi == 0 && qi < nq) lse[(size_t)bh * nq + qi] = mx + __logf(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    if (hi == 0 && qi < nq) lse[(size_t)bh * nq_cap + qi] = mx + __logf(sum);
 #pragma unroll
     for (int i = 0; i < NKF; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float pv = st[i][r] * inv;
-            if (DROP) pv *= dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)(i * 32 + acc_row(r, hi)), p_drop, inv_keep);
+            if (DROP) pv *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)(i * 32 + acc_row(r, hi)), p_drop, inv_keep);
             st[i][r] = pv;
         }
     __syncthreads();                      // V tile staged by all waves
@@ -293,7 +335,7 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
             for (int u = 0; u < 2; ++u) oa = mfma32(tfrag<DH, TR>(vt, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), oa);
-        store_rows<DH>(oa, o + (size_t)b * nq * ldo, ldo, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
+        store_rows<DH>(oa, o + (size_t)q0 * ldo, ldo, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
     }
 }
 
@@ -305,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
                                                     int H, int nq, int nk, int ldq, int ldk, int ldv, int ldo,
                                                     int lddq, int lddk, int lddv, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed, float* __restrict__ cs_ws,
-                                                    const uint64_t* __restrict__ step_seed) {
+                                                    const uint64_t* __restrict__ step_seed, VarLen vl) {
     if (DROP) seed = with_step_seed(seed, step_seed);
     // K, Q, dO are needed both as row fragments and transposed: staged in LDS (unpadded swizzled tiles for DH = 64).  V is only
     // ever read as row fragments -- its own row by the lane that owns the key (phase 2), the same rows as the A operand of
@@ -328,10 +370,16 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
     // NW waves share the staged tiles of one (batch, head) problem; the 32-query fragments of phase 1 and the 32-key
     // fragments of phase 2 are independent tasks dealt round-robin to the waves.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const bf16_t* qb = q + (size_t)b * nq * ldq;
-    const bf16_t* kb = k + (size_t)b * nk * ldk;
-    const bf16_t* vb = v + (size_t)b * nk * ldv;
-    const bf16_t* dob = dout + (size_t)b * nq * ldo;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    zero_pad_rows<bf16_t>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, dq, lddq, h * DH, DH, tid, NW * 64);
+    zero_pad_rows<bf16_t>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dk, lddk, h * DH, DH, tid, NW * 64);
+    zero_pad_rows<bf16_t>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dv, lddv, h * DH, DH, tid, NW * 64);
+    const bf16_t* qb = q + (size_t)q0 * ldq;
+    const bf16_t* kb = k + (size_t)k0 * ldk;
+    const bf16_t* vb = v + (size_t)k0 * ldv;
+    const bf16_t* dob = dout + (size_t)q0 * ldo;
     bf16x8_t vf[NKF][DH / 16];                  // V row fragments: row i*32 + (lane & 31), features s*16 + (lane >> 5)*8 ..
 #pragma unroll
     for (int i = 0; i < NKF; ++i)
@@ -340,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
     stage_tile<DH, NKF * 32, SW>(tk, kb, ldk, nk, h * DH, tid, NW * 64);
     stage_tile<DH, NQF * 32, SW>(tq, qb, ldq, nq, h * DH, tid, NW * 64);
     stage_tile<DH, NQF * 32, SW>(tdo, dob, ldo, nq, h * DH, tid, NW * 64);
-    if (tid < MAXN) s_lse[tid] = tid < nq ? lse[(size_t)bh * nq + tid] : 0.f;
+    if (tid < MAXN) s_lse[tid] = tid < nq ? lse[(size_t)bh * nq_cap + tid] : 0.f;
     constexpr int ND = (DH + 31) / 32;
     __syncthreads();
 
@@ -369,12 +417,12 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
             for (int r = 0; r < 16; ++r) {
                 const int key = i * 32 + acc_row(r, hi);
                 bool ok = key < nk;
-                if (key_mask != nullptr) ok = ok && key_mask[b * nk + min(key, nk - 1)] != 0;
+                if (key_mask != nullptr) ok = ok && key_mask[b * nk_cap + min(key, nk_cap - 1)] != 0;
                 const float e = __expf(st[i][r] * scale - l);
                 const float pv = (ok && qi < nq) ? e : 0.f;
                 float dp = dpt[i][r];
                 if (DROP) {
-                    const float msk = dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)key, p_drop, inv_keep);
+                    const float msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)key, p_drop, inv_keep);
                     dp *= msk;
                     psum += pv * msk;
                 } else psum += pv;
@@ -406,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     qa = mfma32(tfrag<DH, TR, SW>(tk, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), qa);
-            store_rows<DH>(qa, dq + (size_t)b * nq * lddq, lddq, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
+            store_rows<DH>(qa, dq + (size_t)q0 * lddq, lddq, j * 32 + l31, nq, h * DH, id * 32, lane, 1.0f);
         }
     }
     __syncthreads();
@@ -430,7 +478,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
         }
         const int key = i * 32 + l31;
         bool kok = key < nk;
-        if (key_mask != nullptr) kok = kok && key_mask[b * nk + min(key, nk - 1)] != 0;
+        if (key_mask != nullptr) kok = kok && key_mask[b * nk_cap + min(key, nk_cap - 1)] != 0;
 #pragma unroll
         for (int j = 0; j < NQF; ++j)
 #pragma unroll
@@ -439,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
                 const float e = __expf(s2[j][r] * scale - s_lse[qi]);
                 const float pv = (kok && qi < nq) ? e : 0.f;
                 float msk = 1.f;
-                if (DROP) msk = dropout_scale(seed, (uint32_t)(bh * nq + qi), (uint32_t)key, p_drop, inv_keep);
+                if (DROP) msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)key, p_drop, inv_keep);
                 const float dp = dp2[j][r] * msk;
                 dp2[j][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
                 s2[j][r] = pv * msk;                              // P~[q][key]
@@ -464,8 +512,8 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
                     va = mfma32(tfrag<DH, TR, SW>(tdo, id * 32, j * 32 + u * 16, lane), acc_to_frag(s2[j], u), va);
                     ka = mfma32(tfrag<DH, TR, SW>(tq, id * 32, j * 32 + u * 16, lane), acc_to_frag(dp2[j], u), ka);
                 }
-            store_rows<DH>(va, dv + (size_t)b * nk * lddv, lddv, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
-            store_rows<DH>(ka, dk + (size_t)b * nk * lddk, lddk, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
+            store_rows<DH>(va, dv + (size_t)k0 * lddv, lddv, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
+            store_rows<DH>(ka, dk + (size_t)k0 * lddk, lddk, i * 32 + l31, nk, h * DH, id * 32, lane, 1.0f);
         }
     }
     if (cs_ws != nullptr) {
@@ -495,13 +543,14 @@ struct SdpaArgs {
     int B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float scale, p_drop, inv_keep; uint64_t seed;
     float* cs_ws;
+    VarLen vl;
 };
 
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_fwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(NQF * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk,
-                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed, ctx().step_seed);
+                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed, ctx().step_seed, a.vl);
 }
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
@@ -509,7 +558,7 @@ static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP, NW>), dim3(a.B * a.H), dim3(NW * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq,
                        (bf16_t*)a.dk, (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv,
-                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws, ctx().step_seed);
+                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws, ctx().step_seed, a.vl);
 }
 template <int DH, int NQF, int NKF>
 static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
@@ -563,8 +612,10 @@ using namespace xl;
 extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
                            void* o, float* lse, int B, int H, int nq, int nk, int dh,
                            int ldq, int ldk, int ldv, int ldo, float scale,
-                           float p_drop, uint64_t seed, int dtype, void* stream) {
+                           float p_drop, uint64_t seed, const int* q_rowoff, const int* k_rowoff, int q_rows_padded,
+                           int k_rows_padded, int dtype, void* stream) {
     SdpaArgs a = {};
+    a.vl = VarLen{q_rowoff, k_rowoff, q_rows_padded, k_rows_padded};
     a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.o = o; a.lse = lse;
     a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.dh = dh; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.scale = scale; a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
@@ -579,11 +630,11 @@ extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const ui
     } else if (dtype == XL_BF16) {
         hipLaunchKernelGGL((sdpa_fwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, key_mask, (bf16_t*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
-                           a.inv_keep, seed, ctx().step_seed);
+                           a.inv_keep, seed, ctx().step_seed, a.vl);
     } else {
         hipLaunchKernelGGL((sdpa_fwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, key_mask, (float*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop,
-                           a.inv_keep, seed, ctx().step_seed);
+                           a.inv_keep, seed, ctx().step_seed, a.vl);
     }
     XL_CHECK_LAUNCH();
     return XL_OK;
@@ -593,8 +644,10 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
                            const void* dout, const float* lse,
                            void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
                            int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
-                           float p_drop, uint64_t seed, float* bias_grad, float* workspace, int dtype, void* stream) {
+                           float p_drop, uint64_t seed, float* bias_grad, float* workspace,
+                           const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded, int dtype, void* stream) {
     SdpaArgs a = {};
+    a.vl = VarLen{q_rowoff, k_rowoff, q_rows_padded, k_rows_padded};
     a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.dout = dout; a.lse = const_cast<float*>(lse);
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.dh = dh; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -621,17 +674,18 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
     } else if (dtype == XL_BF16) {
         hipLaunchKernelGGL((sdpa_bwd_generic<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, key_mask, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, H, nq,
-                           nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, ctx().step_seed);
+                           nk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);
     } else {
         hipLaunchKernelGGL((sdpa_bwd_generic<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, key_mask, (const float*)dout, lse, (float*)dq, (float*)dk, (float*)dv, H, nq, nk,
-                           dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, ctx().step_seed);
+                           dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);
     }
     XL_CHECK_LAUNCH();
     if (bias_grad != nullptr) {          // no fused partials on this path: column sums of the stored gradients
-        int rc2 = xl_colsum(dq, bias_grad, B * nq, HD, lddq, workspace, dtype, stream);
-        if (rc2 == XL_OK) rc2 = xl_colsum(dk, bias_grad + HD, B * nk, HD, lddk, workspace ? workspace + 1365 * (size_t)HD : nullptr, dtype, stream);
-        if (rc2 == XL_OK) rc2 = xl_colsum(dv, bias_grad + 2 * HD, B * nk, HD, lddv, workspace ? workspace + 2730 * (size_t)HD : nullptr, dtype, stream);
+        const int rq = q_rowoff ? q_rows_padded : B * nq, rk = k_rowoff ? k_rows_padded : B * nk;      // (pad rows are zero)
+        int rc2 = xl_colsum(dq, bias_grad, rq, HD, lddq, workspace, dtype, stream);
+        if (rc2 == XL_OK) rc2 = xl_colsum(dk, bias_grad + HD, rk, HD, lddk, workspace ? workspace + 1365 * (size_t)HD : nullptr, dtype, stream);
+        if (rc2 == XL_OK) rc2 = xl_colsum(dv, bias_grad + 2 * HD, rk, HD, lddv, workspace ? workspace + 2730 * (size_t)HD : nullptr, dtype, stream);
         return rc2;
     }
     return XL_OK;

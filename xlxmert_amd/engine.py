@@ -61,31 +61,46 @@ def reserve_streams(device):
 
 
 class SelfAttBlock:
-    """LxmertSelfAttentionLayer (HF:304-316): y = LN(dense(attn(x,x,mask)) + x)."""
+    """LxmertSelfAttentionLayer (HF:304-316): y = LN(dense(attn(x,x,mask)) + x).  `masked` = language rows (key padding mask, or
+    -- packed language rows -- per-example row offsets instead: engine.Engine pack_lang)."""
 
     def __init__(self, eng, prefix, n_tok, masked, tag):
         self.e, self.n, self.masked, self.tag = eng, n_tok, masked, tag
         self.p = _Att(eng, prefix, "self")
-        self.M = eng.B * n_tok
+        Mc = eng.MLc if masked else eng.MV          # row capacity (the active row count of a packed language side varies per batch)
         d = eng.d
-        self.qkv = eng.act(self.M, 3 * d)
-        self.ctx = eng.act(self.M, d)
-        self.z = eng.act(self.M, d)
+        self.qkv = eng.act(Mc, 3 * d)
+        self.ctx = eng.act(Mc, d)
+        self.z = eng.act(Mc, d)
         self.lse = eng.f32(eng.B * eng.H * n_tok)
-        self.mean, self.rstd = eng.f32(self.M), eng.f32(self.M)
+        self.mean, self.rstd = eng.f32(Mc), eng.f32(Mc)
         self.site = eng.new_site(2)
+
+    @property
+    def M(self):
+        return self.e.ML if self.masked else self.e.MV
+
+    def _att_args(self):
+        """(key mask, packed-row keyword arguments) of this block's attention core"""
+        e = self.e
+        if not self.masked:
+            return e.vkmask, {}
+        if e.packed:
+            return None, dict(q_off=e.loff, k_off=e.loff, q_pad=e.ML, k_pad=e.ML)
+        return e.kmask, {}
 
     def fwd(self, x, y):
         e, p, d, M = self.e, self.p, self.e.d, self.M
         ops = e.ops
         ops.block = self.tag
-        ops.gemm(x, p.wqkv, self.qkv, p.bqkv, None, None, M, 3 * d, d, d, d, 3 * d)
-        km = e.kmask if self.masked else e.vkmask
-        ops.sdpa_fwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, self.ctx, self.lse, e.B, e.H, self.n, self.n,
-                     e.dh, 3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
-        ops.gemm(self.ctx, p.wo, self.z, p.bo, x, None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
+        qkv, ctx, z = self.qkv[:M], self.ctx[:M], self.z[:M]
+        ops.gemm(x, p.wqkv, qkv, p.bqkv, None, None, M, 3 * d, d, d, d, 3 * d)
+        km, vl = self._att_args()
+        ops.sdpa_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], km, ctx, self.lse, e.B, e.H, self.n, self.n,
+                     e.dh, 3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), **vl)
+        ops.gemm(ctx, p.wo, z, p.bo, x, None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
                  p_drop=e.p_hid, seed=e.seed(self.site + 1))
-        ops.layernorm_fwd(self.z, p.g, p.b, y, self.mean, self.rstd, M, d, e.eps)
+        ops.layernorm_fwd(z, p.g, p.b, y, self.mean, self.rstd, M, d, e.eps)
         self.x = x
 
     def bwd(self, dy, dx):
@@ -93,16 +108,17 @@ class SelfAttBlock:
         ops = e.ops
         ops.block = self.tag
         e.wgrad_sync()                  # the previous block's weight-gradient GEMMs still read the shared scratch
+        qkv, ctx, z = self.qkv[:M], self.ctx[:M], self.z[:M]
         dz = e.tmp("dz", M, d)
-        dzm = e.ln_bwd_dense(dy, self.z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo, M, d, self.site + 1)
-        e.wgrad_defer(dzm, self.ctx, p.gwo, d, d, M, d, d, d)
+        dzm = e.ln_bwd_dense(dy, z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo, M, d, self.site + 1)
+        e.wgrad_defer(dzm, ctx, p.gwo, d, d, M, d, d, d)
         dctx = e.tmp("dctx", M, d)
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         dqkv = e.tmp("dqkv", M, 3 * d)
-        km = e.kmask if self.masked else e.vkmask
-        ops.sdpa_bwd(self.qkv, self.qkv[:, d:], self.qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
+        km, vl = self._att_args()
+        ops.sdpa_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
-                     e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws)      # + d(b_q | b_k | b_v)
+                     e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws, **vl)      # + d(b_q | b_k | b_v)
         e.wgrad_defer(dqkv, self.x, p.gwqkv, 3 * d, d, M, 3 * d, d, d)
         e.wgrad_flush(pair=True)        # this layer's four weight gradients: launched together with the next layer's
         ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
@@ -110,10 +126,11 @@ class SelfAttBlock:
 
 
 class FFNBlock:
-    """LxmertIntermediate + LxmertOutput (HF:325-342): y = LN(W2 gelu(W1 x + b1) + b2 + x)."""
+    """LxmertIntermediate + LxmertOutput (HF:325-342): y = LN(W2 gelu(W1 x + b1) + b2 + x).  `lang`: language rows (their
+    active count follows the batch when the language rows are packed)."""
 
-    def __init__(self, eng, p_inter, p_out, M, tag):
-        self.e, self.M, self.tag = eng, M, tag
+    def __init__(self, eng, p_inter, p_out, lang, tag):
+        self.e, self.lang, self.tag = eng, lang, tag
         st = eng.store
         self.w1, self.gw1 = st.cview(p_inter + ".dense.weight"), st.gview(p_inter + ".dense.weight")
         self.b1, self.gb1 = st.view(p_inter + ".dense.bias"), st.gview(p_inter + ".dense.bias")
@@ -122,22 +139,28 @@ class FFNBlock:
         self.g, self.gg = st.view(p_out + ".LayerNorm.weight"), st.gview(p_out + ".LayerNorm.weight")
         self.b, self.gb = st.view(p_out + ".LayerNorm.bias"), st.gview(p_out + ".LayerNorm.bias")
         d, dff = eng.d, eng.dff
-        self.pre = eng.act(M, dff)
-        self.h = eng.act(M, dff)
-        self.z = eng.act(M, d)
-        self.mean, self.rstd = eng.f32(M), eng.f32(M)
+        Mc = eng.MLc if lang else eng.MV
+        self.pre = eng.act(Mc, dff)
+        self.h = eng.act(Mc, dff)
+        self.z = eng.act(Mc, d)
+        self.mean, self.rstd = eng.f32(Mc), eng.f32(Mc)
         self.site = eng.new_site(1)
+
+    @property
+    def M(self):
+        return self.e.ML if self.lang else self.e.MV
 
     def fwd(self, x, y):
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
         ops = e.ops
         ops.block = self.tag
+        pre, h, z = self.pre[:M], self.h[:M], self.z[:M]
         # self.pre holds gelu'(pre-activation): erf and exp(-x^2/2) are in registers in the forward epilogue anyway, and the
         # backward epilogue becomes a multiply (no second erf + exp per element of the [M, dff] gradient)
-        ops.gemm(x, self.w1, self.h, self.b1, None, self.pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU_DG)
-        ops.gemm(self.h, self.w2, self.z, self.b2, x, None, M, d, dff, dff, dff, d, ldr=d, epilogue=EPI_RESIDUAL,
+        ops.gemm(x, self.w1, h, self.b1, None, pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU_DG)
+        ops.gemm(h, self.w2, z, self.b2, x, None, M, d, dff, dff, dff, d, ldr=d, epilogue=EPI_RESIDUAL,
                  p_drop=e.p_hid, seed=e.seed(self.site))
-        ops.layernorm_fwd(self.z, self.g, self.b, y, self.mean, self.rstd, M, d, e.eps)
+        ops.layernorm_fwd(z, self.g, self.b, y, self.mean, self.rstd, M, d, e.eps)
         self.x = x
 
     def bwd(self, dy, dx):
@@ -145,14 +168,15 @@ class FFNBlock:
         ops = e.ops
         ops.block = self.tag
         e.wgrad_sync()
+        pre, h, z = self.pre[:M], self.h[:M], self.z[:M]
         # own scratch names: the two weight gradients registered here are launched together with the attention block's
         # (which runs next on this stream and flushes), so dz / dzm / dpre must outlive that block's scratch use
         dz = e.tmp("f_dz", M, d)
-        dzm = e.ln_bwd_dense(dy, self.z, self.g, self.mean, self.rstd, dz, self.gg, self.gb, self.gb2, M, d, self.site,
+        dzm = e.ln_bwd_dense(dy, z, self.g, self.mean, self.rstd, dz, self.gg, self.gb, self.gb2, M, d, self.site,
                              tmp_name="f_dzm")
-        e.wgrad_defer(dzm, self.h, self.gw2, d, dff, M, d, dff, dff)
+        e.wgrad_defer(dzm, h, self.gw2, d, dff, M, d, dff, dff)
         dpre = e.tmp("dpre", M, dff)
-        ops.gemm(dzm, self.w2, dpre, None, None, self.pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
+        ops.gemm(dzm, self.w2, dpre, None, None, pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
                  epilogue=EPI_MULAUX, colsum=self.gb1, ws=e.ws)      # d(b1) = column sums of dpre, in the same epilogue
         e.wgrad_defer(dpre, self.x, self.gw1, dff, d, M, dff, d, d)
         ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
@@ -161,7 +185,8 @@ class FFNBlock:
 
 class CrossAttBlock:
     """LxmertXLayer.cross_att (HF:377-398): ONE LxmertCrossAttentionLayer applied in both directions on the
-    pre-update inputs.  Rows = [language (B*L) ; visual (B*V)]."""
+    pre-update inputs.  Rows = [visual (B*V) ; language (ML)] -- the visual rows first, so that the language rows, whose count
+    follows the batch when they are packed (Engine pack_lang), are the tail of every buffer."""
 
     def __init__(self, eng, prefix, need_lang, tag, need_vis=True):
         """need_lang / need_vis: whether the language / visual rows of the OUTPUT are consumed.  The last cross layer of a
@@ -172,44 +197,56 @@ class CrossAttBlock:
         self.e, self.need_lang, self.need_vis, self.tag = eng, need_lang, need_vis, tag
         self.p = _Att(eng, prefix, "att")
         d = eng.d
-        self.qkv = eng.act(eng.MX, 3 * d)
-        self.ctx = eng.act(eng.MX, d)
-        self.z = eng.act(eng.MX, d)
+        self.qkv = eng.act(eng.MXc, 3 * d)
+        self.ctx = eng.act(eng.MXc, d)
+        self.z = eng.act(eng.MXc, d)
         self.lse_l = eng.f32(eng.B * eng.H * eng.L)
         self.lse_v = eng.f32(eng.B * eng.H * eng.V)
-        self.mean, self.rstd = eng.f32(eng.MX), eng.f32(eng.MX)
+        self.mean, self.rstd = eng.f32(eng.MXc), eng.f32(eng.MXc)
         self.site = eng.new_site(3)
+
+    def _lq(self):
+        """packed-row arguments of the attention with LANGUAGE queries over visual keys"""
+        e = self.e
+        return dict(q_off=e.loff, q_pad=e.ML) if e.packed else {}
+
+    def _lk(self):
+        """(key mask, packed-row arguments) of the attention with visual queries over LANGUAGE keys"""
+        e = self.e
+        return (None, dict(k_off=e.loff, k_pad=e.ML)) if e.packed else (e.kmask, {})
 
     def fwd(self, X, Y):
         e, p, d = self.e, self.p, self.e.d
         ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
         ops.block = self.tag
-        qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
+        L_, V_ = e.lr, e.vr
+        qkv_l, qkv_v = L_(self.qkv), V_(self.qkv)
         if not self.need_vis:
-            ops.gemm(X[:ML], p.wqkv, qkv_l, p.bqkv, None, None, ML, d, d, d, d, 3 * d)                    # Q of language rows
-            ops.gemm(X[ML:], p.wqkv[d:], qkv_v[:, d:], p.bqkv[d:], None, None, MV, 2 * d, d, d, d, 3 * d)  # K,V of visual rows
-            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
-                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
-            ops.gemm(self.ctx[:ML], p.wo, self.z[:ML], p.bo, X[:ML], None, ML, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
+            ops.gemm(L_(X), p.wqkv, qkv_l, p.bqkv, None, None, ML, d, d, d, d, 3 * d)                    # Q of language rows
+            ops.gemm(V_(X), p.wqkv[d:], qkv_v[:, d:], p.bqkv[d:], None, None, MV, 2 * d, d, d, d, 3 * d)  # K,V of visual rows
+            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, L_(self.ctx), self.lse_l, e.B, e.H, e.L, e.V, e.dh,
+                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), **self._lq())
+            ops.gemm(L_(self.ctx), p.wo, L_(self.z), p.bo, L_(X), None, ML, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
                      p_drop=e.p_hid, seed=e.seed(self.site + 2))
-            ops.layernorm_fwd(self.z[:ML], p.g, p.b, Y[:ML], self.mean[:ML], self.rstd[:ML], ML, d, e.eps)
+            ops.layernorm_fwd(L_(self.z), p.g, p.b, L_(Y), L_(self.mean), L_(self.rstd), ML, d, e.eps)
             self.X = X
             return
         if self.need_lang:
-            ops.gemm(X, p.wqkv, self.qkv, p.bqkv, None, None, MX, 3 * d, d, d, d, 3 * d)
+            ops.gemm(X[:MX], p.wqkv, self.qkv[:MX], p.bqkv, None, None, MX, 3 * d, d, d, d, 3 * d)
             # language queries over visual keys/values (no mask: visual_attention_mask is None in every caller)
-            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, self.ctx[:ML], self.lse_l, e.B, e.H, e.L, e.V, e.dh,
-                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site))
+            ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, L_(self.ctx), self.lse_l, e.B, e.H, e.L, e.V, e.dh,
+                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), **self._lq())
         else:
-            ops.gemm(X[ML:], p.wqkv, qkv_v, p.bqkv, None, None, MV, d, d, d, d, 3 * d)                    # Q of visual rows
-            ops.gemm(X[:ML], p.wqkv[d:], qkv_l[:, d:], p.bqkv[d:], None, None, ML, 2 * d, d, d, d, 3 * d)  # K,V of language rows
+            ops.gemm(V_(X), p.wqkv, qkv_v, p.bqkv, None, None, MV, d, d, d, d, 3 * d)                    # Q of visual rows
+            ops.gemm(L_(X), p.wqkv[d:], qkv_l[:, d:], p.bqkv[d:], None, None, ML, 2 * d, d, d, d, 3 * d)  # K,V of language rows
         # visual queries over language keys/values, padded language keys excluded
-        ops.sdpa_fwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], e.kmask, self.ctx[ML:], self.lse_v, e.B, e.H, e.V, e.L, e.dh,
-                     3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site + 1))
-        r0, M = (0, MX) if self.need_lang else (ML, MV)
-        ops.gemm(self.ctx[r0:], p.wo, self.z[r0:], p.bo, X[r0:], None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
+        km, vl = self._lk()
+        ops.sdpa_fwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], km, V_(self.ctx), self.lse_v, e.B, e.H, e.V, e.L, e.dh,
+                     3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site + 1), **vl)
+        M = MX if self.need_lang else MV           # rows [0, M): visual rows, then (both directions) the language rows
+        ops.gemm(self.ctx[:M], p.wo, self.z[:M], p.bo, X[:M], None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
                  p_drop=e.p_hid, seed=e.seed(self.site + 2))
-        ops.layernorm_fwd(self.z[r0:], p.g, p.b, Y[r0:], self.mean[r0:], self.rstd[r0:], M, d, e.eps)
+        ops.layernorm_fwd(self.z[:M], p.g, p.b, Y[:M], self.mean[:M], self.rstd[:M], M, d, e.eps)
         self.X = X
 
     def bwd(self, dY, dX):
@@ -219,59 +256,61 @@ class CrossAttBlock:
         e.wgrad_sync()
         if not self.need_vis:
             return self._bwd_lang_only(dY, dX)
-        r0, M = (0, MX) if self.need_lang else (ML, MV)
+        L_, V_ = e.lr, e.vr
+        M = MX if self.need_lang else MV
         dz_full = e.tmp("dz", MX, d)
-        dz = dz_full[r0:]
-        dzm = e.ln_bwd_dense(dY[r0:], self.z[r0:], p.g, self.mean[r0:], self.rstd[r0:], dz, p.gg, p.gb, p.gbo, M, d,
+        dz = dz_full[:M]
+        dzm = e.ln_bwd_dense(dY[:M], self.z[:M], p.g, self.mean[:M], self.rstd[:M], dz, p.gg, p.gb, p.gbo, M, d,
                              self.site + 2)
-        e.wgrad_defer(dzm, self.ctx[r0:], p.gwo, d, d, M, d, d, d)
+        e.wgrad_defer(dzm, self.ctx[:M], p.gwo, d, d, M, d, d, d)
         dctx_full = e.tmp("dctx", MX, d)
-        dctx = dctx_full[r0:]
+        dctx = dctx_full[:M]
         ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         dqkv = e.tmp("dqkv", MX, 3 * d)
-        dqkv_l, dqkv_v = dqkv[:ML], dqkv[ML:]
-        qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
-        ops.sdpa_bwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], e.kmask, dctx_full[ML:], self.lse_v, dqkv_v, dqkv_l[:, d:],
+        dqkv_l, dqkv_v = L_(dqkv), V_(dqkv)
+        qkv_l, qkv_v = L_(self.qkv), V_(self.qkv)
+        km, vl = self._lk()
+        ops.sdpa_bwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], km, V_(dctx_full), self.lse_v, dqkv_v, dqkv_l[:, d:],
                      dqkv_l[:, 2 * d:], e.B, e.H, e.V, e.L, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
-                     e.p_attn, e.seed(self.site + 1), bias_grad=p.gbqkv, ws=e.ws)
+                     e.p_attn, e.seed(self.site + 1), bias_grad=p.gbqkv, ws=e.ws, **vl)
         X = self.X
         if self.need_lang:
-            ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, dctx_full[:ML], self.lse_l, dqkv_l, dqkv_v[:, d:],
+            ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, L_(dctx_full), self.lse_l, dqkv_l, dqkv_v[:, d:],
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
-                         e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws)      # both directions share the projections
-            e.wgrad_defer(dqkv, X, p.gwqkv, 3 * d, d, MX, 3 * d, d, d)
+                         e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws, **self._lq())      # both directions share the projections
+            e.wgrad_defer(dqkv, X[:MX], p.gwqkv, 3 * d, d, MX, 3 * d, d, d)
             e.wgrad_flush()
-            ops.gemm(dqkv, p.wqkv, dX, None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+            ops.gemm(dqkv, p.wqkv, dX[:MX], None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
         else:
-            e.wgrad_defer(dqkv_v, X[ML:], p.gwqkv, d, d, MV, 3 * d, d, d)
-            e.wgrad_defer(dqkv_l[:, d:], X[:ML], p.gwqkv[d:], 2 * d, d, ML, 3 * d, d, d)
+            e.wgrad_defer(dqkv_v, V_(X), p.gwqkv, d, d, MV, 3 * d, d, d)
+            e.wgrad_defer(dqkv_l[:, d:], L_(X), p.gwqkv[d:], 2 * d, d, ML, 3 * d, d, d)
             e.wgrad_flush()
-            ops.gemm(dqkv_v, p.wqkv, dX[ML:], None, dz, None, MV, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+            ops.gemm(dqkv_v, p.wqkv, V_(dX), None, dz, None, MV, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
                      epilogue=EPI_RESIDUAL)
-            ops.gemm(dqkv_l[:, d:], p.wqkv[d:], dX[:ML], None, None, None, ML, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
-
+            ops.gemm(dqkv_l[:, d:], p.wqkv[d:], L_(dX), None, None, None, ML, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
 
     def _bwd_lang_only(self, dY, dX):
         e, p, d = self.e, self.p, self.e.d
         ops, ML, MV, MX = e.ops, e.ML, e.MV, e.MX
+        L_, V_ = e.lr, e.vr
         X = self.X
-        dz = e.tmp("dz", MX, d)[:ML]
-        dzm = e.ln_bwd_dense(dY[:ML], self.z[:ML], p.g, self.mean[:ML], self.rstd[:ML], dz, p.gg, p.gb, p.gbo, ML, d, self.site + 2)
-        e.wgrad_defer(dzm, self.ctx[:ML], p.gwo, d, d, ML, d, d, d)
-        dctx = e.tmp("dctx", MX, d)[:ML]
+        dz = L_(e.tmp("dz", MX, d))
+        dzm = e.ln_bwd_dense(L_(dY), L_(self.z), p.g, L_(self.mean), L_(self.rstd), dz, p.gg, p.gb, p.gbo, ML, d, self.site + 2)
+        e.wgrad_defer(dzm, L_(self.ctx), p.gwo, d, d, ML, d, d, d)
+        dctx = L_(e.tmp("dctx", MX, d))
         ops.gemm(dzm, p.wo, dctx, None, None, None, ML, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
         dqkv = e.tmp("dqkv", MX, 3 * d)
-        dqkv_l, dqkv_v = dqkv[:ML], dqkv[ML:]
-        qkv_l, qkv_v = self.qkv[:ML], self.qkv[ML:]
+        dqkv_l, dqkv_v = L_(dqkv), V_(dqkv)
+        qkv_l, qkv_v = L_(self.qkv), V_(self.qkv)
         ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, dctx, self.lse_l, dqkv_l, dqkv_v[:, d:], dqkv_v[:, 2 * d:],
                      e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale, e.p_attn, e.seed(self.site),
-                     bias_grad=p.gbqkv, ws=e.ws)
-        e.wgrad_defer(dqkv_l, X[:ML], p.gwqkv, d, d, ML, 3 * d, d, d)
-        e.wgrad_defer(dqkv_v[:, d:], X[ML:], p.gwqkv[d:], 2 * d, d, MV, 3 * d, d, d)
+                     bias_grad=p.gbqkv, ws=e.ws, **self._lq())
+        e.wgrad_defer(dqkv_l, L_(X), p.gwqkv, d, d, ML, 3 * d, d, d)
+        e.wgrad_defer(dqkv_v[:, d:], V_(X), p.gwqkv[d:], 2 * d, d, MV, 3 * d, d, d)
         e.wgrad_flush()
-        ops.gemm(dqkv_l, p.wqkv, dX[:ML], None, dz, None, ML, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0, epilogue=EPI_RESIDUAL)
-        ops.gemm(dqkv_v[:, d:], p.wqkv[d:], dX[ML:], None, None, None, MV, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
+        ops.gemm(dqkv_l, p.wqkv, L_(dX), None, dz, None, ML, d, d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0, epilogue=EPI_RESIDUAL)
+        ops.gemm(dqkv_v[:, d:], p.wqkv[d:], V_(dX), None, None, None, MV, d, 2 * d, 3 * d, d, d, a_kmajor=1, b_kmajor=0)
 
 
 class AnswerHead:
@@ -369,7 +408,7 @@ class LangHeads:
 
     def __init__(self, eng):
         self.e = eng
-        st, d, ML, B = eng.store, eng.d, eng.ML, eng.B
+        st, d, ML, B = eng.store, eng.d, eng.MLd, eng.B
         self.has_mlm = "cls.predictions.bias" in st.index and eng.task in ("word_mask", "all")
         self.has_rel = "cls.seq_relationship.weight" in st.index and eng.task in ("matched", "all")
         self.loss = eng.f32(2)                  # [lm_loss, matched_loss]
@@ -409,17 +448,17 @@ class LangHeads:
     def set_rows(self, word_rows):
         """word_rows: flat indices b*L+l of the labelled positions (host tensor / list: its length is the launch size), or None."""
         self.n_rows = 0
-        if word_rows is not None and 0 < len(word_rows) < self.e.ML:
+        if word_rows is not None and 0 < len(word_rows) < self.e.MLd:
             idx = torch.as_tensor(word_rows, dtype=torch.int64)
             n = int(idx.numel())
-            self.n_rows = self.e.pad_rows(self.rows, idx, n, self.e.ML)
+            self.n_rows = self.e.pad_rows(self.rows, idx, n, self.e.MLd)
 
     def mlm_fwd(self, lang):
         e, d = self.e, self.e.d
         ops, st = e.ops, e.store
-        M = self.n_rows if self.n_rows else e.ML
+        M = self.n_rows if self.n_rows else e.MLd
         if self.n_rows:
-            self.x = e.tmp("mlm_x", e.ML, d)[:M]
+            self.x = e.tmp("mlm_x", e.MLd, d)[:M]
             ops.gather_rows(lang, self.rows, self.x, M, d, d, d)
         else:
             self.x = lang
@@ -439,7 +478,7 @@ class LangHeads:
         """lm_loss and d(scores) (nothing of the parameter gradients is touched)."""
         e, Vn, Vp = self.e, self.Vn, self.Vp
         ops = e.ops
-        M = self.n_rows if self.n_rows else e.ML
+        M = self.n_rows if self.n_rows else e.MLd
         ops.zero(self.loss[0:1])
         ops.mask_counts(self.word_labels, e.kmask, self.counts, self.dummy, e.B, e.L)
         labels = self.word_labels
@@ -453,21 +492,21 @@ class LangHeads:
     def mlm_bwd(self, d_lang):
         e, d, Vn, Vp = self.e, self.e.d, self.Vn, self.Vp
         ops, st = e.ops, e.store
-        M = self.n_rows if self.n_rows else e.ML
+        M = self.n_rows if self.n_rows else e.MLd
         emb = "bert.embeddings.word_embeddings.weight"
         ops.colsum(self.dscores, self._gvb_pad(), M, Vp, Vp, ws=e.ws)
         e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, M, Vp, d, d)              # tied decoder: d(word embeddings)
-        dhn = e.tmp("dctx", e.ML, d)
+        dhn = e.tmp("dctx", e.MLd, d)
         ops.gemm(self.dscores, st.cview(emb), dhn, None, None, None, M, d, Vn, Vp, d, d, a_kmajor=1, b_kmajor=0)
-        dh = e.tmp("dz", e.ML, d)
+        dh = e.tmp("dz", e.MLd, d)
         ops.layernorm_bwd(dhn, self.h, self.g, self.mean, self.rstd, dh, self.gg, self.gb, None, M, d, ws=e.ws)
-        dpre = e.tmp("dzm", e.ML, d)
+        dpre = e.tmp("dzm", e.MLd, d)
         ops.gelu_bwd(dh, self.pre, dpre, M * d)
         ops.colsum(dpre, self.gbt, M, d, d, ws=e.ws)
         e.wgrad_defer(dpre, self.x, self.gwt, d, d, M, d, d, d)
         e.wgrad_flush()
         if self.n_rows:
-            dx = e.tmp("mlm_dx", e.ML, d)[:M]
+            dx = e.tmp("mlm_dx", e.MLd, d)[:M]
             ops.gemm(dpre, self.wt, dx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
             ops.scatter_rows(dx, self.rows, d_lang, M, d, d, d)
         else:
@@ -520,7 +559,16 @@ class Engine:
     """Static-shape forward/backward program.  `need_lang`: whether lang/pooled outputs of the last cross layer are
     consumed (False for the masked-visual-token step)."""
 
-    def __init__(self, cfg, store, ops, B, L, V, need_lang=False, train_dropout=False, two_streams=True):
+    def __init__(self, cfg, store, ops, B, L, V, need_lang=False, train_dropout=False, two_streams=True, pack_lang=None):
+        """pack_lang: run the language side on the REAL tokens only.  The attention mask (input_ids > 0, ref lxmert_pretrain.py:206)
+        removes the [PAD] positions as keys everywhere (HF:238-266) and no loss or head reads a [PAD] position's output, so every
+        row the reference computes for them -- a third of the B x 20 language rows at sentence lengths U{6..20} -- is dead work:
+        after the embeddings the language rows are gathered into a packed [sum of lengths, d] matrix (row list + per-example
+        offsets from the data loader, rounded up to the GEMM row tile with zero rows), every language-side contraction /
+        LayerNorm runs over those rows, the attention cores address an example's rows through the offsets (xl_sdpa_* q_rowoff /
+        k_rowoff), and the final language output is scattered back to [B, L, d] with zero rows at the [PAD] positions (the
+        reference leaves don't-care values there).  Exact for the real rows and for every gradient.  Default: env XL_PACK_LANG
+        (on); the nn.Module surface passes False where it hands out per-layer hidden states."""
         assert cfg.l_layers >= 1 and cfg.r_layers >= 1 and cfg.x_layers >= 1
         assert L <= 64 and V <= 64, "attention kernels hold a whole (batch, head) problem on chip: n <= 64"
         self.cfg, self.store, self.ops = cfg, store, ops
@@ -529,8 +577,13 @@ class Engine:
         self.d, self.dff, self.F, self.K = cfg.hidden_size, cfg.intermediate_size, cfg.visual_feat_dim, cfg.num_clusters
         self.H, self.dh = cfg.num_attention_heads, cfg.head_dim
         self.P = cfg.visual_pos_dim
-        self.ML, self.MV = B * L, B * V
-        self.MX = self.ML + self.MV
+        self.pack_lang = (os.environ.get("XL_PACK_LANG", "1") != "0") if pack_lang is None else bool(pack_lang)
+        self.packed = False                 # this batch runs packed (set_inputs: pack_lang and a usable attention mask)
+        self.MLd, self.MV = B * L, B * V    # dense language rows / visual rows
+        # language row CAPACITY of every buffer (a packed row count is rounded up to the row tile) and the ACTIVE count
+        self.MLc = (self.MLd + self.ROW_PAD - 1) // self.ROW_PAD * self.ROW_PAD if self.pack_lang else self.MLd
+        self.ML = self.MLd
+        self.MXc = self.MV + self.MLc
         self.scale = 1.0 / math.sqrt(self.dh)
         self.eps = cfg.layer_norm_eps
         self.need_lang = need_lang
@@ -554,10 +607,10 @@ class Engine:
         # ---- blocks
         e_ = "bert.encoder"
         self.lang_layers = [(SelfAttBlock(self, f"{e_}.layer.{i}.attention", L, True, f"l{i}"),
-                             FFNBlock(self, f"{e_}.layer.{i}.intermediate", f"{e_}.layer.{i}.output", self.ML, f"l{i}"))
+                             FFNBlock(self, f"{e_}.layer.{i}.intermediate", f"{e_}.layer.{i}.output", True, f"l{i}"))
                             for i in range(cfg.l_layers)]
         self.vis_layers = [(SelfAttBlock(self, f"{e_}.r_layers.{i}.attention", V, False, f"r{i}"),
-                            FFNBlock(self, f"{e_}.r_layers.{i}.intermediate", f"{e_}.r_layers.{i}.output", self.MV, f"r{i}"))
+                            FFNBlock(self, f"{e_}.r_layers.{i}.intermediate", f"{e_}.r_layers.{i}.output", False, f"r{i}"))
                            for i in range(cfg.r_layers)]
         self.x_layers = []
         task0 = getattr(store, "task", "vis_mask")
@@ -570,25 +623,30 @@ class Engine:
                    "vis_on": vis_on}
             if vis_on:
                 blk["sa_v"] = SelfAttBlock(self, p + ".visn_self_att", V, False, f"x{i}v")
-                blk["ffn_v"] = FFNBlock(self, p + ".visn_inter", p + ".visn_output", self.MV, f"x{i}v")
+                blk["ffn_v"] = FFNBlock(self, p + ".visn_inter", p + ".visn_output", False, f"x{i}v")
             if lang_on:
                 blk["sa_l"] = SelfAttBlock(self, p + ".lang_self_att", L, True, f"x{i}l")
-                blk["ffn_l"] = FFNBlock(self, p + ".lang_inter", p + ".lang_output", self.ML, f"x{i}l")
+                blk["ffn_l"] = FFNBlock(self, p + ".lang_inter", p + ".lang_output", True, f"x{i}l")
             self.x_layers.append(blk)
         # ---- activations of the chain
-        self.emb_y, self.emb_pre = self.act(self.ML, d), self.act(self.ML, d)
-        self.emb_mean, self.emb_rstd = self.f32(self.ML), self.f32(self.ML)
+        self.emb_y, self.emb_pre = self.act(self.MLd, d), self.act(self.MLd, d)        # embeddings: dense [B*L] rows
+        self.emb_mean, self.emb_rstd = self.f32(self.MLd), self.f32(self.MLd)
+        self.emb_p = self.act(self.MLc, d) if self.pack_lang else None                 # ... gathered to the packed rows
+        self.lrows = torch.full((self.MLc,), -1, dtype=torch.int32, device=self.dev)   # b*L+l of packed row r (-1: pad tail)
+        self.loff = torch.zeros(B + 1, dtype=torch.int32, device=self.dev)             # first packed row of example b
+        self.lang_pad = self.act(self.MLd, d) if self.pack_lang else None              # final language output, dense layout
+        self.glang_pad = self.act(self.MLd, d) if self.pack_lang else None             # its gradient, dense layout
         self.feats = self.act(self.MV, self.F)
         self.xv = self.act(self.MV, d)
         self.vis0 = self.act(self.MV, d)
         self.vn_stats = [self.f32(self.MV) for _ in range(4)]
-        self.lang_mid = [self.act(self.ML, d) for _ in range(cfg.l_layers)]          # attention-block outputs
-        self.lang_out = [self.act(self.ML, d) for _ in range(cfg.l_layers - 1)]
+        self.lang_mid = [self.act(self.MLc, d) for _ in range(cfg.l_layers)]          # attention-block outputs
+        self.lang_out = [self.act(self.MLc, d) for _ in range(cfg.l_layers - 1)]
         self.vis_mid = [self.act(self.MV, d) for _ in range(cfg.r_layers)]
         self.vis_out = [self.act(self.MV, d) for _ in range(cfg.r_layers - 1)]
-        self.X = [self.act(self.MX, d) for _ in range(cfg.x_layers + 1)]             # [lang ; vis] per cross layer
-        self.XY = [self.act(self.MX, d) for _ in range(cfg.x_layers)]                # cross-attention outputs
-        self.XS = [self.act(self.MX, d) for _ in range(cfg.x_layers)]                # self-attention outputs
+        self.X = [self.act(self.MXc, d) for _ in range(cfg.x_layers + 1)]            # [vis ; lang] per cross layer
+        self.XY = [self.act(self.MXc, d) for _ in range(cfg.x_layers)]               # cross-attention outputs
+        self.XS = [self.act(self.MXc, d) for _ in range(cfg.x_layers)]               # self-attention outputs
         self.pooled = self.act(B, d)
         self.kmask = torch.ones(B, L, dtype=torch.uint8, device=self.dev)
         self.vkmask, self._vkmask_buf = None, None        # visual_attention_mask (HF:760-770): None in every reference caller
@@ -634,7 +692,7 @@ class Engine:
         self.mf_tmp = self.f32(d)
         self.mf_tmp_c = self.act(1, d)
         # ---- activation-gradient ping-pong
-        self.GA, self.GB = self.act(self.MX, d), self.act(self.MX, d)
+        self.GA, self.GB = self.act(self.MXc, d), self.act(self.MXc, d)
         # two-stage column reductions: one workspace per stream (language / visual work runs concurrently)
         # (the second stages are deferred and combined per layer -- flush_reductions -- so every producer between two flushes
         # gets a workspace region of its own: _WS_REGIONS per stream)
@@ -661,6 +719,19 @@ class Engine:
             streams += [torch.cuda.current_stream()] + ([self.side] if self.side is not None else [])
             for s_ in streams:
                 self._slab_ws.append(ops.gemm_workspace(256, s_))
+
+    # ------------------------------------------------------------ row layout: [visual (MV) ; language (ML active of MLc)]
+    @property
+    def MX(self):
+        return self.MV + self.ML
+
+    def vr(self, T):
+        """visual rows of a [vis ; lang] buffer"""
+        return T[:self.MV]
+
+    def lr(self, T):
+        """active language rows of a [vis ; lang] buffer"""
+        return T[self.MV:self.MV + self.ML]
 
     # ------------------------------------------------------------ memory helpers
     def act(self, *shape):
@@ -790,7 +861,7 @@ class Engine:
         with the layers whose weight gradients are held for a paired launch (wgrad_flush)."""
         key = (name, N, self._tag, self._gen[self._tag])
         if key not in self._tmp:
-            self._tmp[key] = torch.zeros(self.MX, N, dtype=self.cdtype, device=self.dev)
+            self._tmp[key] = torch.zeros(self.MXc, N, dtype=self.cdtype, device=self.dev)
         return self._tmp[key][:M]
 
     ROW_PAD = 256
@@ -886,12 +957,15 @@ class Engine:
     # ------------------------------------------------------------ inputs
     def set_inputs(self, input_ids, attention_mask=None, token_type_ids=None, visual_pos=None, cluster_ids=None,
                    vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None, feat_labels=None,
-                   visual_attention_mask=None, inputs_embeds=None):
+                   visual_attention_mask=None, inputs_embeds=None, lang_rows=None, lang_off=None):
         """masked_rows (optional): ascending ids b*V+v of the masked positions, i.e. vis_mask.flatten().nonzero(), as the data
         loader can compute them on the CPU next to vis_mask itself; given, the step needs no host <-> device round trip.
         feat_labels (optional, [B,V,F]): regression targets of the feature loss (label_dict['feat_labels'], ref
         lxrt/modeling.py:275; the trainer passes the real grid features, lxmert_pretrain.py:177-179); without them the
-        feature loss regresses onto the centroid of each position's cluster id."""
+        feature loss regresses onto the centroid of each position's cluster id.
+        lang_rows / lang_off (optional, pack_lang): ascending ids b*L+l of the real tokens, i.e. attention_mask.flatten().nonzero(),
+        and the [B+1] prefix sums of the per-example token counts -- computed by the data loader next to the mask (given, the
+        step needs no host <-> device round trip; every example must have at least one real token)."""
         B, L, V = self.B, self.L, self.V
         # inputs_embeds [B, L, d] instead of input_ids (HF:699,731-744,773 -> HF:191-214: they replace the word-embedding
         # lookup; position / token-type embeddings, LayerNorm and dropout still apply): staged as a per-call "word table" of
@@ -912,6 +986,20 @@ class Engine:
             self.kmask.fill_(1)
         else:
             self.kmask.copy_(attention_mask.reshape(B, L) != 0, non_blocking=True)
+        self.packed, self.ML = False, self.MLd
+        if self.pack_lang and attention_mask is not None:
+            if lang_rows is None:                   # no row list from the loader: one device round trip
+                m = attention_mask.reshape(B, L) != 0
+                lang_rows = m.reshape(-1).nonzero().reshape(-1)
+                cnt = m.sum(1)
+                assert int(cnt.min().item()) >= 1, "an example without a single real token"
+                lang_off = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)])
+            idx = lang_rows.reshape(-1)
+            n = int(idx.numel())
+            assert 0 < n <= self.MLd and lang_off is not None and int(lang_off.numel()) == B + 1
+            self.ML = self.pad_rows(self.lrows, idx, n, self.MLc)
+            self.loff.copy_(lang_off.reshape(-1), non_blocking=True)
+            self.packed = True
         if token_type_ids is None:
             self.tt.zero_()
         else:
@@ -954,14 +1042,25 @@ class Engine:
         every language layer then of every cross layer / of every visual layer then of every cross layer -- views of the
         activation plan (valid until the next forward)."""
         cfg, ML = self.cfg, self.ML
-        lang = [self.lang_out[i] if i < cfg.l_layers - 1 else self.X[0][:ML] for i in range(cfg.l_layers)]
-        vis = [self.vis_out[i] if i < cfg.r_layers - 1 else self.X[0][ML:] for i in range(cfg.r_layers)]
+        lang = [self.lang_out[i][:ML] if i < cfg.l_layers - 1 else self.lr(self.X[0]) for i in range(cfg.l_layers)]
+        vis = [self.vis_out[i] if i < cfg.r_layers - 1 else self.vr(self.X[0]) for i in range(cfg.r_layers)]
         for i, blk in enumerate(self.x_layers):
             if blk["lang_on"]:
-                lang.append(self.X[i + 1][:ML])
+                lang.append(self.lr(self.X[i + 1]))
             if blk["vis_on"]:
-                vis.append(self.X[i + 1][ML:])
+                vis.append(self.vr(self.X[i + 1]))
+        if self.packed:                 # packed language rows -> the dense [B*L, d] layout, zero rows at the [PAD] positions
+            lang = [self._dense_lang(t) for t in lang]
         return lang, vis
+
+    def _dense_lang(self, t, out=None):
+        """packed language rows -> dense [B*L, d] (zero rows where the attention mask is 0)"""
+        if out is None:
+            out = torch.zeros(self.MLd, self.d, dtype=self.cdtype, device=self.dev)
+        else:
+            self.ops.zero(out)
+        self.ops.scatter_rows(t, self.lrows, out, self.ML, self.d, self.d, self.d)
+        return out
 
     # ------------------------------------------------------------ forward
     def encoder_forward(self, want_pooled=True):
@@ -970,7 +1069,7 @@ class Engine:
 
     def _language_stack_forward(self):
         """embeddings + l_layers self-attention layers (HF:516-521); leaves the language rows of the first cross layer's input
-        in X[0][:ML]."""
+        in the language rows of X[0]."""
         cfg, st, ops, d, ML = self.cfg, self.store, self.ops, self.d, self.ML
         X0 = self.X[0]
         e = "bert.embeddings"
@@ -982,13 +1081,17 @@ class Engine:
                          st.view(e + ".LayerNorm.bias"), self.emb_y, self.emb_pre, self.emb_mean, self.emb_rstd,
                          self.B, self.L, d, self.eps)
         if self.p_hid > 0:              # HF:213
-            ops.dropout(self.emb_y, self.emb_y, ML, d, d, d, self.p_hid, self.seed(0))
+            ops.dropout(self.emb_y, self.emb_y, self.MLd, d, d, d, self.p_hid, self.seed(0))
         x = self.emb_y
+        if self.packed:                 # the real tokens' rows, packed (zero rows in the tail that pads to the row tile)
+            x = self.emb_p[:ML]
+            ops.gather_rows(self.emb_y, self.lrows, x, ML, d, d, d)
         for i, (sa, ffn) in enumerate(self.lang_layers):
             self._pr(("lang", i))
-            sa.fwd(x, self.lang_mid[i])
-            y = X0[:ML] if i == cfg.l_layers - 1 else self.lang_out[i]
-            ffn.fwd(self.lang_mid[i], y)
+            mid = self.lang_mid[i][:ML]
+            sa.fwd(x, mid)
+            y = self.lr(X0) if i == cfg.l_layers - 1 else self.lang_out[i][:ML]
+            ffn.fwd(mid, y)
             x = y
 
     def _encoder_forward(self, want_pooled=True):
@@ -998,7 +1101,7 @@ class Engine:
         self.fork()
         # samplers: the text does not change between refinement steps and, without dropout, neither does the output of the
         # language stack (embeddings + l_layers self-attention layers: it never sees the visual tokens) -- it still sits in
-        # X[0][:ML] from the loop's first pass (no later layer writes there), so the later passes skip it.  Exact.
+        # the language rows of X[0] from the loop's first pass (no later layer writes there), so the later passes skip it.  Exact.
         skip_lang = getattr(self, "_reuse_lang_stack", False) and self.p_hid == 0 and self.p_attn == 0
         if not skip_lang:
             with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream
@@ -1022,7 +1125,7 @@ class Engine:
         for i, (sa, ffn) in enumerate(self.vis_layers):
             self._pr(("vis", i))
             sa.fwd(x, self.vis_mid[i])
-            y = X0[ML:] if i == cfg.r_layers - 1 else self.vis_out[i]
+            y = self.vr(X0) if i == cfg.r_layers - 1 else self.vis_out[i]
             ffn.fwd(self.vis_mid[i], y)
             x = y
         self.join()
@@ -1033,15 +1136,17 @@ class Engine:
             if blk["lang_on"]:
                 self.fork()
                 with self.lang_stream():
-                    blk["sa_l"].fwd(Y[:ML], S[:ML])
-                    blk["ffn_l"].fwd(S[:ML], Xo[:ML])
+                    blk["sa_l"].fwd(self.lr(Y), self.lr(S))
+                    blk["ffn_l"].fwd(self.lr(S), self.lr(Xo))
             if blk["vis_on"]:
-                blk["sa_v"].fwd(Y[ML:], S[ML:])
-                blk["ffn_v"].fwd(S[ML:], Xo[ML:])
+                blk["sa_v"].fwd(self.vr(Y), self.vr(S))
+                blk["ffn_v"].fwd(self.vr(S), self.vr(Xo))
             if blk["lang_on"]:
                 self.join()
         Xl = self.X[-1]
-        self.lang_final, self.vis_final = Xl[:ML], Xl[ML:]
+        self.lang_final, self.vis_final = self.lr(Xl), self.vr(Xl)
+        if self.packed and self.need_lang:          # language_output in the reference's [B, L, d] layout for whoever reads it
+            self.lang_final = self._dense_lang(self.lr(Xl), self.lang_pad)
         self._pr("heads")                   # pooler and every head on top of the encoder
         if want_pooled and self.need_lang:
             # LxmertPooler (HF:566-572): tanh(dense(lang[:, 0]))
@@ -1128,15 +1233,15 @@ class Engine:
         """backward of LxmertModel.forward from gradients of its three outputs (any may be None): ACCUMULATES into store.grad
         (HF:691-822; the pooler's gradient joins the [CLS] rows of d(language_output))."""
         assert self.need_lang, "needs the language side of the last cross layer (engine built with need_lang=True)"
-        ML, d = self.ML, self.d
+        d = self.d
         self.begin_backward()
         GA = self.GA
         if d_lang is None or d_vis is None:
-            self.ops.zero(GA)
+            self.zero_out_grads(GA)
         if d_lang is not None:
-            GA[:ML].copy_(d_lang.reshape(ML, d))
+            self.glang(GA).copy_(d_lang.reshape(self.MLd, d))
         if d_vis is not None:
-            GA[ML:].copy_(d_vis.reshape(self.MV, d))
+            self.vr(GA).copy_(d_vis.reshape(self.MV, d))
         if d_pooled is not None:
             if not hasattr(self, "_dpooled"):
                 self._dpooled, self._dpool_z = self.act(self.B, d), self.act(self.B, d)
@@ -1145,9 +1250,21 @@ class Engine:
             self.pooler_backward(self._dpooled, self._dpool_z, cls_rows, d_cls, accumulate=True)
         self.encoder_backward(have_lang_grad=True)
 
+    def glang(self, G):
+        """where the heads leave d(language_output) in the reference's dense [B*L, d] layout: the language rows of the gradient
+        buffer G themselves, or -- packed language rows -- a dense side buffer that encoder_backward gathers into them."""
+        return self.glang_pad if self.packed else self.lr(G)
+
+    def zero_out_grads(self, G):
+        """d(language_output) = d(vision_output) = 0 (the caller then writes what its loss produces)"""
+        self.ops.zero(G[:self.MX])
+        if self.packed:
+            self.ops.zero(self.glang_pad)
+
     def _cls_views(self, G):
+        """[B, d] views with row stride L*d of the [CLS] rows of language_output and of its gradient"""
         B, L, d = self.B, self.L, self.d
-        return self.lang_final.view(B, L * d)[:, :d], G[:self.ML].view(B, L * d)[:, :d]
+        return self.lang_final.view(B, L * d)[:, :d], self.glang(G).view(B, L * d)[:, :d]
 
     # Every branch of XLxmertForPretraining.forward (ref lxrt/modeling.py:154-308) as two phases: task_forward = encoder + heads
     # + losses (and the loss gradients w.r.t. the head outputs: no parameter gradient is touched), task_backward = everything
@@ -1203,21 +1320,21 @@ class Engine:
         if task == "vis_mask":
             self._hrows = self._hrows_step
             try:
-                self.head_backward(GA[self.ML:], report=not qa)
+                self.head_backward(self.vr(GA), report=not qa)
             finally:
                 self._hrows = None
             if self.need_lang:          # the language side of the last cross layer exists: zero gradient ...
-                self.ops.zero(GA[:self.ML])
+                self.ops.zero(self.glang(GA))
             if qa:                      # ... unless the QA branch reads pooled_output
                 cls_rows, d_cls = self._cls_views(GA)
                 ans.bwd(self.pooled, cls_rows, d_cls)
                 self._ready_heads()
             self.encoder_backward(self.need_lang)
             return
-        self.ops.zero(GA)
+        self.zero_out_grads(GA)
         cls_rows, d_cls = self._cls_views(GA)
         if task == "word_mask":
-            lh.mlm_bwd(GA[:self.ML])
+            lh.mlm_bwd(self.glang(GA))
             if qa:
                 ans.bwd(self.pooled, cls_rows, d_cls, accumulate=True)     # the MLM gradient of the [CLS] rows is there
         elif task == "matched":
@@ -1265,9 +1382,9 @@ class Engine:
         self.zero_accumulated_grads()
         loss = ans.loss_fwd_bwd(True)
         GA = self.GA
-        self.ops.zero(GA)                            # only the [CLS] rows of the language output carry gradient
-        cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
-        ans.bwd(self.pooled, cls_rows, GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
+        self.zero_out_grads(GA)                      # only the [CLS] rows of the language output carry gradient
+        cls_rows, d_cls = self._cls_views(GA)
+        ans.bwd(self.pooled, cls_rows, d_cls)
         self._ready_heads()
         self.encoder_backward(True)
         return loss
@@ -1283,9 +1400,9 @@ class Engine:
         self.zero_accumulated_grads()
         loss = ans.ce_loss_fwd_bwd(True)
         GA = self.GA
-        self.ops.zero(GA)
-        cls_rows = self.lang_final.view(self.B, self.L * self.d)[:, :self.d]
-        ans.bwd(self.pooled, cls_rows, GA[:self.ML].view(self.B, self.L * self.d)[:, :self.d])
+        self.zero_out_grads(GA)
+        cls_rows, d_cls = self._cls_views(GA)
+        ans.bwd(self.pooled, cls_rows, d_cls)
         self._ready_heads()
         self.encoder_backward(True)
         return loss
@@ -1471,6 +1588,9 @@ class Engine:
         cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
         ML, MV = self.ML, self.MV
         GA, GB = self.GA, self.GB
+        L_, V_ = self.lr, self.vr
+        if self.packed and have_lang_grad:      # d(language_output), dense layout -> the packed rows (zero rows in the pad tail)
+            ops.gather_rows(self.glang_pad, self.lrows, L_(GA), ML, d, d, d)
         for i in reversed(range(cfg.x_layers)):
             blk = self.x_layers[i]
             lang_on = blk["lang_on"] and (have_lang_grad or i < cfg.x_layers - 1)
@@ -1479,15 +1599,15 @@ class Engine:
                     raise RuntimeError("engine built with need_lang=True needs d(language_output)")
                 self.fork()
                 with self.lang_stream():
-                    blk["ffn_l"].bwd(GA[:ML], GB[:ML])
-                    blk["sa_l"].bwd(GB[:ML], GA[:ML])
+                    blk["ffn_l"].bwd(L_(GA), L_(GB))
+                    blk["sa_l"].bwd(L_(GB), L_(GA))
                     if i == 0:                  # the language side of the cross layers is reported by the main stream (below):
                         self.wgrad_flush(pair=True, force=True)      # nothing of it may stay held into the language stack
                     self.flush_reductions()
                     self.wgrad_sync()
             if blk["vis_on"]:
-                blk["ffn_v"].bwd(GA[ML:], GB[ML:])
-                blk["sa_v"].bwd(GB[ML:], GA[ML:])
+                blk["ffn_v"].bwd(V_(GA), V_(GB))
+                blk["sa_v"].bwd(V_(GB), V_(GA))
             if blk["lang_on"]:
                 self.join()
             blk["cross"].bwd(GA, GB)
@@ -1497,17 +1617,22 @@ class Engine:
         with self.lang_stream():            # ---- language stack + embeddings (HF:191-214) on the side stream
             for i in reversed(range(cfg.l_layers)):
                 sa, ffn = self.lang_layers[i]
-                ffn.bwd(GA[:ML], GB[:ML])
-                sa.bwd(GB[:ML], GA[:ML])
+                ffn.bwd(L_(GA), L_(GB))
+                sa.bwd(L_(GB), L_(GA))
                 self.flush_reductions()
                 self._ready_lang(st.range_of(f"bert.encoder.layer.{i}.")[1])
             self.wgrad_flush(pair=True, force=True)      # an odd layer left over
             e = "bert.embeddings"
+            dy, MLd = L_(GA), self.MLd
+            if self.packed:                       # back to the dense [B*L] rows of the embedding kernels (zero at [PAD] positions)
+                dy = self.tmp("emb_dy", MLd, d)
+                ops.zero(dy)
+                ops.scatter_rows(L_(GA), self.lrows, dy, ML, d, d, d)
             if self.p_hid > 0:
-                ops.dropout(GA[:ML], GA[:ML], ML, d, d, d, self.p_hid, self.seed(0))
-            dpre = self.tmp("emb_dz", ML, d)      # not "dz": layer 0's weight-gradient group may still be reading it
-            ops.layernorm_bwd(GA[:ML], self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
-                              st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, ML, d, ws=self.ws)
+                ops.dropout(dy, dy, MLd, d, d, d, self.p_hid, self.seed(0))
+            dpre = self.tmp("emb_dz", MLd, d)     # not "dz": layer 0's weight-gradient group may still be reading it
+            ops.layernorm_bwd(dy, self.emb_pre, st.view(e + ".LayerNorm.weight"), self.emb_mean, self.emb_rstd, dpre,
+                              st.gview(e + ".LayerNorm.weight"), st.gview(e + ".LayerNorm.bias"), None, MLd, d, ws=self.ws)
             emb = getattr(self, "embeds_mode", False)
             if emb:                                   # d(inputs_embeds) instead of d(word_embeddings): see set_inputs
                 ops.zero(self._emb_grad)
@@ -1521,8 +1646,8 @@ class Engine:
         # ---- relational (visual) stack
         for i in reversed(range(cfg.r_layers)):
             sa, ffn = self.vis_layers[i]
-            ffn.bwd(GA[ML:], GB[ML:])
-            sa.bwd(GB[ML:], GA[ML:])
+            ffn.bwd(V_(GA), V_(GB))
+            sa.bwd(V_(GB), V_(GA))
             if i == 0:
                 self.wgrad_flush(pair=True, force=True)
             self._ready(f"bert.encoder.r_layers.{i}.")
@@ -1531,8 +1656,8 @@ class Engine:
         ops.block = "visn_fc"
         dxv = self.tmp("dctx", MV, d)
         if self.p_hid > 0:
-            ops.dropout(GA[ML:], GA[ML:], MV, d, d, d, self.p_hid, self.seed(1))
-        ops.visn_ln_bwd(GA[ML:], self.xv, self.pos, st.view(v + ".box_fc.weight"), st.view(v + ".box_fc.bias"),
+            ops.dropout(V_(GA), V_(GA), MV, d, d, d, self.p_hid, self.seed(1))
+        ops.visn_ln_bwd(V_(GA), self.xv, self.pos, st.view(v + ".box_fc.weight"), st.view(v + ".box_fc.bias"),
                         st.view(v + ".visn_layer_norm.weight"), st.view(v + ".box_layer_norm.weight"), *self.vn_stats,
                         dxv, st.gview(v + ".visn_layer_norm.weight"), st.gview(v + ".visn_layer_norm.bias"),
                         st.gview(v + ".box_layer_norm.weight"), st.gview(v + ".box_layer_norm.bias"),

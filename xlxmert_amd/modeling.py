@@ -151,8 +151,8 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head, vis, want_obj):
         eng = head._bert._engine
-        eng.X[-1][eng.ML:].copy_(vis.reshape(eng.MV, eng.d))
-        eng.vis_final = eng.X[-1][eng.ML:]
+        eng.vr(eng.X[-1]).copy_(vis.reshape(eng.MV, eng.d))
+        eng.vis_final = eng.vr(eng.X[-1])
         feat, logits = eng.head_forward(want_logits=want_obj)
         ctx.head = head
         B, V = eng.B, eng.V
@@ -193,8 +193,8 @@ class LxmertVisualObjHead(_Named):
         if torch.is_grad_enabled() and hidden_states.requires_grad:
             feat, obj = _HeadFn.apply(self, hidden_states, True)
         else:
-            eng.X[-1][eng.ML:].copy_(hidden_states.reshape(eng.MV, eng.d))
-            eng.vis_final = eng.X[-1][eng.ML:]
+            eng.vr(eng.X[-1]).copy_(hidden_states.reshape(eng.MV, eng.d))
+            eng.vis_final = eng.vr(eng.X[-1])
             f, o = eng.head_forward(True)
             feat, obj = f.view(eng.B, eng.V, -1).float().clone(), o.view(eng.B, eng.V, -1).clone()
         output = {}
@@ -419,9 +419,9 @@ class _VqaFn(torch.autograd.Function):
         ans = eng.answer
         ans.dlogit.zero_()
         ans.dlogit[:, :ans.A].copy_(d_logit)
-        eng.GA.zero_()
-        cls_rows = eng.lang_final.view(eng.B, eng.L * eng.d)[:, :eng.d]
-        ans.bwd(eng.pooled, cls_rows, eng.GA[:eng.ML].view(eng.B, eng.L * eng.d)[:, :eng.d])
+        eng.zero_out_grads(eng.GA)
+        cls_rows, d_cls = eng._cls_views(eng.GA)
+        ans.bwd(eng.pooled, cls_rows, d_cls)
         eng.encoder_backward(True)            # gradients accumulate into the flat buffer: call model.zero_grad() per step
         return None, None
 

@@ -244,17 +244,20 @@ class HipOps:
                       self._p(code_ids), B, V, int(fixed_pos), self._stream())
 
     # -- attention core
-    def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0):
+    def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0,
+                 q_off=None, k_off=None, q_pad=0, k_pad=0):
+        """q_off / k_off: int32 [B+1] row offsets of a PACKED side (None = dense [B, n] rows); q_pad: rows [q_off[B], q_pad) of
+        `o` are written as zeros."""
         self._call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),
-                      B, H, nq, nk, dh, ldq, ldk, ldv, ldo, float(scale), float(p_drop), int(seed), self.dt,
-                      self._stream())
+                   B, H, nq, nk, dh, ldq, ldk, ldv, ldo, float(scale), float(p_drop), int(seed), self._p(q_off), self._p(k_off),
+                   int(q_pad), int(k_pad), self.dt, self._stream())
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
-                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None):
+                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None, q_off=None, k_off=None, q_pad=0, k_pad=0):
         self._call("xl_sdpa_bwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(dout),
-                      self._p(lse), self._p(dq), self._p(dk), self._p(dv), B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq,
-                      lddk, lddv, float(scale), float(p_drop), int(seed), self._p(bias_grad), self._p(ws), self.dt,
-                      self._stream())
+                   self._p(lse), self._p(dq), self._p(dk), self._p(dv), B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq,
+                   lddk, lddv, float(scale), float(p_drop), int(seed), self._p(bias_grad), self._p(ws), self._p(q_off),
+                   self._p(k_off), int(q_pad), int(k_pad), self.dt, self._stream())
 
     # -- head losses
     def mask_counts(self, labels, vis_mask, counts, nmask, B, V):

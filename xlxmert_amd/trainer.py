@@ -345,7 +345,8 @@ class PretrainStep:
             # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels (+ optional word_rows:
             # word_rows_of(word_labels), the masked-row decoder) | matched_labels
             eng.set_step_seed(self.t * self.world + self.rank)
-            eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"])
+            eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
+                           lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
             self._mark_consumed(batch)
             eng.grad_ready = None
             if exchange:
@@ -370,7 +371,8 @@ class PretrainStep:
             if run == "nlvr2":
                 feats, pos = feats.reshape(-1, *feats.shape[2:]), pos.reshape(-1, *pos.shape[2:])
             eng.set_step_seed(self.t * self.world + self.rank)
-            eng.set_inputs(ids, am, batch.get("token_type_ids"), pos, visual_feats=feats)
+            eng.set_inputs(ids, am, batch.get("token_type_ids"), pos, visual_feats=feats,
+                           lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
             self._mark_consumed(batch)
             eng.grad_ready = None
             if exchange:
@@ -389,7 +391,8 @@ class PretrainStep:
         eng.set_step_seed(self.t * self.world + self.rank)
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                        vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"),
-                       feat_labels=batch.get("feat_labels") if self.feat_loss else None)
+                       feat_labels=batch.get("feat_labels") if self.feat_loss else None,
+                       lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
         self._mark_consumed(batch)
         if self.plan_mode and qa_labels is None and not accumulating:
             return self._planned_step()
@@ -421,7 +424,8 @@ class PretrainStep:
         use runs AND records; from then on the step is one xl_plan_run."""
         eng = self.engine
         use_rows = eng.compact_head and eng.has_vmask and 0 < eng.n_mrows < eng.MV
-        key = (eng.n_mrows if use_rows else -1, bool(self.feat_loss), eng.feat_tgt is not None, eng.has_vmask, eng.use_codebook)
+        key = (eng.n_mrows if use_rows else -1, bool(self.feat_loss), eng.feat_tgt is not None, eng.has_vmask, eng.use_codebook,
+               eng.ML if eng.packed else -1)                  # (padded count of packed language rows: a launch size too)
         plan = self._plans.get(key)
         if plan is not None:
             if self.exchange:
@@ -486,44 +490,75 @@ class PretrainStep:
         return math.sqrt(float(self.sumsq.item())) / self.world
 
 
+class PackedBatch(dict):
+    """a host minibatch whose tensors are views of ONE page-locked byte buffer (`buf`): a single H2D copy moves all of it.
+    `layout`: [(name, dtype, shape, byte offset)], offsets 16-byte aligned; non-tensor entries are plain dict items."""
+    buf, layout = None, ()
+
+
 class BatchUploader:
     """Host -> device hand-over of minibatches (the reference's `.cuda()` calls at the top of every step, ref
-    lxmert_pretrain.py:145-160), one step ahead of the compute: `upload(host_batch)` queues the copies of the NEXT batch from
-    pinned host memory into one of two device staging slots on a copy stream of its own and returns the staged batch;
-    PretrainStep.step() makes the compute stream wait for that upload (`_ready`) before it moves the tensors into the engine's
-    static input buffers, and marks the slot free afterwards (`_consumed`).  The copy stream never waits for anything younger than
-    two steps, so it does not hold up a hardware queue it may share with a compute stream (engine.reserve_streams)."""
+    lxmert_pretrain.py:145-160), one step ahead of the compute: `upload(packed_batch)` queues ONE copy of the NEXT batch from
+    pinned host memory into one of two device staging slots on a copy stream of its own and returns the staged batch (views of
+    the slot); PretrainStep.step() makes the compute stream wait for that upload (`_ready`) before it moves the tensors into the
+    engine's static input buffers, and marks the slot free afterwards (`_consumed`).  One copy per step and no wait on anything
+    younger than two steps: the copy stream shares a hardware queue with a compute stream (engine.reserve_streams: four queues,
+    four compute streams), and every packet it queues sits in front of that stream's kernels (nine separate copies per step cost
+    0.3 ms of step time, measured)."""
 
     def __init__(self, device, slots=2):
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
-        self.slots = [{} for _ in range(slots)]
+        self.slots = [None] * slots
         self.ready = [torch.cuda.Event() for _ in range(slots)]
         self.consumed = [None] * slots
         self.n = 0
 
     @staticmethod
     def pin(batch):
-        """a host batch in page-locked memory (what a DataLoader(pin_memory=True) hands over, ref lxmert_data.py:666-671)."""
-        return {k: (v.pin_memory() if torch.is_tensor(v) and not v.is_cuda else v) for k, v in batch.items()}
+        """pack a host batch into one page-locked buffer (what a collate function with pin_memory would hand over, ref
+        lxmert_data.py:666-671)."""
+        layout, off = [], 0
+        for name, v in batch.items():
+            if torch.is_tensor(v):
+                v = v.contiguous()
+                layout.append((name, v.dtype, tuple(v.shape), off))
+                off = (off + v.numel() * v.element_size() + 15) // 16 * 16
+        out = PackedBatch()
+        out.buf = torch.empty(max(off, 16), dtype=torch.uint8).pin_memory()
+        out.layout = layout
+        for name, dtype, shape, o in layout:
+            view = BatchUploader._view(out.buf, dtype, shape, o)
+            view.copy_(batch[name])
+            out[name] = view
+        for name, v in batch.items():
+            if not torch.is_tensor(v):
+                out[name] = v
+        return out
+
+    @staticmethod
+    def _view(buf, dtype, shape, off):
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        return buf[off:off + nbytes].view(dtype).view(shape)
 
     def upload(self, batch):
+        assert isinstance(batch, PackedBatch), "BatchUploader.upload takes BatchUploader.pin(batch)"
         k = self.n % len(self.slots)
         self.n += 1
-        slot = self.slots[k]
+        if self.slots[k] is None or self.slots[k].numel() < batch.buf.numel():
+            self.slots[k] = torch.empty(batch.buf.numel(), dtype=torch.uint8, device=self.device)
+        dev = self.slots[k]
         with torch.cuda.stream(self.stream):
             if self.consumed[k] is not None:
                 self.stream.wait_event(self.consumed[k])       # the step that read this slot (two uploads ago) has taken its copy
-            for name, v in batch.items():
-                if not torch.is_tensor(v):
-                    slot[name] = v
-                    continue
-                buf = slot.get(name)
-                if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
-                    buf = slot[name] = torch.empty(v.shape, dtype=v.dtype, device=self.device)
-                buf.copy_(v, non_blocking=True)
+            dev[:batch.buf.numel()].copy_(batch.buf, non_blocking=True)
             self.ready[k].record(self.stream)
-        out = {name: slot[name] for name in batch}
+        out = {name: v for name, v in batch.items() if not torch.is_tensor(v)}
+        for name, dtype, shape, o in batch.layout:
+            out[name] = self._view(dev, dtype, shape, o)
         out["_ready"] = self.ready[k]
         self.consumed[k] = out["_consumed"] = torch.cuda.Event()
         return out
@@ -550,9 +585,13 @@ def synthetic_batch(cfg, B, L=20, grid=8, seed=9595, device="cpu", ragged=True):
     for i in range(grid):
         for j in range(grid):
             pos[i * grid + j] = torch.tensor([j / grid, i / grid, (j + 1) / grid, (i + 1) / grid])
-    batch = {"input_ids": ids, "attention_mask": ids > 0, "token_type_ids": torch.zeros_like(ids),
+    am = ids > 0
+    batch = {"input_ids": ids, "attention_mask": am, "token_type_ids": torch.zeros_like(ids),
              "cluster_ids": cid, "vis_mask": vm, "obj_labels": lab, "visual_pos": pos[None].expand(B, -1, -1).contiguous(),
-             "masked_rows": vm.reshape(-1).nonzero().reshape(-1)}      # computed where the mask is drawn: on the host
+             "masked_rows": vm.reshape(-1).nonzero().reshape(-1),      # computed where the mask is drawn: on the host
+             # ... and likewise the real tokens' row list + per-example offsets (packed language rows, engine pack_lang)
+             "lang_rows": am.reshape(-1).nonzero().reshape(-1),
+             "lang_off": torch.cat([torch.zeros(1, dtype=torch.int64), am.sum(1).cumsum(0)]).to(torch.int32)}
     return {k: v.to(device) for k, v in batch.items()}
 
 
