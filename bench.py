@@ -442,7 +442,9 @@ def main():
                 "element_type": "bf16" if tr.comm_buf is not None else "fp32",
                 "bucket_mb": round(tr.bucket_elems * (2 if tr.comm_buf is not None else 4) / (1 << 20), 1),
                 "bytes_per_step": int(tr.store.n_used * (2 if tr.comm_buf is not None else 4)),
-                "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3)}
+                "issued_by": ("xl_comm_* (the library's own RCCL binding: the collectives are entries of the launch plan, XL_COMM=rccl)"
+                              if tr.xl_comm is not None else "torch.distributed (host operations between the segments of the launch plan)"),
+                "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3) if tr.xl_comm is None else None}
         if not args.no_extra and world == 1 and not args.single_stream:
             del tr, batches
             torch.cuda.empty_cache()

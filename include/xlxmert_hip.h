@@ -41,6 +41,7 @@ extern "C" {
 #define XL_ERR_UNALIGNED -3
 #define XL_ERR_HIP       -4
 #define XL_ERR_BAD_ARG   -5
+#define XL_ERR_RCCL      -6
 
 /* GEMM epilogues */
 #define XL_EPI_NONE     0   /* C = acc (+bias)                                                      */
@@ -351,6 +352,31 @@ int  xl_plan_fn_nargs(int fn_id);
 int64_t xl_plan_create(int n_calls, const int* fn_ids, const int* n_args, const uint64_t* words);
 int  xl_plan_run(int64_t plan);
 int  xl_plan_destroy(int64_t plan);
+
+/* ---------------------------------------------------------------- gradient exchange (RCCL over xGMI; csrc/comm.hip)
+ * The data-parallel step of the reference is DistributedDataParallel around the model (ref pretrain/lxmert_pretrain.py:102-106,
+ * 694-700: one process per GPU, NCCL backend).  These calls put the same collectives behind the C ABI so that a launch plan can
+ * contain them: one communicator per process, every collective on the communicator's OWN stream, ordered after everything
+ * queued so far on `after_stream` (event record + wait, issued by the call), all asynchronous.
+ *   xl_comm_unique_id(id128): rank 0 fills a 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *     (xlxmert_amd.trainer broadcasts it through torch.distributed);  xl_comm_init(id128, rank, nranks) -> handle (0 on error:
+ *     collective over all ranks, each with its GPU current);  xl_comm_destroy.
+ *   xl_comm_allreduce: buf (count elements of `dtype`, XL_F32 or XL_BF16) := sum over ranks, in place.
+ *   xl_comm_reduce_scatter / xl_comm_allgather: the two halves (recv_count / send_count = elements per rank): rank r ends up
+ *     with the sum of everybody's r-th piece / everybody ends up with every rank's piece.
+ *   xl_comm_bcast(buf, bytes, root): parameter / optimizer-state broadcast at start-up (DDP's constructor broadcast);
+ *   xl_comm_reduce: sum onto `root` (the epoch metrics of ref utils.py:11-39).
+ *   xl_comm_wait(comm, stream): `stream` continues after every collective issued so far.
+ * RCCL is bound at run time (dlopen librccl.so.1): a process that never calls xl_comm_* does not need it. */
+int  xl_comm_unique_id(void* id128);
+int64_t xl_comm_init(const void* id128, int rank, int nranks);
+int  xl_comm_destroy(int64_t comm);
+int  xl_comm_allreduce(int64_t comm, void* buf, int64_t count, int dtype, void* after_stream);
+int  xl_comm_reduce_scatter(int64_t comm, const void* send, void* recv, int64_t recv_count, int dtype, void* after_stream);
+int  xl_comm_allgather(int64_t comm, const void* send, void* recv, int64_t send_count, int dtype, void* after_stream);
+int  xl_comm_bcast(int64_t comm, void* buf, int64_t bytes, int root, void* after_stream);
+int  xl_comm_reduce(int64_t comm, void* buf, int64_t count, int dtype, int root, void* after_stream);
+int  xl_comm_wait(int64_t comm, void* stream);
 
 #ifdef __cplusplus
 }

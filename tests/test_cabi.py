@@ -75,3 +75,27 @@ def test_launch_plan_records_and_replays_host_side():
         lib.make_plan([bad_drop]).run()
     with pytest.raises(XlError, match="cannot be part of a launch plan"):
         lib.make_plan([("xl_gemm_trace", (None,))])
+
+
+def test_comm_entry_points_and_rccl_constants():
+    """xl_comm_* (csrc/comm.hip) binds RCCL at run time by symbol name and passes ncclDataType_t / ncclRedOp_t by VALUE: the
+    values it hard-codes must be the ones of the installed rccl.h; an unknown communicator is an error, not a crash."""
+    import re
+    from xlxmert_amd._lib import XlError, get_lib, parse_header
+    protos = parse_header()
+    for fn in ("xl_comm_unique_id", "xl_comm_init", "xl_comm_destroy", "xl_comm_allreduce", "xl_comm_reduce_scatter",
+               "xl_comm_allgather", "xl_comm_bcast", "xl_comm_reduce", "xl_comm_wait"):
+        assert fn in protos, fn
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if os.path.exists(hdr):
+        txt = open(hdr).read()
+        want = {"ncclUint8": 1, "ncclInt64": 4, "ncclFloat32": 7, "ncclBfloat16": 9, "ncclSum": 0, "ncclMax": 2}
+        for name, val in want.items():
+            m = re.search(rf"\b{name}\s*=\s*(\d+)", txt)
+            assert m and int(m.group(1)) == val, (name, m and m.group(1))
+        assert re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+128", txt)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xlxmert_amd", "csrc", "comm.hip")).read()
+    assert "NCCL_FLOAT32 = 7" in src and "NCCL_BFLOAT16 = 9" in src and "NCCL_SUM = 0" in src
+    lib = get_lib()
+    with pytest.raises(XlError, match="unknown communicator|cannot load"):
+        lib.call("xl_comm_wait", 12345, None)

@@ -307,10 +307,15 @@ def test_gradient_ranges_are_final_when_reported():
             assert any(lane == "l" and s != main for _, _, lane, s in seen)
 
 
-def test_exchange_on_one_rank_rccl_group_is_identity():
+@pytest.mark.parametrize("via,plan,comm_dtype", [("torch", False, None), ("torch", True, None), ("rccl", False, None),
+                                                  ("rccl", True, None), ("rccl", True, torch.bfloat16)])
+def test_exchange_on_one_rank_rccl_group_is_identity(via, plan, comm_dtype):
     """The data-parallel exchange through a real RCCL process group (one rank: every all-reduce is the identity): the
-    collectives are queued from three streams (main, language-range reports, end of step) exactly as on N GPUs, and two
-    training steps must give the same losses, gradient norm and parameters as the same two steps without the exchange."""
+    collectives are queued from three streams (main, language-range reports, end of step) exactly as on N GPUs, and the
+    training steps must give the same losses, gradient norm and parameters as the same steps without the exchange.
+    via = "torch": torch.distributed issues the collectives (in a launch plan: host operations between plan segments);
+    via = "rccl": the library's own RCCL binding (xl_comm_*, XL_COMM=rccl) -- the collectives are entries of ONE plan.
+    plan: the third step is a plan replay."""
     import os
     import socket
     import torch.distributed as dist
@@ -325,31 +330,42 @@ def test_exchange_on_one_rank_rccl_group_is_identity():
     def run(tr):
         tr.store.view("mask_feat").copy_(mask_feat)
         tr.set_centroids(cent)
-        out = [tr.step(batch).clone() for _ in range(2)]
+        out = [tr.step(batch).clone() for _ in range(3)]
         torch.cuda.synchronize()
         return out, tr.store.master.clone(), tr.grad_norm()
 
-    ref = run(PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1, bucket_mb=8))
+    ref = run(PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1, bucket_mb=8, plan=plan, drop_grads=False))
     with socket.socket() as sck:
         sck.bind(("127.0.0.1", 0))
         port = sck.getsockname()[1]
     os.environ["XL_FORCE_EXCHANGE"] = "1"
+    os.environ["XL_COMM"] = via
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda:0"))
     try:
-        tr = PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1, bucket_mb=8)
-        assert tr.exchange and tr.world == 1
+        tr = PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1, bucket_mb=8, plan=plan, drop_grads=False,
+                          grad_comm_dtype=comm_dtype)
+        assert tr.exchange and tr.world == 1 and (tr.xl_comm is not None) == (via == "rccl")
         got = run(tr)
         assert len(tr._works) > 4, len(tr._works)
         lo, hi = tr.store.language_range()
         assert any(lo <= a < hi for a, _ in tr._slices)
+        if plan:
+            (p,) = tr._plans.values()
+            if via == "rccl":               # one plan, the collectives inside it
+                assert p.n_segments == 1 and p.n_host_ops == 0
+            else:                           # segments around torch.distributed's collectives
+                assert p.n_host_ops == len(tr._slices) + 1 and p.n_segments >= len(tr._slices)
     finally:
         dist.destroy_process_group()
         os.environ.pop("XL_FORCE_EXCHANGE", None)
-    # (not bit-identical: split-K and loss sums use float atomics, whose order differs from run to run)
+        os.environ.pop("XL_COMM", None)
+    # (not bit-identical: split-K and loss sums use float atomics, whose order differs from run to run; bf16 buckets round
+    #  the gradients once more)
+    tol = 1e-5 if comm_dtype is None else 2e-3
     for a, b in zip(ref[0], got[0]):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)
-    assert (ref[1] - got[1]).abs().max().item() < 2e-5 and abs(ref[2] - got[2]) < 1e-4 * ref[2]
+        assert torch.allclose(a, b, rtol=tol, atol=1e-6), (a, b)
+    assert (ref[1] - got[1]).abs().max().item() < (2e-5 if comm_dtype is None else 2e-3) and abs(ref[2] - got[2]) < (1e-4 if comm_dtype is None else 5e-3) * ref[2]
 
 
 def test_full_size_step_properties_bf16():

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxlxmert_hip.so")
-SOURCES = ["gemm_pp.hip", "gemm_pp_nn.hip", "gemm_pp_192.hip", "gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip"]
+SOURCES = ["gemm_pp.hip", "gemm_pp_nn.hip", "gemm_pp_192.hip", "gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip", "comm.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -55,7 +55,7 @@ def build_library(force=False, verbose=True):
         objs = list(ex.map(cc, SOURCES))
     if not force and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
         return LIB                                      # every object up to date and already linked
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], capture_output=True, text=True)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return LIB

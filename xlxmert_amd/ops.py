@@ -310,6 +310,17 @@ class HipOps:
                       self._p(decay_flags), self._p(chunk_steps), self._p(sumsq), self._p(lr_and_steps), n, float(beta1), float(beta2),
                       float(eps), float(weight_decay), float(max_norm), float(grad_scale), int(zero_grad), self.dt, self._stream())
 
+    # -- gradient exchange behind the C ABI (csrc/comm.hip): RCCL collectives as plan-able calls
+    def comm_allreduce(self, comm, buf, n, after_stream=None):
+        """buf[:n] := sum over ranks (in place) on the communicator's stream, after everything queued so far on `after_stream`
+        (default: the current stream)."""
+        st = after_stream.cuda_stream if after_stream is not None else self._stream()
+        self._call("xl_comm_allreduce", int(comm), self._p(buf), int(n), xl_dtype(buf.dtype), st)
+
+    def comm_wait(self, comm, stream=None):
+        st = stream.cuda_stream if stream is not None else self._stream()
+        self._call("xl_comm_wait", int(comm), st)
+
     def cast_from_f32(self, src, dst, n):
         self._call("xl_cast_from_f32", self._p(src), self._p(dst), n, self.dt, self._stream())
 

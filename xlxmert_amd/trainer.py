@@ -134,6 +134,13 @@ class PretrainStep:
             if isinstance(self.ops, HipOps) and self.ops.dtype != torch.bfloat16:
                 self._comm_ops = HipOps(torch.bfloat16)
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // (2 if self.comm_buf is not None else 4))
+        # XL_COMM=rccl: the collectives go through the library's own RCCL binding (xl_comm_*, csrc/comm.hip) instead of
+        # torch.distributed -- they are then ordinary entries of the launch plan (one xl_plan_run per step, no host operation
+        # in between).  Opt-in: like the torch path it has only ever met one rank on hardware.
+        self.xl_comm = None
+        if (self.exchange and os.environ.get("XL_COMM", "torch") == "rccl" and isinstance(self.ops, HipOps)
+                and self.device.type == "cuda" and dist.get_backend() == "nccl"):
+            self.xl_comm = self._init_xl_comm()
         self.exposed_comm_ms = []              # per step: time the main stream waited for collectives after backward
         env = os.environ.get("XL_PLAN")
         self.plan_mode = bool(int(env)) if env else bool(plan)
@@ -173,6 +180,22 @@ class PretrainStep:
     total_steps, warmup_steps = _hyper("total_steps"), _hyper("warmup_steps")
     betas, eps = _hyper("betas"), _hyper("eps")
     del _hyper
+
+    def _init_xl_comm(self):
+        """one RCCL communicator for this process behind the C ABI: rank 0 draws the 128-byte id, torch.distributed carries it
+        to the other ranks (the only use of the process group by this path besides the start-up broadcast)."""
+        import ctypes
+        lib = self.ops.lib
+        idbuf = (ctypes.c_uint8 * 128)()
+        if self.rank == 0:
+            lib.call("xl_comm_unique_id", ctypes.addressof(idbuf))
+        t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.device)
+        dist.broadcast(t, src=0)
+        idbuf = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+        h = int(lib.raw("xl_comm_init")(ctypes.addressof(idbuf), self.rank, self.world))
+        if h <= 0:
+            raise RuntimeError("xl_comm_init failed: " + lib.raw("xl_last_error")().decode())
+        return h
 
     def _wait_params(self, key):
         """engine hook: the current stream is about to read the parameters of group `key` -- wait for the optimizer pass of
@@ -265,6 +288,11 @@ class PretrainStep:
             self._comm_ops.cast_from_f32(self.store.grad[lo:hi], self.comm_buf[lo:hi], hi - lo)
             buf = self.comm_buf
         piece = buf[lo:hi]
+        if self.xl_comm is not None:            # a C-ABI call like any other: recorded into the plan as such
+            self._comm_ops.comm_allreduce(self.xl_comm, piece, hi - lo)
+            self._works.append(None)
+            self._slices.append((lo, hi))
+            return
         stream = torch.cuda.current_stream() if self.device.type == "cuda" else None      # the stream that finished the slice
 
         def issue():
@@ -293,6 +321,12 @@ class PretrainStep:
             assert lo == pos, (lo, pos)
             pos = hi
         assert pos == self.store.n_used, (pos, self.store.n_used)
+        if self.xl_comm is not None:
+            self.ops.comm_wait(self.xl_comm)        # the compute stream continues after every collective of this step
+            if self.comm_buf is not None:
+                n = self.store.n_used
+                self._comm_ops.cast_to_f32(self.comm_buf[:n], self.store.grad[:n], n)
+            return
         timed = self.device.type == "cuda"
 
         def wait_all():                         # the compute stream waits for every bucket (a host operation of a recorded plan)
