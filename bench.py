@@ -288,8 +288,9 @@ def main():
     torch.cuda.set_device(local)
     from xlxmert_amd.engine import reserve_streams
     torch.zeros(8, device=f"cuda:{local}").add_(1.0)          # main stream first, then the engine's three: one hardware queue each,
-    reserve_streams(f"cuda:{local}")                          # before RCCL's stream can take one of the four (engine.reserve_streams)
     grouped = world > 1 or os.environ.get("XL_FORCE_EXCHANGE", "0") == "1"    # (one-rank group: exercises the exchange on 1 GPU)
+    reserve_streams(f"cuda:{local}", comm=grouped and os.environ.get("XL_COMM") == "rccl")   # before RCCL's stream can take one of the
+                                                                                             # four (engine.reserve_streams)
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

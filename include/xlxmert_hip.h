@@ -359,8 +359,11 @@ int  xl_plan_destroy(int64_t plan);
  * contain them: one communicator per process, every collective on the communicator's OWN stream, ordered after everything
  * queued so far on `after_stream` (event record + wait, issued by the call), all asynchronous.
  *   xl_comm_unique_id(id128): rank 0 fills a 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
- *     (xlxmert_amd.trainer broadcasts it through torch.distributed);  xl_comm_init(id128, rank, nranks) -> handle (0 on error:
- *     collective over all ranks, each with its GPU current);  xl_comm_destroy.
+ *     (xlxmert_amd.trainer broadcasts it through torch.distributed);  xl_comm_init(id128, rank, nranks, comm_stream) -> handle
+ *     (0 on error: collective over all ranks, each with its GPU current).  comm_stream: the caller's stream for the collectives
+ *     (NULL: the library creates one) -- HIP binds a stream to one of its few hardware queues at FIRST USE, and a collective
+ *     stream that lands on a compute stream's queue blocks that stream's kernels behind its event waits (+2.6 ms per step
+ *     measured): create and first-use it together with the compute streams (engine.reserve_streams(comm=True)).  xl_comm_destroy.
  *   xl_comm_allreduce: buf (count elements of `dtype`, XL_F32 or XL_BF16) := sum over ranks, in place.
  *   xl_comm_reduce_scatter / xl_comm_allgather: the two halves (recv_count / send_count = elements per rank): rank r ends up
  *     with the sum of everybody's r-th piece / everybody ends up with every rank's piece.
@@ -369,7 +372,7 @@ int  xl_plan_destroy(int64_t plan);
  *   xl_comm_wait(comm, stream): `stream` continues after every collective issued so far.
  * RCCL is bound at run time (dlopen librccl.so.1): a process that never calls xl_comm_* does not need it. */
 int  xl_comm_unique_id(void* id128);
-int64_t xl_comm_init(const void* id128, int rank, int nranks);
+int64_t xl_comm_init(const void* id128, int rank, int nranks, void* comm_stream);
 int  xl_comm_destroy(int64_t comm);
 int  xl_comm_allreduce(int64_t comm, void* buf, int64_t count, int dtype, void* after_stream);
 int  xl_comm_reduce_scatter(int64_t comm, const void* send, void* recv, int64_t recv_count, int dtype, void* after_stream);

@@ -347,7 +347,7 @@ def test_exchange_on_one_rank_rccl_group_is_identity(via, plan, comm_dtype):
                           grad_comm_dtype=comm_dtype)
         assert tr.exchange and tr.world == 1 and (tr.xl_comm is not None) == (via == "rccl")
         got = run(tr)
-        assert len(tr._works) > 4, len(tr._works)
+        assert len(tr._slices) > 4, len(tr._slices)
         lo, hi = tr.store.language_range()
         assert any(lo <= a < hi for a, _ in tr._slices)
         if plan:

@@ -58,7 +58,8 @@ static const Rccl* rccl() {
 struct Comm {
     NcclComm comm = nullptr;
     int rank = 0, nranks = 1;
-    hipStream_t stream = nullptr;      // the collectives' own stream
+    hipStream_t stream = nullptr;      // the collectives' own stream (the caller's, or created here)
+    bool own_stream = false;
     hipEvent_t ev[64];                 // ring of "slice ready" events (a wait refers to the record that precedes it at enqueue time)
     unsigned next = 0;
     hipEvent_t done = nullptr;
@@ -100,7 +101,7 @@ extern "C" int xl_comm_unique_id(void* id128) {
     return XL_OK;
 }
 
-extern "C" int64_t xl_comm_init(const void* id128, int rank, int nranks) {
+extern "C" int64_t xl_comm_init(const void* id128, int rank, int nranks, void* comm_stream) {
     if (id128 == nullptr || nranks < 1 || rank < 0 || rank >= nranks) { set_error("xl_comm_init: bad arguments"); return 0; }
     const Rccl* r = rccl();
     if (r == nullptr) return 0;
@@ -110,7 +111,9 @@ extern "C" int64_t xl_comm_init(const void* id128, int rank, int nranks) {
     memcpy(&id, id128, sizeof id);
     const int rc = r->CommInitRank(&c->comm, nranks, id, rank);
     if (rc != 0) { set_error("xl_comm_init: RCCL error %d: %s", rc, r->GetErrorString(rc)); delete c; return 0; }
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = true;
+    if (comm_stream != nullptr) c->stream = (hipStream_t)comm_stream;
+    else { ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = ok; }
     for (int i = 0; i < 64 && ok; ++i) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { set_error("xl_comm_init: stream / event creation failed"); return 0; }
@@ -131,7 +134,7 @@ extern "C" int xl_comm_destroy(int64_t comm) {
     if (r != nullptr && c->comm != nullptr) (void)r->CommDestroy(c->comm);
     for (int i = 0; i < 64; ++i) (void)hipEventDestroy(c->ev[i]);
     (void)hipEventDestroy(c->done);
-    (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return XL_OK;
 }

@@ -41,9 +41,10 @@ class _Att:
 _RESERVED_STREAMS = {}
 
 
-def reserve_streams(device):
+def reserve_streams(device, comm=False):
     """The engine's three extra HIP streams (language stream + the two weight-gradient companions), created and FIRST USED
-    here.  HIP binds a stream to one of its few hardware queues (GPU_MAX_HW_QUEUES = 4) at first use, round-robin: with the
+    here.  comm=True: a fourth one for the library's own RCCL binding (xl_comm_*, trainer XL_COMM=rccl), reserved in the same breath
+    so that the collectives' event waits never sit in a compute stream's hardware queue (needs GPU_MAX_HW_QUEUES >= 5).  HIP binds a stream to one of its few hardware queues (GPU_MAX_HW_QUEUES = 4) at first use, round-robin: with the
     main stream these four must land on four different queues, or two of them serialise behind each other's barrier
     packets and the step loses its overlap (+3.3 ms measured).  Any stream that gets used in between shifts the assignment -
     RCCL's does: call this BEFORE torch.distributed.init_process_group (bench.py does; measured 24.4 -> 20.5 ms per step
@@ -57,7 +58,21 @@ def reserve_streams(device):
                 torch.zeros(8, device=dev).add_(1.0)
         torch.cuda.synchronize(dev)
         _RESERVED_STREAMS[key] = streams
-    return _RESERVED_STREAMS[key]
+    if comm and len(_RESERVED_STREAMS[key]) == 3:
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            torch.zeros(8, device=dev).add_(1.0)
+        torch.cuda.synchronize(dev)
+        _RESERVED_STREAMS[key].append(st)
+    return _RESERVED_STREAMS[key][:3]
+
+
+def comm_stream(device):
+    """the stream reserved for xl_comm_* collectives (reserve_streams(comm=True)), created now if nobody reserved it"""
+    dev = torch.device(device)
+    reserve_streams(dev, comm=True)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    return _RESERVED_STREAMS[key][3]
 
 
 class SelfAttBlock:

@@ -192,7 +192,9 @@ class PretrainStep:
         t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.device)
         dist.broadcast(t, src=0)
         idbuf = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
-        h = int(lib.raw("xl_comm_init")(ctypes.addressof(idbuf), self.rank, self.world))
+        from .engine import comm_stream
+        self._comm_stream = comm_stream(self.device)           # (kept alive: the library holds its raw handle)
+        h = int(lib.raw("xl_comm_init")(ctypes.addressof(idbuf), self.rank, self.world, self._comm_stream.cuda_stream))
         if h <= 0:
             raise RuntimeError("xl_comm_init failed: " + lib.raw("xl_last_error")().decode())
         return h
@@ -271,8 +273,11 @@ class PretrainStep:
     # asynchronous all-reduce of that contiguous slice is queued (RCCL runs it on its own stream behind an event recorded
     # on the reporting stream), overlapping with the rest of backward.  Every rank queues the same slices in the same
     # order (the order is a function of the model layout only).
-    def _begin_exchange(self):
-        self._lanes, self._works, self._slices = {}, [], []
+    def _begin_exchange(self, replay=False):
+        """replay: a recorded plan re-issues the collectives of the step it was recorded from (same slices, same order)"""
+        self._works = []
+        if not replay:
+            self._lanes, self._slices = {}, []
 
     def _host_op(self, fn):
         """run `fn` now and, while a launch plan is being recorded, make it a host operation of the plan (replayed between
@@ -463,7 +468,7 @@ class PretrainStep:
         plan = self._plans.get(key)
         if plan is not None:
             if self.exchange:
-                self._begin_exchange()          # (the recorded host operations append to this replay's work list)
+                self._begin_exchange(replay=True)       # (the recorded host operations append to this replay's work list)
             plan.run()
             HipOps._bound = None                # (the replay ends in whichever context its last recorded bind named)
             self.t += 1
