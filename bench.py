@@ -273,10 +273,14 @@ def main():
     os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or os.environ.get("XL_FORCE_EXCHANGE", "0") == "1":
-        # RCCL's stream needs a hardware queue of its own: on HIP's default 4 it shares one with a compute stream, whose
-        # kernels then queue behind the collective's barrier packets (22.5 ms per step against 21.3 with 8 queues, measured
-        # with the exchange on a one-rank group; without a process group 4 queues are the better setting).  Read at HIP init.
+    torch_issues = os.environ.get("XL_COMM", "rccl") == "torch" or args.backend != "nccl"
+    if (world > 1 or os.environ.get("XL_FORCE_EXCHANGE", "0") == "1") and torch_issues:
+        # torch.distributed's RCCL stream needs a hardware queue of its own: on HIP's default 4 it shares one with a compute
+        # stream, whose kernels then queue behind the collective's barrier packets (22.5 ms per step against 21.3 with 8
+        # queues, measured with the exchange on a one-rank group).  The library's own binding (xl_comm_*, the default with the
+        # nccl backend) runs the collectives on a stream that owns one of the four default queues already, and more queues
+        # than streams that need them only cost (every further active queue: +3 ms per step measured): default 4 there.
+        # Read at HIP init.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,8 +293,8 @@ def main():
     from xlxmert_amd.engine import reserve_streams
     torch.zeros(8, device=f"cuda:{local}").add_(1.0)          # main stream first, then the engine's three: one hardware queue each,
     grouped = world > 1 or os.environ.get("XL_FORCE_EXCHANGE", "0") == "1"    # (one-rank group: exercises the exchange on 1 GPU)
-    reserve_streams(f"cuda:{local}", comm=grouped and os.environ.get("XL_COMM") == "rccl")   # before RCCL's stream can take one of the
-                                                                                             # four (engine.reserve_streams)
+    reserve_streams(f"cuda:{local}", comm=grouped and os.environ.get("XL_COMM_STREAM") == "own")   # before RCCL's stream can take one
+                                                                                                   # of the four (engine.reserve_streams)
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

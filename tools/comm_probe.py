@@ -8,7 +8,7 @@ import torch.distributed as dist
 from xlxmert_amd.engine import reserve_streams
 torch.cuda.set_device(0)
 torch.zeros(8, device="cuda").add_(1.0)
-reserve_streams("cuda:0", comm=os.environ.get("XL_COMM") == "rccl")
+reserve_streams("cuda:0", comm=os.environ.get("XL_COMM_STREAM") == "own")
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=torch.device("cuda:0"))
 from xlxmert_amd.config import XLxmertConfig
 from xlxmert_amd.trainer import PretrainStep, synthetic_batch

@@ -11,6 +11,7 @@
 // the call is issued, and the compute stream waits for all of them with xl_comm_wait -- neither compute stream ever blocks on a
 // collective it does not need.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -146,6 +147,8 @@ extern "C" int xl_comm_allreduce(int64_t comm, void* buf, int64_t count, int dty
     XL_CHECK_ARG(buf != nullptr && count > 0 && nccl_type(dtype) >= 0, XL_ERR_BAD_ARG, "xl_comm_allreduce: bad arguments");
     int rc = order_after(c, (hipStream_t)after_stream, "xl_comm_allreduce");
     if (rc) return rc;
+    static const bool skip1 = getenv("XL_COMM_SKIP_SINGLE") != nullptr;       // diagnostic: stream plumbing without the RCCL launch
+    if (skip1 && c->nranks == 1) return XL_OK;
     XL_NCCL(r->AllReduce(buf, buf, (size_t)count, nccl_type(dtype), NCCL_SUM, c->comm, c->stream), "xl_comm_allreduce");
     return XL_OK;
 }

@@ -50,15 +50,15 @@ class HipOps:
     def rebind(self):
         """bind this object's context unconditionally (first entry of a recorded launch plan; after a plan replay, whose last
         recorded bind -- possibly another object's -- is the one in effect)."""
-        HipOps._bound = None
-        self._call("xl_ctx_bind", self.ctx)
+        HipOps._bound = self.ctx
+        self.lib.call("xl_ctx_bind", self.ctx)
 
     def __del__(self):
-        try:
+        try:                             # raw calls: a collection that happens while a plan is being recorded must not end up in it
             if HipOps._bound == self.ctx:
-                self.lib.call("xl_ctx_bind", 0)
+                self.lib.raw("xl_ctx_bind")(0)
                 HipOps._bound = None
-            self.lib.call("xl_ctx_destroy", self.ctx)
+            self.lib.raw("xl_ctx_destroy")(self.ctx)
         except Exception:
             pass
 

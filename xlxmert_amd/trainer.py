@@ -134,13 +134,20 @@ class PretrainStep:
             if isinstance(self.ops, HipOps) and self.ops.dtype != torch.bfloat16:
                 self._comm_ops = HipOps(torch.bfloat16)
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // (2 if self.comm_buf is not None else 4))
-        # XL_COMM=rccl: the collectives go through the library's own RCCL binding (xl_comm_*, csrc/comm.hip) instead of
-        # torch.distributed -- they are then ordinary entries of the launch plan (one xl_plan_run per step, no host operation
-        # in between).  Opt-in: like the torch path it has only ever met one rank on hardware.
+        # Who issues the collectives.  "rccl" (default with the nccl backend): the library's own RCCL binding (xl_comm_*,
+        # csrc/comm.hip) -- the collectives are ordinary entries of the launch plan (one xl_plan_run per step) and run on a stream
+        # that already owns a hardware queue.  "torch": torch.distributed (any backend; host operations between plan segments;
+        # its NCCL stream is a fifth hardware queue).  XL_COMM overrides; a binding that fails its start-up self-test falls back.
         self.xl_comm = None
-        if (self.exchange and os.environ.get("XL_COMM", "torch") == "rccl" and isinstance(self.ops, HipOps)
-                and self.device.type == "cuda" and dist.get_backend() == "nccl"):
-            self.xl_comm = self._init_xl_comm()
+        want = os.environ.get("XL_COMM", "rccl")
+        if (self.exchange and want == "rccl" and isinstance(self.ops, HipOps) and self.device.type == "cuda"
+                and dist.get_backend() == "nccl"):
+            try:
+                self.xl_comm = self._init_xl_comm()
+            except Exception as e:                   # (no librccl.so.1, an RCCL error at init, a wrong sum: keep torch's path)
+                import warnings
+                warnings.warn(f"xl_comm_* unavailable ({e}); the gradient exchange goes through torch.distributed")
+                self.xl_comm = None
         self.exposed_comm_ms = []              # per step: time the main stream waited for collectives after backward
         env = os.environ.get("XL_PLAN")
         self.plan_mode = bool(int(env)) if env else bool(plan)
@@ -192,11 +199,25 @@ class PretrainStep:
         t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.device)
         dist.broadcast(t, src=0)
         idbuf = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+        # the collectives' stream.  Default: the language stream's weight-gradient companion -- one of the four streams that own a
+        # hardware queue already (a FIFTH active queue costs the step 3-6 ms whatever sits in it, measured with the RCCL launch
+        # itself skipped), idle most of the step, and never on the visual critical path.  XL_COMM_STREAM=own: a stream of its own.
         from .engine import comm_stream
-        self._comm_stream = comm_stream(self.device)           # (kept alive: the library holds its raw handle)
+        if os.environ.get("XL_COMM_STREAM", "dw") == "own" or self.engine._dw is None:
+            self._comm_stream = comm_stream(self.device)       # (kept alive: the library holds its raw handle)
+        else:
+            self._comm_stream = self.engine._dw["l"]
         h = int(lib.raw("xl_comm_init")(ctypes.addressof(idbuf), self.rank, self.world, self._comm_stream.cuda_stream))
         if h <= 0:
             raise RuntimeError("xl_comm_init failed: " + lib.raw("xl_last_error")().decode())
+        # self-test: every rank contributes rank + 1; the sum must be world (world + 1) / 2 on every rank
+        probe = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device=self.device)
+        self._comm_ops.comm_allreduce(h, probe, probe.numel())
+        self._comm_ops.comm_wait(h)
+        torch.cuda.synchronize(self.device)
+        want = self.world * (self.world + 1) / 2
+        if not bool((probe == want).all()):
+            raise RuntimeError(f"xl_comm self-test: all-reduce gave {probe[0].item()} instead of {want}")
         return h
 
     def _wait_params(self, key):
