@@ -254,6 +254,12 @@ int xl_sdpa_bwd(const void* q, const void* k, const void* v, const uint8_t* key_
                 int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
                 float p_drop, uint64_t seed, float* bias_grad, float* workspace,
                 const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded, int dtype, void* stream);
+/* Attention probabilities of one attention block, for LxmertModel.forward(output_attentions=True) (HF:691-704, 238-266: the
+ * softmax AFTER its dropout): probs fp32 [B, H, nq, nk] (dense, also for packed rows: queries / keys beyond an example's length
+ * and masked keys give zeros), recomputed from q, k and the lse that xl_sdpa_fwd saved -- the fused forward never stores them. */
+int xl_attn_probs(const void* q, const void* k, const uint8_t* key_mask, const float* lse, float* probs,
+                  int B, int H, int nq, int nk, int dh, int ldq, int ldk, float scale, float p_drop, uint64_t seed,
+                  const int* q_rowoff, const int* k_rowoff, int dtype, void* stream);
 /* bias_grad (optional, fp32 [3*H*dh]): bias_grad[q | k | v] += column sums of dq / dk / dv over all B*n rows - the bias
  * gradients of the query/key/value projections (HF:232-239 nn.Linear) - from per-token scalars inside the kernel, without
  * re-reading dq/dk/dv; `workspace` as for xl_colsum (the second stage obeys xl_set_deferred_reduce). */

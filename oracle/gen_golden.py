@@ -556,6 +556,32 @@ def gen_embeds(name, cfg, seed, B, L, grid):
     print(name, "loss", float(loss), "n_grads", len(grads))
 
 
+def gen_attn(name, cfg, seed, B, L, grid):
+    """LxmertModel.forward(output_attentions=True) (HF:691-704, 498-557): the attention probabilities HF's encoder collects --
+    language_attentions (one [B,H,L,L] per language layer), vision_attentions ([B,H,V,V] per visual layer, with a ragged
+    visual_attention_mask) and cross_encoder_attentions ([B,H,L,V] per cross layer: language queries over visual keys)."""
+    torch.manual_seed(0)
+    m, sd = build_reference(cfg, seed)
+    inp = O.make_inputs(cfg, seed + 1, B, L, grid)
+    g = torch.Generator().manual_seed(seed + 2)
+    V = grid * grid
+    feats = torch.randn(B, V, cfg.visual_feat_dim, generator=g)
+    n_keep = torch.randint(V // 2, V + 1, (B,), generator=g)
+    vmask = (torch.rand(B, V, generator=g).argsort(1).argsort(1) < n_keep[:, None]).long()
+    with torch.no_grad():
+        bo = m.bert(input_ids=inp["input_ids"], visual_feats=feats, visual_pos=inp["visual_pos"], attention_mask=inp["attention_mask"],
+                    visual_attention_mask=vmask, token_type_ids=inp["token_type_ids"], output_attentions=True, return_dict=True)
+    d = dict(seed=np.array(seed), **cfg_fields(cfg), **np_inputs(inp), in_visual_feats=feats.numpy(), in_visual_attention_mask=vmask.numpy(),
+             lang=bo.language_output.numpy(), vis=bo.vision_output.numpy(), pooled=bo.pooled_output.numpy())
+    for key, tup in (("lang_att", bo.language_attentions), ("vis_att", bo.vision_attentions), ("x_att", bo.cross_encoder_attentions)):
+        d["n_" + key] = np.array(len(tup))
+        for i, a in enumerate(tup):
+            d[f"{key}{i}"] = a.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, {k: int(d["n_" + k]) for k in ("lang_att", "vis_att", "x_att")}, bo.language_attentions[0].shape,
+          bo.vision_attentions[0].shape, bo.cross_encoder_attentions[0].shape)
+
+
 def gen_ckpt(name, cfg, seed, B, L, grid):
     """a checkpoint as the REFERENCE writes it -- `torch.save(self.model.state_dict(), "%s_LXRT.pth")` of the
     DDP-wrapped model (ref pretrain/lxmert_pretrain.py:675-677, :102-106), i.e. the reference model's own `state_dict()` with
@@ -596,6 +622,11 @@ def gen_ckpt(name, cfg, seed, B, L, grid):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
+    if only == ["attn"]:
+        gen_attn("attn_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
+                 num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
+                 num_clusters=50), seed=5150, B=3, L=8, grid=4)
+        sys.exit(0)
     if only == ["ckpt"]:
         gen_ckpt("ckpt_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, vocab_size=100, hidden_size=64,
                  num_attention_heads=4, intermediate_size=128, max_position_embeddings=32, visual_feat_dim=32,
@@ -641,3 +672,4 @@ if __name__ == "__main__":
     gen_nlvr2("nlvr2_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=1357, P=3, L=8, grid=4)
     gen_embeds("embeds_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=8024, B=3, L=8, grid=4)
     gen_ckpt("ckpt_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=3141, B=3, L=8, grid=4)
+    gen_attn("attn_tiny", O.OracleConfig(l_layers=2, x_layers=2, r_layers=2, **tiny), seed=5150, B=3, L=8, grid=4)

@@ -299,6 +299,18 @@ class FakeOps:
         out = (torch.softmax(s, -1) * self._pmask(B, H, nq, nk, p_drop, self._seed(seed))) @ V_
         self._store(o, out, B, nq, H, dh, ldo, q_off, q_pad)
 
+    def attn_probs(self, q, k, key_mask, lse, probs, B, H, nq, nk, dh, ldq, ldk, scale, p_drop=0.0, seed=0, q_off=None, k_off=None):
+        (Q, qv), (K_, kv) = self._load(q, B, nq, H, dh, ldq, q_off), self._load(k, B, nk, H, dh, ldk, k_off)
+        p = torch.exp(Q @ K_.transpose(-1, -2) * scale - lse.view(B, H, nq, 1))
+        if key_mask is not None:
+            p = p.masked_fill(key_mask.view(B, 1, 1, nk) == 0, 0.0)
+        if kv is not None:
+            p = p.masked_fill(~kv.view(B, 1, 1, nk), 0.0)
+        if qv is not None:
+            p = p.masked_fill(~qv.view(B, 1, nq, 1), 0.0)
+        p = torch.nan_to_num(p, nan=0.0, posinf=0.0)
+        probs.view(B, H, nq, nk).copy_(p * self._pmask(B, H, nq, nk, p_drop, self._seed(seed)))
+
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
                  lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None, q_off=None, k_off=None, q_pad=0, k_pad=0):
         (Q, qv), (K_, kv), (V_, _), (dO, _) = (self._load(t, B, n, H, dh, ld, off) for t, n, ld, off in

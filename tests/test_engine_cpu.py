@@ -571,3 +571,34 @@ def test_packed_language_rows_equal_the_dense_path(monkeypatch, row_pad):
         assert maxdiff(a[real], b[real]) < 2e-6 and b[~real].abs().max().item() == 0.0
     assert maxdiff(ls0, ls1) < 1e-6
     assert maxdiff(g0, g1) < 5e-6, maxdiff(g0, g1)
+
+
+def check_attention_probs(g, eng, tol):
+    """Engine.attention_probs() against the reference's LxmertModel(output_attentions=True) (fixture attn_tiny): per language
+    layer [B,H,L,L], per visual layer [B,H,V,V] (ragged visual mask), per cross layer [B,H,L,V]; rows of [PAD] queries are
+    excluded (the reference leaves don't-care values there, the packed path zeros)."""
+    t = lambda k: torch.from_numpy(g[k]).to(eng.dev)
+    eng.encoder_forward(want_pooled=True)
+    la, va, xa = eng.attention_probs()
+    assert (len(la), len(va), len(xa)) == (int(g["n_lang_att"]), int(g["n_vis_att"]), int(g["n_x_att"]))
+    real = t("in_attention_mask").bool()                       # [B, L]
+    for i, a in enumerate(la):
+        ref = t(f"lang_att{i}")
+        m = real[:, None, :, None].expand_as(ref)
+        assert maxdiff(a[m], ref[m]) < tol, ("lang", i)
+        assert a.shape == ref.shape and abs(a.sum(-1)[real[:, None, :].expand(-1, a.shape[1], -1)] - 1).max().item() < 10 * tol
+    for i, a in enumerate(va):
+        assert maxdiff(a, t(f"vis_att{i}")) < tol, ("vis", i)
+    for i, a in enumerate(xa):
+        ref = t(f"x_att{i}")
+        m = real[:, None, :, None].expand_as(ref)
+        assert maxdiff(a[m], ref[m]) < tol, ("cross", i)
+
+
+@pytest.mark.parametrize("pack", [False, True])
+def test_attention_probs_match_reference(pack, monkeypatch):
+    monkeypatch.setenv("XL_PACK_LANG", "1" if pack else "0")
+    g = load_golden("attn_tiny")
+    eng = make_vismask_engine(g, FakeOps(torch.float32))
+    assert eng.packed == pack
+    check_attention_probs(g, eng, 2e-6)

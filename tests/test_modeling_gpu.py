@@ -384,3 +384,28 @@ def test_reference_written_checkpoint_through_the_module_api(tmp_path):
     assert set(back) == set(sd)
     for k, v in sd.items():
         assert torch.equal(back[k], v), k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_output_attentions_through_the_module_api(dtype, tol):
+    """LxmertModel.forward(output_attentions=True) (HF:691-704): language / vision / cross-encoder attention probabilities with
+    HF's field names, tuple position and shapes, against the reference's own outputs (fixture attn_tiny); hidden states and
+    attentions together in the tuple form."""
+    g = load_golden("attn_tiny")
+    m, oc, sd = make_model(g, dtype)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    kw = dict(input_ids=t("in_input_ids"), visual_feats=t("in_visual_feats").to(dtype), visual_pos=t("in_visual_pos"),
+              attention_mask=t("in_attention_mask"), visual_attention_mask=t("in_visual_attention_mask"),
+              token_type_ids=t("in_token_type_ids"))
+    with torch.no_grad():
+        out = m.bert(output_attentions=True, **kw)
+        tup = m.bert(output_attentions=True, output_hidden_states=True, return_dict=False, **kw)
+    assert len(tup) == 8 and len(tup[5]) == int(g["n_lang_att"]) and len(tup[6]) == int(g["n_vis_att"]) and len(tup[7]) == int(g["n_x_att"])
+    real = t("in_attention_mask").bool()
+    assert maxdiff(out.vision_output.float().cpu(), g["vis"]) < (1e-4 if dtype == torch.float32 else 0.15)
+    for name, got in (("lang_att", out.language_attentions), ("vis_att", out.vision_attentions), ("x_att", out.cross_encoder_attentions)):
+        for i, a in enumerate(got):
+            ref = t(f"{name}{i}")
+            assert a.shape == ref.shape and a.dtype == torch.float32
+            msk = torch.ones_like(ref, dtype=torch.bool) if name == "vis_att" else real[:, None, :, None].expand_as(ref)
+            assert maxdiff(a[msk].cpu(), ref[msk].cpu()) < tol, (name, i)

@@ -150,6 +150,44 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
     }
 }
 
+// attention probabilities of one layer, recomputed from the saved log-sum-exp (LxmertModel.forward(output_attentions=True),
+// HF:238-266 returns softmax(scores) AFTER its dropout): probs[b, h, q, key] fp32, dense [B, H, nq, nk] whatever the row
+// packing; rows of queries / columns of keys beyond a packed example's length and masked keys are zeros.  Not on the hot path.
+template <typename T>
+__global__ __launch_bounds__(64) void attn_probs_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const uint8_t* __restrict__ key_mask, const float* __restrict__ lse,
+                                                        float* __restrict__ probs, int H, int nq, int nk, int dh, int ldq, int ldk,
+                                                        float scale, float p_drop, float inv_keep, uint64_t seed,
+                                                        const uint64_t* __restrict__ step_seed, VarLen vl) {
+    seed = with_step_seed(seed, step_seed);
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int qi = threadIdx.x;
+    const int nq_cap = nq, nk_cap = nk;
+    if (qi >= nq_cap) return;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    float* out = probs + ((size_t)bh * nq_cap + qi) * nk_cap;
+    if (qi >= nq) {
+        for (int j = 0; j < nk_cap; ++j) out[j] = 0.f;
+        return;
+    }
+    const T* qr = q + (size_t)(q0 + qi) * ldq + h * dh;
+    float qv[MAXN];
+    for (int d = 0; d < dh; ++d) qv[d] = Elem<T>::ld(qr + d);
+    const float l = lse[(size_t)bh * nq_cap + qi];
+    for (int j = 0; j < nk_cap; ++j) {
+        float p = 0.f;
+        if (j < nk && (key_mask == nullptr || key_mask[b * nk_cap + j] != 0)) {
+            const T* kr = k + (size_t)(k0 + j) * ldk + h * dh;
+            float s0 = 0.f;
+            for (int d = 0; d < dh; ++d) s0 = fmaf(qv[d], Elem<T>::ld(kr + d), s0);
+            p = expf(s0 * scale - l);
+            if (p_drop > 0.f) p *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)j, p_drop, inv_keep);
+        }
+        out[j] = p;
+    }
+}
+
 // ================================================================== bf16 MFMA kernels
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4bf16s_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 v8bf16s_t;
@@ -688,5 +726,26 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
         if (rc2 == XL_OK) rc2 = xl_colsum(dv, bias_grad + 2 * HD, rk, HD, lddv, workspace ? workspace + 2730 * (size_t)HD : nullptr, dtype, stream);
         return rc2;
     }
+    return XL_OK;
+}
+
+extern "C" int xl_attn_probs(const void* q, const void* k, const uint8_t* key_mask, const float* lse, float* probs,
+                             int B, int H, int nq, int nk, int dh, int ldq, int ldk, float scale, float p_drop, uint64_t seed,
+                             const int* q_rowoff, const int* k_rowoff, int dtype, void* stream) {
+    SdpaArgs a = {};
+    a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.dh = dh; a.p_drop = p_drop;
+    int rc = check_common(a, dtype, "xl_attn_probs");
+    if (rc) return rc;
+    XL_CHECK_ARG(q && k && lse && probs, XL_ERR_BAD_ARG, "xl_attn_probs: null pointer");
+    const VarLen vl{q_rowoff, k_rowoff, 0, 0};
+    const float inv_keep = 1.0f / (1.0f - p_drop);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XL_BF16)
+        hipLaunchKernelGGL((attn_probs_kernel<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k, key_mask, lse,
+                           probs, H, nq, nk, dh, ldq, ldk, scale, p_drop, inv_keep, seed, ctx().step_seed, vl);
+    else
+        hipLaunchKernelGGL((attn_probs_kernel<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k, key_mask, lse,
+                           probs, H, nq, nk, dh, ldq, ldk, scale, p_drop, inv_keep, seed, ctx().step_seed, vl);
+    XL_CHECK_LAUNCH();
     return XL_OK;
 }

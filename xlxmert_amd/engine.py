@@ -118,6 +118,17 @@ class SelfAttBlock:
         ops.layernorm_fwd(z, p.g, p.b, y, self.mean, self.rstd, M, d, e.eps)
         self.x = x
 
+    def probs(self):
+        """attention probabilities [B, H, n, n] fp32 of the last forward (after dropout, as HF returns them)"""
+        e, d, M = self.e, self.e.d, self.M
+        qkv = self.qkv[:M]
+        out = torch.zeros(e.B, e.H, self.n, self.n, dtype=torch.float32, device=e.dev)
+        km, vl = self._att_args()
+        vl = {k: v for k, v in vl.items() if k in ("q_off", "k_off")}
+        e.ops.attn_probs(qkv, qkv[:, d:], km, self.lse, out, e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, e.scale, e.p_attn,
+                         e.seed(self.site), **vl)
+        return out
+
     def bwd(self, dy, dx):
         e, p, d, M = self.e, self.p, self.e.d, self.M
         ops = e.ops
@@ -263,6 +274,18 @@ class CrossAttBlock:
                  p_drop=e.p_hid, seed=e.seed(self.site + 2))
         ops.layernorm_fwd(self.z[:M], p.g, p.b, Y[:M], self.mean[:M], self.rstd[:M], M, d, e.eps)
         self.X = X
+
+    def probs(self):
+        """cross-attention probabilities of the LANGUAGE queries over the visual keys, [B, H, L, V] fp32 -- what
+        LxmertXLayer.forward hands out as its attention output (HF:417-449: `attention_probs = lang_att_output[1:]`)"""
+        e, d = self.e, self.e.d
+        assert self.need_lang, "this cross layer skipped its language direction (dead-branch elimination)"
+        qkv_l, qkv_v = e.lr(self.qkv), e.vr(self.qkv)
+        out = torch.zeros(e.B, e.H, e.L, e.V, dtype=torch.float32, device=e.dev)
+        vl = {k: v for k, v in self._lq().items() if k == "q_off"}
+        e.ops.attn_probs(qkv_l, qkv_v[:, d:], e.vkmask, self.lse_l, out, e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, e.scale, e.p_attn,
+                         e.seed(self.site), **vl)
+        return out
 
     def bwd(self, dY, dX):
         e, p, d = self.e, self.p, self.e.d
@@ -1067,6 +1090,17 @@ class Engine:
         if self.packed:                 # packed language rows -> the dense [B*L, d] layout, zero rows at the [PAD] positions
             lang = [self._dense_lang(t) for t in lang]
         return lang, vis
+
+    def attention_probs(self):
+        """(language_attentions, vision_attentions, cross_encoder_attentions) of the last encoder_forward, as HF's LxmertEncoder
+        collects them (HF:498-557): one [B, H, L, L] per language layer, one [B, H, V, V] per visual layer, one [B, H, L, V]
+        (language queries over visual keys) per cross layer.  Recomputed from the saved q / k / log-sum-exp: the fused attention
+        kernels never store them, and nothing on the training path asks for them."""
+        with Engine._Seeded(self):
+            lang = [sa.probs() for sa, _ in self.lang_layers]
+            vis = [sa.probs() for sa, _ in self.vis_layers]
+            cross = [blk["cross"].probs() for blk in self.x_layers]
+        return lang, vis, cross
 
     def _dense_lang(self, t, out=None):
         """packed language rows -> dense [B*L, d] (zero rows where the attention mask is 0)"""

@@ -32,6 +32,7 @@ class LxmertModelOutput(tuple):
         obj = super().__new__(cls, (lang, vis, pooled))
         obj.language_output, obj.vision_output, obj.pooled_output = lang, vis, pooled
         obj.language_hidden_states, obj.vision_hidden_states = None, None        # filled when output_hidden_states is asked for
+        obj.language_attentions, obj.vision_attentions, obj.cross_encoder_attentions = None, None, None      # output_attentions
         return obj
 
 
@@ -119,8 +120,6 @@ class LxmertModel(_Named):
             raise ValueError("`visual_feats` cannot be `None`")
         if visual_pos is None:
             raise ValueError("`visual_pos` cannot be `None`")
-        if output_attentions:
-            raise NotImplementedError("attention maps are not materialised by the fused attention kernels")
         B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]          # HF:735-741
         V = visual_feats.shape[1]
         eng = self._engine_for(B, L, V)
@@ -137,10 +136,17 @@ class LxmertModel(_Named):
             lh, vh = eng.hidden_states()
             out.language_hidden_states = tuple(h.view(B, L, -1).detach().clone() for h in lh)
             out.vision_hidden_states = tuple(h.view(B, V, -1).detach().clone() for h in vh)
+        if output_attentions:           # HF:806-822; fp32 [B, H, nq, nk] copies without a gradient path, recomputed on demand
+            la, va, xa = eng.attention_probs()
+            out.language_attentions, out.vision_attentions, out.cross_encoder_attentions = tuple(la), tuple(va), tuple(xa)
         if return_dict in (None, True):
             return out
         t = tuple(out)
-        return t + (out.language_hidden_states, out.vision_hidden_states) if output_hidden_states else t
+        if output_hidden_states:
+            t = t + (out.language_hidden_states, out.vision_hidden_states)
+        if output_attentions:
+            t = t + (out.language_attentions, out.vision_attentions, out.cross_encoder_attentions)
+        return t
 
 
 LXRTModel = LxmertModel          # legacy names (original LXMERT code base / BASELINE.json wording)

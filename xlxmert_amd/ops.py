@@ -259,6 +259,11 @@ class HipOps:
                    lddk, lddv, float(scale), float(p_drop), int(seed), self._p(bias_grad), self._p(ws), self._p(q_off),
                    self._p(k_off), int(q_pad), int(k_pad), self.dt, self._stream())
 
+    def attn_probs(self, q, k, key_mask, lse, probs, B, H, nq, nk, dh, ldq, ldk, scale, p_drop=0.0, seed=0, q_off=None, k_off=None):
+        """probs fp32 [B, H, nq, nk] := softmax (after dropout) of one attention block, from q, k and the saved lse."""
+        self._call("xl_attn_probs", self._p(q), self._p(k), self._p(key_mask), self._p(lse), self._p(probs), B, H, nq, nk, dh,
+                   ldq, ldk, float(scale), float(p_drop), int(seed), self._p(q_off), self._p(k_off), self.dt, self._stream())
+
     # -- head losses
     def mask_counts(self, labels, vis_mask, counts, nmask, B, V):
         self._call("xl_mask_counts", self._p(labels), self._p(vis_mask), self._p(counts), self._p(nmask), B, V,
