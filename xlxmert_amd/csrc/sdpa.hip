@@ -211,6 +211,14 @@ __device__ __forceinline__ bf16x8_t gfrag(const bf16_t* __restrict__ base, int l
     return f;
 }
 
+// key mask of one batch element as a 64-bit word (bit = key attends): ONE byte load per lane + a ballot, instead of a
+// dependent byte load per accumulator register (32 serialised round trips per wave and phase)
+__device__ __forceinline__ uint64_t key_bits(const uint8_t* __restrict__ key_mask, int base, int nk_cap, int lane) {
+    if (key_mask == nullptr) return ~0ull;
+    const bool on = lane < nk_cap && key_mask[base + lane] != 0;
+    return __ballot(on);
+}
+
 // (the transposed-operand gathers and the K-major fragments below both read tiles staged ONCE per problem with coalesced
 //  16-byte loads: per-lane strided global fragment loads touch 64 cache lines per instruction and were ~6x slower)
 // SW (backward kernel, DH = 64): no row padding -- 128-byte rows whose 16-byte chunk c sits at chunk c ^ ((row >> 1) & 7), the
@@ -228,19 +236,32 @@ template <int DH, bool SW = false> struct Tile {
     }
 };
 
-// stage rows [0,64) x [0,DH) of a [n, ld] matrix (head slice at column c0) into an LDS tile; rows >= n and
-// columns >= DH are zero.
-template <int DH, int ROWS = MAXN, bool SW = false>
-__device__ __forceinline__ void stage_tile(uint8_t* tile, const bf16_t* __restrict__ base, int ld, int n, int c0, int lane,
-                                           int nthr = 64) {
-    constexpr int CH = Tile<DH, SW>::DHP / 8;           // 16-byte chunks per row
-    for (int idx = lane; idx < ROWS * CH; idx += nthr) {
-        const int row = idx / CH, c = idx % CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < n && c * 8 < DH) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c0 + c * 8);
-        *reinterpret_cast<uint4*>(tile + Tile<DH, SW>::off(row, c * 8)) = v;
+// stage rows [0,ROWS) x [0,DH) of a [n, ld] matrix (head slice at column c0) into an LDS tile; rows >= n and
+// columns >= DH are zero.  Two halves, so that a kernel can issue the loads of ALL its tiles before it waits for any of
+// them: as one loop (load, wait, write) the compiler kept a single 16-byte load in flight per thread, and the 12 dependent
+// round trips of the backward's three tiles were most of its 21 us "load and stage" phase.
+template <int DH, int ROWS, int NTHR, bool SW = false>
+struct TileStage {
+    static constexpr int CH = Tile<DH, SW>::DHP / 8;           // 16-byte chunks per row
+    static constexpr int NIT = (ROWS * CH + NTHR - 1) / NTHR;
+    uint4 v[NIT];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int n, int c0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx / CH, c = idx % CH;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (idx < ROWS * CH && row < n && c * 8 < DH) v[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c0 + c * 8);
+        }
     }
-}
+    __device__ __forceinline__ void store(uint8_t* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * NTHR;
+            if (idx < ROWS * CH) *reinterpret_cast<uint4*>(tile + Tile<DH, SW>::off(idx / CH, (idx % CH) * 8)) = v[i];
+        }
+    }
+};
 
 // K-major fragment from a staged tile: row `row`, 8 features at d = s*16 + (lane>>5)*8 (rows >= n are zero in the tile)
 template <int DH, bool SW = false>
@@ -283,21 +304,29 @@ __device__ __forceinline__ bf16x8_t acc_to_frag(const f32x16_t& a, int u) {
     return f;
 }
 
-// store an "X^T" accumulator pair as rows of X: lane owns sequence row (l&31), 4 consecutive features per register quad
+// store an "X^T" accumulator (MFMA rows = features d0 .. d0+31, columns = sequence rows) as rows of X.  A lane owns sequence
+// row (l&31) and, per register quad g, the 4 consecutive features 8g + 4*(l>>5) ..: the two half-waves hold the two halves of
+// every 8-feature group, so they trade quads (v_permlane32_swap) -- the low half ends up with the whole groups 0 and 2, the
+// high half with 1 and 3 -- and each lane writes two 16-byte segments instead of four 8-byte ones (the store tail of these
+// kernels is issue-bound: half the store instructions).
 template <int DH>
 __device__ __forceinline__ void store_rows(const f32x16_t& a, bf16_t* __restrict__ base, int ld, int row, int nrows, int c0,
                                            int d0, int lane, float mul) {
-    if (row >= nrows) return;
     const int hi = lane >> 5;
+    uint32_t w[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int d = d0 + 8 * g + 4 * hi;
-        if (d < DH) {
-            uint2 w;
-            w.x = pack2bf(a[4 * g] * mul, a[4 * g + 1] * mul);
-            w.y = pack2bf(a[4 * g + 2] * mul, a[4 * g + 3] * mul);
-            *reinterpret_cast<uint2*>(base + (size_t)row * ld + c0 + d) = w;
-        }
+        w[g][0] = pack2bf(a[4 * g] * mul, a[4 * g + 1] * mul);
+        w[g][1] = pack2bf(a[4 * g + 2] * mul, a[4 * g + 3] * mul);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {          // group pair (2p, 2p+1)
+        const auto x = __builtin_amdgcn_permlane32_swap(w[2 * p][0], w[2 * p + 1][0], false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(w[2 * p][1], w[2 * p + 1][1], false, false);
+        // low half: {own quad of group 2p, partner's quad of 2p}; high half: {partner's quad of 2p+1, own quad of 2p+1}
+        const int d = d0 + 8 * (2 * p + hi);
+        if (row < nrows && d < DH)
+            *reinterpret_cast<uint4*>(base + (size_t)row * ld + c0 + d) = make_uint4(x[0], y[0], x[1], y[1]);
     }
 }
 
@@ -320,18 +349,30 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
     const bf16_t* qb = q + (size_t)q0 * ldq;
     const bf16_t* kb = k + (size_t)k0 * ldk;
     const bf16_t* vb = v + (size_t)k0 * ldv;
-    stage_tile<DH, NKF * 32>(vt, vb, ldv, nk, h * DH, tid, NQF * 64);
+    TileStage<DH, NKF * 32, NQF * 64> sv;
+    sv.load(vb, ldv, nk, h * DH, tid);
 
     // S^T[key][q] for this wave's queries
     f32x16_t st[NKF];
 #pragma unroll
     for (int i = 0; i < NKF; ++i) st[i] = zero16();
+    {
+        // every Q / K fragment of the wave is requested before the first MFMA (as `mfma(load, load)` in one loop the compiler
+        // waited for each pair in turn: eight dependent round trips)
+        bf16x8_t fq[DH / 16], fk[NKF][DH / 16];
 #pragma unroll
-    for (int s = 0; s < DH / 16; ++s) {
-        const bf16x8_t fq = gfrag(qb, ldq, j * 32 + l31, nq, h * DH + s * 16 + hi * 8);
+        for (int s = 0; s < DH / 16; ++s) {
+            fq[s] = gfrag(qb, ldq, j * 32 + l31, nq, h * DH + s * 16 + hi * 8);
 #pragma unroll
-        for (int i = 0; i < NKF; ++i) st[i] = mfma32(gfrag(kb, ldk, i * 32 + l31, nk, h * DH + s * 16 + hi * 8), fq, st[i]);
+            for (int i = 0; i < NKF; ++i) fk[i][s] = gfrag(kb, ldk, i * 32 + l31, nk, h * DH + s * 16 + hi * 8);
+        }
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+            for (int i = 0; i < NKF; ++i) st[i] = mfma32(fk[i][s], fq[s], st[i]);
     }
+    sv.store(vt, tid);                    // (issued before the Q / K fragment loads above: one wait covers them all)
+    const uint64_t kbits = key_bits(key_mask, b * nk_cap, nk_cap, lane);
     const int qi = j * 32 + l31;
     float mx = -INFINITY;
 #pragma unroll
@@ -339,11 +380,10 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = i * 32 + acc_row(r, hi);
-            bool ok = key < nk;
-            if (key_mask != nullptr) ok = ok && key_mask[b * nk_cap + min(key, nk_cap - 1)] != 0;
-            const float sv = ok ? st[i][r] * scale : -INFINITY;
-            st[i][r] = sv;
-            mx = fmaxf(mx, sv);
+            const bool ok = key < nk && ((kbits >> key) & 1ull) != 0;
+            const float sc = ok ? st[i][r] * scale : -INFINITY;
+            st[i][r] = sc;
+            mx = fmaxf(mx, sc);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (mx == -INFINITY) mx = 0.f;
@@ -423,10 +463,18 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
     for (int i = 0; i < NKF; ++i)
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) vf[i][s] = gfrag(vb, ldv, i * 32 + l31, nk, h * DH + s * 16 + hi * 8);
-    stage_tile<DH, NKF * 32, SW>(tk, kb, ldk, nk, h * DH, tid, NW * 64);
-    stage_tile<DH, NQF * 32, SW>(tq, qb, ldq, nq, h * DH, tid, NW * 64);
-    stage_tile<DH, NQF * 32, SW>(tdo, dob, ldo, nq, h * DH, tid, NW * 64);
+    {
+        TileStage<DH, NKF * 32, NW * 64, SW> sk;
+        TileStage<DH, NQF * 32, NW * 64, SW> sq, sd;
+        sk.load(kb, ldk, nk, h * DH, tid);
+        sq.load(qb, ldq, nq, h * DH, tid);
+        sd.load(dob, ldo, nq, h * DH, tid);
+        sk.store(tk, tid);
+        sq.store(tq, tid);
+        sd.store(tdo, tid);
+    }
     if (tid < MAXN) s_lse[tid] = tid < nq ? lse[(size_t)bh * nq_cap + tid] : 0.f;
+    const uint64_t kbits = key_bits(key_mask, b * nk_cap, nk_cap, lane);
     constexpr int ND = (DH + 31) / 32;
     __syncthreads();
 
@@ -454,8 +502,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = i * 32 + acc_row(r, hi);
-                bool ok = key < nk;
-                if (key_mask != nullptr) ok = ok && key_mask[b * nk_cap + min(key, nk_cap - 1)] != 0;
+                const bool ok = key < nk && ((kbits >> key) & 1ull) != 0;
                 const float e = __expf(st[i][r] * scale - l);
                 const float pv = (ok && qi < nq) ? e : 0.f;
                 float dp = dpt[i][r];
@@ -515,8 +562,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
             }
         }
         const int key = i * 32 + l31;
-        bool kok = key < nk;
-        if (key_mask != nullptr) kok = kok && key_mask[b * nk_cap + min(key, nk_cap - 1)] != 0;
+        const bool kok = key < nk && ((kbits >> key) & 1ull) != 0;
 #pragma unroll
         for (int j = 0; j < NQF; ++j)
 #pragma unroll
@@ -628,9 +674,9 @@ static bool mfma_eligible(const SdpaArgs& a, bool bwd) {
     if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 8) return false;
     if (!aligned16(a.q) || !aligned16(a.k) || !aligned16(a.v)) return false;
     if (bwd) {
-        if (a.lddq % 4 || a.lddk % 4 || a.lddv % 4) return false;
+        if (a.lddq % 8 || a.lddk % 8 || a.lddv % 8) return false;          // 16-byte output stores
         if (!aligned16(a.dout) || !aligned16(a.dq) || !aligned16(a.dk) || !aligned16(a.dv)) return false;
-    } else if (a.ldo % 4 || !aligned16(a.o)) return false;
+    } else if (!aligned16(a.o)) return false;
     return true;
 }
 
