@@ -396,14 +396,20 @@ __device__ __forceinline__ void load_bias8(const GemmParams& p, int lane, bool f
     }
 }
 
+// the dropout seed of a launch (site seed + device-resident step part): ONE fetch per workgroup, ahead of the K loop
+template <int EPI>
+__device__ __forceinline__ uint64_t dropout_seed_of(const GemmParams& p) {
+    if constexpr (EPI == XL_EPI_RESIDUAL) return p.p_drop > 0.0f ? with_step_seed(p.seed, p.step_seed) : 0;
+    else return 0;
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const float* wbuf, int lane, bool first, int mq, int nq,
-                                                   const QuadOperand& op, float (&cs)[8], const float (&bv)[8]) {
+                                                   const QuadOperand& op, float (&cs)[8], const float (&bv)[8], uint64_t seed) {
     const int c8 = lane & 7, rr = lane >> 3;
     const int n = nq + c8 * 8;
-    const bool drop = p.p_drop > 0.0f;
-    const uint64_t seed = (EPI == XL_EPI_RESIDUAL && drop) ? with_step_seed(p.seed, p.step_seed) : 0;      // one scalar load per call
-#pragma unroll
+    const bool drop = p.p_drop > 0.0f;      // (seed: dropout_seed_of(p), fetched by the caller BEFORE its K loop -- fetched here, the
+#pragma unroll                              //  load sat behind a vmcnt(0) that also drained every store of the previous row groups)
     for (int ps = 0; ps < 8; ++ps) {
         const int row = ps * 8 + rr;
         const size_t m = (size_t)(mq + row);
@@ -481,12 +487,11 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
 // rows of a 64 x W sub-tile already in LDS (sub_to_lds) -> epilogue math -> 16-byte stores (no fused column sums)
 template <int EPI, int W>
 __device__ __forceinline__ void sub_rows_fast(const GemmParams& p, const float* wbuf, int lane, int mq, int nq,
-                                              const QuadOperand& op, const float (&bv)[8]) {
+                                              const QuadOperand& op, const float (&bv)[8], uint64_t seed) {
     constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = 64 / RPP;
     const int c8 = lane % LPR, rr = lane / LPR;
     const int n = nq + c8 * 8;
     const bool drop = p.p_drop > 0.0f;
-    const uint64_t seed = (EPI == XL_EPI_RESIDUAL && drop) ? with_step_seed(p.seed, p.step_seed) : 0;      // one scalar load per call
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
         const int row = ps * RPP + rr;
@@ -542,7 +547,7 @@ __device__ __forceinline__ void epilogue_quad_fast(const GemmParams& p, float* w
     float bv[8];
     load_bias8(p, lane, first, nq, bv);
     quad_to_lds(wbuf, lane, a00, a01, a10, a11);
-    epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op, cs, bv);
+    epilogue_rows_fast<EPI>(p, wbuf, lane, first, mq, nq, op, cs, bv, dropout_seed_of<EPI>(p));
     if (p.colsum_ws != nullptr) colsum_flush(p, lane, mq >> 6, nq, cs);          // one slab per 64 rows
 }
 

@@ -233,6 +233,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     stamp(0);
     // the epilogue's bias segment is requested before the first DMA: older than every counted load, so the K loop's vmcnt
     // arithmetic is unchanged, and its latency (a full miss after 15 us of streaming operands) is off the epilogue's front
+    [[maybe_unused]] const uint64_t dseed = dropout_seed_of<EPIK>(p);
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] float bias8b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // BN = 192: third column fragment
     if constexpr (EPIK >= 0) {
@@ -305,11 +306,11 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         sub_operand_load<EPIK, 32>(p, lane, mw, nw + 64, op1);
         __builtin_amdgcn_sched_barrier(0);
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8);
+        epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8, dseed);
         __builtin_amdgcn_sched_barrier(0);
         half_to_lds(wbuf, lane, acc[0][2], acc[1][2]);
         __builtin_amdgcn_sched_barrier(0);
-        sub_rows_fast<EPIK, 32>(p, wbuf, lane, mw, nw + 64, op1, bias8b);
+        sub_rows_fast<EPIK, 32>(p, wbuf, lane, mw, nw + 64, op1, bias8b, dseed);
         if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
         return;
     } else {
@@ -325,11 +326,11 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
                 quad_operand_load<EPIK>(p, lane, mw + 64, nw, op1);
                 __builtin_amdgcn_sched_barrier(0);
                 float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8);
+                epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw, nw, op0, cs, bias8, dseed);
                 __builtin_amdgcn_sched_barrier(0);
                 quad_to_lds(wbuf, lane, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
                 __builtin_amdgcn_sched_barrier(0);
-                epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1, cs, bias8);
+                epilogue_rows_fast<EPIK>(p, wbuf, lane, first, mw + 64, nw, op1, cs, bias8, dseed);
                 if (p.colsum_ws != nullptr) colsum_flush(p, lane, mw >> 7, nw, cs);      // one slab per 128 rows
                 if (p.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
                 return;
