@@ -129,6 +129,53 @@ def test_gemm_weight_gradient_splitk_and_accumulate(dtype, pingpong):
     close(gpu[2], cpu[2], dtype, "dW accumulate", f32_tol=1e-4, bf16_tol=2e-3)
 
 
+@pytest.mark.parametrize("M,N,K,bk,epi,colsum", [(16384, 3072, 768, 1, 6, False), (16384, 3072, 768, 0, 7, True), (8192, 2304, 128, 1, 0, False),
+                                                 (8192, 2304, 1536, 0, 0, False), (19456, 3072, 768, 1, 1, False), (16384, 3072, 192, 0, 3, False),
+                                                 (16384, 3072, 768, 0, 7, False)])
+def test_gemm_persistent_kernel_equals_plain_kernel(M, N, K, bk, epi, colsum):
+    """Launches of several rounds of 256x256 tiles with a short contraction take the persistent ping-pong kernel (one workgroup per
+    CU walks its tiles, next tile's first K tile requested under the epilogue): same MFMA order per tile and the same epilogue
+    arithmetic, so C and the saved aux must be BIT-identical to the plain kernel's (xl_set_gemm_persistent(0)); fused column sums
+    (another partial grouping) to fp32 rounding.  Integer-valued operands also pin both against the exact product on a row sample.
+    Tile counts: 768 (3 full rounds), 288 (one round + 32), 912 (3 rounds + 144)."""
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16).cuda()
+    B = torch.randint(-3, 4, ((N, K) if bk else (K, N)), generator=g).to(torch.bfloat16).cuda()
+    bias = torch.randint(-2, 3, (N,), generator=g).float().cuda() if bk else None
+    auxin = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    ops = hip(torch.bfloat16)
+    ops.set_gemm_pingpong(2)
+    out = {}
+    try:
+        for mode in (0, 1):
+            ops.set_gemm_persistent(mode)
+            for rep in range(2):                     # twice: a stale ring slot / ticket from the first launch would show in the second
+                C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+                aux = auxin.clone()
+                cs = torch.zeros(N, device="cuda")
+                ws = torch.zeros(ops.workspace_floats(N), device="cuda")
+                ops.gemm(A, B, C, bias, None, aux, M, N, K, K, K if bk else N, N, ldx=N, a_kmajor=1, b_kmajor=bk, epilogue=epi,
+                         colsum=cs if colsum else None, ws=ws if colsum else None)
+                torch.cuda.synchronize()
+            out[mode] = (C, aux, cs)
+    finally:
+        ops.set_gemm_persistent(1)
+        ops.set_gemm_pingpong(1)
+    assert torch.equal(out[0][0], out[1][0]), (out[0][0].float() - out[1][0].float()).abs().max().item()
+    assert torch.equal(out[0][1], out[1][1])
+    if colsum:
+        ref = out[1][0].float().sum(0)
+        assert (out[1][2] - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+        assert (out[0][2] - out[1][2]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    if epi == 0:                                     # exact product on a sample of rows (every tile row, first / last rows of tiles)
+        rows = torch.cat([torch.arange(0, M, 251), torch.tensor([255, 256, M - 1])]).cuda()
+        Bf = B.float()
+        ref = A[rows].float() @ (Bf.t() if bk else Bf)
+        if bias is not None:
+            ref = ref + bias
+        assert torch.equal(out[1][0][rows].float(), ref.to(torch.bfloat16).float())
+
+
 @pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0), (0, 1)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 128), (300, 260, 200), (520, 1030, 1000), (512, 256, 1536)])
 def test_gemm_pingpong_pipeline_depths(M, N, K, layout):

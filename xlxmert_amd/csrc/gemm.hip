@@ -295,6 +295,11 @@ extern "C" int xl_set_gemm_pingpong(int mode) {
     return XL_OK;
 }
 
+extern "C" int xl_set_gemm_persistent(int on) {
+    ctx().gemm_persist = on ? 1 : 0;
+    return XL_OK;
+}
+
 extern "C" int xl_set_gemm_tile192(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_tile192: mode %d", mode);
     ctx().gemm_bn192 = mode;
@@ -440,6 +445,23 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
                 nblk = tiles - rem + rem * S;
             }
         }
+    }
+    // several rounds of 256x256 tiles with a short contraction: the persistent variant (next tile's first K tile requested under
+    // the epilogue, no workgroup hand-over between tiles) -- OPT-IN: faster alone, slower inside the four-stream step
+    if (cx.gemm_persist < 0) cx.gemm_persist = env_int("XL_GEMM_PERSIST", 0);      // opt-in: see gemm_pp_persist.hip
+    static const int n_cu = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    static const int persist_max_k = env_int("XL_GEMM_PERSIST_MAX_K", 1536);
+    if (use_pp && cx.gemm_persist && bn == 256 && a_kmajor && epik >= 0 && epik != XL_EPI_TANH && epik != XL_EPI_ROWMAX &&
+        epik != XL_EPI_RESIDUAL && out_dtype == XL_BF16 && !p.atomic_out && p.splitk == 1 && p.tail_tiles == 0 && M % 256 == 0 &&
+        N % 256 == 0 && K % 64 == 0 && K >= 128 && K <= persist_max_k && tiles > n_cu && (colsum_out == nullptr || colsum_fused) &&
+        (double)M * lda < 1e9 && cx.gemm_trace == nullptr) {
+        hipError_t e = launch_pp_persist(p, b_kmajor, epik, std::min(tiles, n_cu), st);
+        if (e == hipSuccess) {
+            XL_CHECK_LAUNCH();
+            if (colsum_fused) { launch_colsum_reduce(colsum_ws, M / 128, N, colsum_out, st); XL_CHECK_LAUNCH(); }
+            return XL_OK;
+        }
+        XL_CHECK_ARG(e == hipErrorInvalidValue, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
     if (use_pp) {
         hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st);

@@ -342,15 +342,28 @@ __device__ __forceinline__ void sub_load_bias8(const GemmParams& p, int lane, bo
     }
 }
 
-template <int EPI>
+template <int EPI, int NPS = 8>           // NPS row groups of 8 rows: 8 = a 64 x 64 quad, 4 = a 32 x 64 half quad
 __device__ __forceinline__ void quad_operand_load(const GemmParams& p, int lane, int mq, int nq, QuadOperand& op) {
     if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU || EPI == XL_EPI_MULAUX) {
         const bf16_t* src = reinterpret_cast<const bf16_t*>(EPI == XL_EPI_RESIDUAL ? p.residual : p.aux);
         const int ld = EPI == XL_EPI_RESIDUAL ? p.ldr : p.ldx;
         const bf16_t* s0 = src + (size_t)(mq + (lane >> 3)) * ld + nq + (lane & 7) * 8;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) op.row[ps] = *reinterpret_cast<const uint4*>(s0 + (size_t)(ps * 8) * ld);
+        for (int ps = 0; ps < NPS; ++ps) op.row[ps] = *reinterpret_cast<const uint4*>(s0 + (size_t)(ps * 8) * ld);
     }
+}
+
+// 32 rows x 64 columns (two accumulators side by side) -> 8 KiB of wave-private LDS, row pitch 64 floats (the quad image's upper half)
+__device__ __forceinline__ void hquad_to_lds(float* wbuf, int lane, const f32x16_t& a0, const f32x16_t& a1) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x16_t& a = j == 0 ? a0 : a1;
+        const int col = j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wbuf[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + col] = a[r];
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
@@ -403,14 +416,14 @@ __device__ __forceinline__ uint64_t dropout_seed_of(const GemmParams& p) {
     else return 0;
 }
 
-template <int EPI>
+template <int EPI, int NPS = 8>
 __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const float* wbuf, int lane, bool first, int mq, int nq,
                                                    const QuadOperand& op, float (&cs)[8], const float (&bv)[8], uint64_t seed) {
     const int c8 = lane & 7, rr = lane >> 3;
     const int n = nq + c8 * 8;
     const bool drop = p.p_drop > 0.0f;      // (seed: dropout_seed_of(p), fetched by the caller BEFORE its K loop -- fetched here, the
 #pragma unroll                              //  load sat behind a vmcnt(0) that also drained every store of the previous row groups)
-    for (int ps = 0; ps < 8; ++ps) {
+    for (int ps = 0; ps < NPS; ++ps) {
         const int row = ps * 8 + rr;
         const size_t m = (size_t)(mq + row);
         float v[8];
@@ -485,9 +498,9 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
 }
 
 // rows of a 64 x W sub-tile already in LDS (sub_to_lds) -> epilogue math -> 16-byte stores (no fused column sums)
-template <int EPI, int W>
+template <int EPI, int W, bool CS = false>
 __device__ __forceinline__ void sub_rows_fast(const GemmParams& p, const float* wbuf, int lane, int mq, int nq,
-                                              const QuadOperand& op, const float (&bv)[8], uint64_t seed) {
+                                              const QuadOperand& op, const float (&bv)[8], uint64_t seed, float (&cs)[8]) {
     constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = 64 / RPP;
     const int c8 = lane % LPR, rr = lane / LPR;
     const int n = nq + c8 * 8;
@@ -534,9 +547,22 @@ __device__ __forceinline__ void sub_rows_fast(const GemmParams& p, const float* 
             uint4 t;
             t.x = pack2bf(v[0], v[1]); t.y = pack2bf(v[2], v[3]); t.z = pack2bf(v[4], v[5]); t.w = pack2bf(v[6], v[7]);
             *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = t;
+            if constexpr (CS) {                     // sums of the values as stored (persistent kernel: fused column sums)
+                float sv[8];
+                unpack8(t, sv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] += sv[e];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int EPI, int W>
+__device__ __forceinline__ void sub_rows_fast(const GemmParams& p, const float* wbuf, int lane, int mq, int nq,
+                                              const QuadOperand& op, const float (&bv)[8], uint64_t seed) {
+    float none[8];
+    sub_rows_fast<EPI, W, false>(p, wbuf, lane, mq, nq, op, bv, seed, none);
 }
 
 template <int EPI>
@@ -660,5 +686,8 @@ hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st);
 // the host for launches whose C / residual / aux rows are 16-byte aligned (interior tiles take it, edge tiles fall back)
 // bn: 256 (256x256 tile) or 192 (256x192 tile: N a multiple of 192, every tile interior, fast epilogue, no fused column sums)
 hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int bn, int nblk, hipStream_t st);
+// persistent variant (gemm_pp_persist.hip): A K-major, bf16 in / out, every tile interior, fast epilogue, several rounds of tiles;
+// hipErrorInvalidValue when the (layout, epilogue kind) has no instance
+hipError_t launch_pp_persist(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);
 
 }  // namespace xl

@@ -82,6 +82,10 @@ class HipOps:
         """0: 128x128 GEMM kernel only; 1: by shape (default); 2: 256x256 ping-pong kernel whenever eligible."""
         self._call("xl_set_gemm_pingpong", int(mode))
 
+    def set_gemm_persistent(self, on):
+        """persistent ping-pong kernel for multi-round, short-K launches: 1 = when eligible (default), 0 = never."""
+        self._call("xl_set_gemm_persistent", int(on))
+
     def set_gemm_tail_split(self, max_tail_tiles, min_k):
         self._call("xl_set_gemm_tail_split", int(max_tail_tiles), int(min_k))
 
