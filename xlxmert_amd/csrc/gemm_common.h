@@ -156,6 +156,37 @@ struct OpTile {
     }
 };
 
+// M-major fragments next to IN-FLIGHT LDS-DMA (ping-pong kernel).  In front of the ds_read_b64_tr_b16 BUILTIN hipcc places an
+// `s_waitcnt vmcnt(0)` whenever `buffer_load ... lds` requests are outstanding -- it cannot see that the ring slots being read
+// and the slots being filled differ -- which drains the whole prefetch once (dX layout) or twice (weight gradients) per K tile:
+// the LDS-DMA then has ONE phase to land instead of three, and that, not the second read instruction per fragment, was most of
+// the 1.73 us per K tile of the weight-gradient kernel against 1.44 for the K-major layout (whose plain ds_read_b128 gets no such
+// wait).  Issued through inline assembly the transpose reads are invisible to that pass; what orders them is what orders the
+// K-major reads too -- the kernel's own protocol: a slot is read only after the counted vmcnt + barrier that follow its fill,
+// and every read is retired (the explicit lgkmcnt(0) of the phase) before the barrier that lets the slot be refilled.
+//   tr_lane_off: byte offset, inside an M-major tile, of the lane's first transpose read of the s = 0 fragment of rows r0..r0+31
+//   TrFrag<RP, BASE>::get<S>(addr): fragment s = S; addr = LDS byte address of the BUFFER + tr_lane_off, BASE = the tile's
+//   constant byte offset inside the buffer (goes into the instruction's 16-bit offset field together with the s part)
+template <int ROWS>
+__device__ __forceinline__ uint32_t tr_lane_off(int r0, int lane) {
+    using T = OpTile<false, ROWS>;
+    const int t = lane & 15;
+    const int mb = (r0 + ((lane >> 4) & 1) * 16 + (t & 3) * 4) * 2;
+    const int k0r = (lane >> 5) * 8 + (t >> 2);
+    return (uint32_t)(k0r * T::RP + (mb ^ T::swz(k0r)));
+}
+template <int RP, int BASE>
+struct TrFrag {
+    template <int S>
+    __device__ static __forceinline__ bf16x8_t get(uint32_t addr) {
+        static_assert(BASE + S * 16 * RP + 4 * RP < 65536, "DS offset field");
+        bf16x4_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(BASE + S * 16 * RP));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(BASE + S * 16 * RP + 4 * RP));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+};
+
 // predicated (zero-filling) load of the 16 bytes that belong at LDS offset o: ragged last k-tile only
 template <bool KMAJ, int ROWS>
 __device__ __forceinline__ uint4 gload16(const bf16_t* __restrict__ P, int ld, int row0, int rows_ext, int k0, int kend, int o) {

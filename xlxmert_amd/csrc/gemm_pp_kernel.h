@@ -154,20 +154,50 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
         }
     };
     bf16x8_t fa[AF][4], fb[NB][4];        // A: row fragments x 4 k-steps of the current A half; B: all parts
+    // M-major operands: transpose reads through inline assembly (gemm_common.h TrFrag: no compiler-made vmcnt(0) in front of them)
+    [[maybe_unused]] uint32_t a_tr[AF], b_tr = 0;
+    if constexpr (!AK) {
+#pragma unroll
+        for (int i = 0; i < AF; ++i) a_tr[i] = tr_lane_off<128>(wr * HR + i * 32, lane);
+    }
+    if constexpr (!BKM) b_tr = tr_lane_off<BROWS>(wc * 32, lane);
+    const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;
     auto read_a = [&](const uint8_t* buf, auto H) {
-        const uint8_t* t = buf + (decltype(H)::value == 0 ? 0 : HT + NB * BPB);
+        constexpr int toff = decltype(H)::value == 0 ? 0 : HT + NB * BPB;
+        if constexpr (!AK) {
+            const uint32_t base = smem_lds + (uint32_t)(buf - smem);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int i = 0; i < AF; ++i) {
+                using R = TrFrag<TA::RP, toff>;
+                const uint32_t ad = base + a_tr[i];
+                fa[i][0] = R::template get<0>(ad); fa[i][1] = R::template get<1>(ad);
+                fa[i][2] = R::template get<2>(ad); fa[i][3] = R::template get<3>(ad);
+            }
+        } else {
+            const uint8_t* t = buf + toff;
 #pragma unroll
-            for (int i = 0; i < AF; ++i) fa[i][s] = TA::template frag<true>(t, wr * HR + i * 32, s, lane);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < AF; ++i) fa[i][s] = TA::template frag<true>(t, wr * HR + i * 32, s, lane);
+        }
     };
-    auto read_b = [&](const uint8_t* buf) {
-#pragma unroll
-        for (int h = 0; h < NB; ++h) {
+    auto read_b_part = [&](const uint8_t* buf, auto HH) {
+        constexpr int h = decltype(HH)::value;
+        if constexpr (!BKM) {
+            using R = TrFrag<TB::RP, HT + h * BPB>;
+            const uint32_t ad = smem_lds + (uint32_t)(buf - smem) + b_tr;
+            fb[h][0] = R::template get<0>(ad); fb[h][1] = R::template get<1>(ad);
+            fb[h][2] = R::template get<2>(ad); fb[h][3] = R::template get<3>(ad);
+        } else {
             const uint8_t* t = buf + HT + h * BPB;
 #pragma unroll
             for (int s = 0; s < 4; ++s) fb[h][s] = TB::template frag<true>(t, wc * 32, s, lane);
         }
+    };
+    auto read_b = [&](const uint8_t* buf) {
+        read_b_part(buf, ic<0>{});
+        read_b_part(buf, ic<1>{});
+        if constexpr (NB == 3) read_b_part(buf, ic<2>{});
     };
     auto mma2 = [&](auto AH) {            // 16 (12) MFMAs over 4 (3) independent accumulators
         constexpr int ah = decltype(AH)::value;
