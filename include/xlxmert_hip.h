@@ -89,6 +89,11 @@ int  xl_set_gemm_tile192(int mode);
  * Bit-identical results either way.  Measured: -5 % on the FFN1 + GELU launch in isolation, +0.1 ms on the whole step -- a
  * workgroup that holds its CU across tiles keeps the other streams' workgroups out at the tile boundaries. */
 int  xl_set_gemm_persistent(int on);
+/* 128x192 "duo" tiles of the ping-pong kernel: four waves and 80 KiB of LDS per workgroup, TWO workgroups per CU, so that one's
+ * prologue / epilogue / hand-over runs under the other's K loop and workgroups of different streams can share a CU.  Eligible:
+ * forward / dX layouts, M % 128 == 0, N % 192 == 0, bf16 output through a fast epilogue.  0 = never, 1 = when eligible (and
+ * K <= XL_GEMM_DUO_MAX_K), 2 = whenever eligible; env XL_GEMM_DUO.  Bit-identical results to the other tile shapes. */
+int  xl_set_gemm_duo(int mode);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */
 int  xl_gemm_trace(void* buffer);

@@ -200,10 +200,59 @@ def test_gemm_pingpong_pipeline_depths(M, N, K, layout):
         ops.set_gemm_pingpong(1)
 
 
+@pytest.mark.parametrize("M,N,K,bk,epi,p_drop", [(16384, 768, 768, 1, 2, 0.1), (16384, 768, 3072, 1, 2, 0.1), (16384, 3072, 768, 1, 6, 0.0),
+                                                 (16384, 3072, 768, 0, 7, 0.0), (5120, 2304, 768, 1, 0, 0.0), (16384, 768, 2304, 0, 2, 0.1),
+                                                 (2176, 768, 768, 0, 0, 0.0), (3200, 3072, 768, 1, 1, 0.0), (3200, 768, 3072, 0, 3, 0.0)])
+def test_gemm_duo_tiles_equal_whole_cu_tiles(M, N, K, bk, epi, p_drop):
+    """128x192 "duo" tiles (four waves, 80 KiB of LDS, two workgroups per CU) against the 256-row tiles on the step's own shapes:
+    the same 32x32x16 MFMA chain per output element and the same epilogue arithmetic (the dropout draw is a function of the
+    element's coordinates), so C and the saved aux must be BIT-identical; twice, so that a stale ring slot would show."""
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    B = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    auxin = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    ops = hip(torch.bfloat16)
+    ops.set_gemm_pingpong(2)
+    out = {}
+    try:
+        for mode in (0, 2):
+            ops.set_gemm_duo(mode)
+            for rep in range(2):
+                C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+                aux = auxin.clone()
+                ops.gemm(A, B, C, bias, res if epi == 2 else None, aux if epi in (1, 3, 6, 7) else None, M, N, K, K, K if bk else N, N,
+                         ldr=N, ldx=N, a_kmajor=1, b_kmajor=bk, epilogue=epi, p_drop=p_drop, seed=77)
+                torch.cuda.synchronize()
+            out[mode] = (C, aux)
+    finally:
+        ops.set_gemm_duo(0)
+        ops.set_gemm_pingpong(1)
+    assert torch.equal(out[0][0], out[2][0]), (out[0][0].float() - out[2][0].float()).abs().max().item()
+    assert torch.equal(out[0][1], out[2][1])
+    if p_drop > 0:
+        frac = (out[2][0] == res).float().mean().item()         # dropped elements keep the residual alone
+        assert abs(frac - p_drop) < 0.01, frac
+
+
+@pytest.mark.parametrize("bk", [1, 0])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 6, 7])
+@pytest.mark.parametrize("M,N,K", [(128, 192, 64), (384, 768, 128), (640, 384, 200), (128, 2304, 1000), (896, 768, 1536)])
+def test_gemm_duo_tiles_exact(M, N, K, epi, bk):
+    """the 128x192 duo variant forced for every eligible launch, as test_gemm_256x192_tiles_exact: 1 / 2 / 4 (ragged) / 16 (ragged) /
+    24 K tiles, forward and dX layouts, the six fast epilogues, against the host restatement on integer-valued operands."""
+    _tiles_exact(M, N, K, epi, bk, duo=2)
+
+
 @pytest.mark.parametrize("bk", [1, 0])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 768, 128), (768, 384, 200), (256, 2304, 1000), (1024, 768, 1536)])
 def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
+    _tiles_exact(M, N, K, epi, bk, duo=0)
+
+
+def _tiles_exact(M, N, K, epi, bk, duo):
     """the 256x192 variant of the ping-pong kernel (waves 4 x 2, wave tile 64 x 96, B staged in three 8 KiB parts) forced for
     every eligible launch: 1 / 2 / 4 (ragged) / 16 (ragged) / 24 K tiles, forward and dX operand layouts, all four fast
     epilogues.  Integer-valued operands: the fp32 accumulation is exact, so the plain result must equal the host product bit
@@ -218,6 +267,7 @@ def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
     ops = hip(torch.bfloat16)
     ops.set_gemm_pingpong(2)
     ops.set_gemm_tile192(2)
+    ops.set_gemm_duo(duo)
     try:
         for rep in range(2):
             C = torch.full((M, N), 7.0, dtype=torch.bfloat16)
@@ -237,6 +287,7 @@ def test_gemm_256x192_tiles_exact(M, N, K, epi, bk):
     finally:
         ops.set_gemm_pingpong(1)
         ops.set_gemm_tile192(1)
+        ops.set_gemm_duo(0)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -244,11 +244,21 @@ def test_task_round_robin_on_one_parameter_set(grouped):
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A listening port BELOW the kernel's ephemeral range (32768+): a port handed out by bind(0) can be taken by an outgoing
+    connection of the previous test's gloo pairs before the store listens on it (EADDRINUSE seen once on the GPU box)."""
+    import random
+    rng = random.Random(os.getpid() * 7919 + int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        p = rng.randrange(15000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return p
+    raise RuntimeError("no free port")
 
 
 def _dp_worker(rank, world, port, out_dir):

@@ -300,6 +300,12 @@ extern "C" int xl_set_gemm_persistent(int on) {
     return XL_OK;
 }
 
+extern "C" int xl_set_gemm_duo(int mode) {
+    XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_duo: mode %d", mode);
+    ctx().gemm_duo = mode;
+    return XL_OK;
+}
+
 extern "C" int xl_set_gemm_tile192(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_tile192: mode %d", mode);
     ctx().gemm_bn192 = mode;
@@ -422,6 +428,18 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         p.tiles_n = (N + tile - 1) / tile;
         tiles = p.tiles_m * p.tiles_n;    // (the tail split below and the grid size count THESE tiles; the K split above was sized
     }                                     //  for an fp32-output launch, which never takes the 192-wide tile)
+    // 128x192 "duo" tiles, two four-wave workgroups per CU (gemm_pp_kernel.h PPGeo<192, 128>): same eligibility as the 256x192 tile
+    // (forward / dX layouts, N a multiple of 192, fast epilogue, plain stores) with M a multiple of 128
+    if (cx.gemm_duo < 0) cx.gemm_duo = env_int("XL_GEMM_DUO", 0);
+    static const int duo_max_k = env_int("XL_GEMM_DUO_MAX_K", 1 << 30);
+    int bm = 256;
+    if (use_pp && cx.gemm_duo && a_kmajor && M % 128 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate && epik >= 0 &&
+        colsum_out == nullptr && epilogue != XL_EPI_TANH && epilogue != XL_EPI_ROWMAX && splitk == 1 && !p.atomic_out &&
+        (double)M * lda < 1e9 && (cx.gemm_duo == 2 || K <= duo_max_k)) {
+        bm = 128; bn = 192;
+        p.tiles_m = M / 128; p.tiles_n = N / 192;
+        tiles = p.tiles_m * p.tiles_n;
+    }
     // column sums of C ride in the fast epilogue when every tile takes it; otherwise a separate pass over C follows
     const bool colsum_fused = colsum_out != nullptr && mfma_ok && epik >= 0 && splitk == 1 && a_kmajor && M % tile == 0 &&
                               N % tile == 0;
@@ -433,7 +451,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // contraction, K = 2048, 1320 tiles, does not gain -- 338 -> 368 us -- hence the depth threshold)
     if (cx.tail_max < 0) { cx.tail_max = env_int("XL_GEMM_TAIL_MAX", 64); cx.tail_min_k = env_int("XL_GEMM_TAIL_MIN_K", 4096); }
     const int tail_max = cx.tail_max, tail_min_k = cx.tail_min_k;
-    if (use_pp && splitk == 1 && !p.atomic_out && tiles > 256 && tiles % 256 <= tail_max && tiles % 256 > 0 && K >= tail_min_k) {
+    if (use_pp && bm == 256 && splitk == 1 && !p.atomic_out && tiles > 256 && tiles % 256 <= tail_max && tiles % 256 > 0 && K >= tail_min_k) {
         const int rem = tiles % 256;
         int S = std::min(std::min(256 / rem, K / 512), 8);          // >= 8 K tiles per slice, <= 7 slabs for the last arriver to add
         if (S >= 2) {
@@ -451,7 +469,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     if (cx.gemm_persist < 0) cx.gemm_persist = env_int("XL_GEMM_PERSIST", 0);      // opt-in: see gemm_pp_persist.hip
     static const int n_cu = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
     static const int persist_max_k = env_int("XL_GEMM_PERSIST_MAX_K", 1536);
-    if (use_pp && cx.gemm_persist && bn == 256 && a_kmajor && epik >= 0 && epik != XL_EPI_TANH && epik != XL_EPI_ROWMAX &&
+    if (use_pp && cx.gemm_persist && bn == 256 && bm == 256 && a_kmajor && epik >= 0 && epik != XL_EPI_TANH && epik != XL_EPI_ROWMAX &&
         epik != XL_EPI_RESIDUAL && out_dtype == XL_BF16 && !p.atomic_out && p.splitk == 1 && p.tail_tiles == 0 && M % 256 == 0 &&
         N % 256 == 0 && K % 64 == 0 && K >= 128 && K <= persist_max_k && tiles > n_cu && (colsum_out == nullptr || colsum_fused) &&
         (double)M * lda < 1e9 && cx.gemm_trace == nullptr) {
@@ -464,7 +482,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         XL_CHECK_ARG(e == hipErrorInvalidValue, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
     if (use_pp) {
-        hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st);
+        hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st, bm);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     } else if (mfma_ok) {
         if (a_kmajor && b_kmajor) launch_mfma<true, true>(p, epik, nblk, st);

@@ -716,7 +716,7 @@ hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st);
 // EPIK: -1 = generic epilogue (runtime kind, ragged edges); XL_EPI_NONE / GELU / RESIDUAL / DGELU = fast epilogue, used by
 // the host for launches whose C / residual / aux rows are 16-byte aligned (interior tiles take it, edge tiles fall back)
 // bn: 256 (256x256 tile) or 192 (256x192 tile: N a multiple of 192, every tile interior, fast epilogue, no fused column sums)
-hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int bn, int nblk, hipStream_t st);
+hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int bn, int nblk, hipStream_t st, int bm = 256);
 // persistent variant (gemm_pp_persist.hip): A K-major, bf16 in / out, every tile interior, fast epilogue, several rounds of tiles;
 // hipErrorInvalidValue when the (layout, epilogue kind) has no instance
 hipError_t launch_pp_persist(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);

@@ -30,31 +30,38 @@ template <int V> using ic = std::integral_constant<int, V>;
 // (N = 768 = 3 x 256 = 4 x 192: 64 row tiles give 192 tiles of 256x256 -- a quarter of the 256 CUs idle for the whole launch --
 // or 256 tiles of 256x192; N = 2304 likewise 576 -> 768 = 3 full rounds.)  The A half-tiles are 128 rows x 64 k (16 KiB,
 // 2 DMA pieces per wave) in both; a B part is (waves in N) x 32 columns: 128 rows / 16 KiB / 2 pieces or 64 rows / 8 KiB / 1 piece.
-template <int BN> struct PPGeo;
-template <> struct PPGeo<256> { static constexpr int WR = 2, WC = 4, AF = 2, NB = 2; };
-template <> struct PPGeo<192> { static constexpr int WR = 4, WC = 2, AF = 1, NB = 3; };
+// BM = 128 ("duo", BN = 192 only): FOUR waves (2 x 2) with the 64 x 96 wave tile of the 256x192 shape, 80 KiB of LDS and 256
+// registers per wave -- TWO workgroups per CU.  Nothing synchronises the two; each is its partner's filler: while one runs its
+// prologue / epilogue / hand-over to the next workgroup, the other's K loop has the MFMA pipes (the 8-wave shapes leave them idle
+// for ~1/3 of a K = 768 tile's life), and workgroups of different launches (streams) can share a CU.
+template <int BN, int BM = 256> struct PPGeo;
+template <> struct PPGeo<256, 256> { static constexpr int WR = 2, WC = 4, AF = 2, NB = 2; };
+template <> struct PPGeo<192, 256> { static constexpr int WR = 4, WC = 2, AF = 1, NB = 3; };
+template <> struct PPGeo<192, 128> { static constexpr int WR = 2, WC = 2, AF = 1, NB = 3; };
 
-template <bool AK, bool BKM, int EPIK, int BN = 256>
+template <bool AK, bool BKM, int EPIK, int BN = 256, int BM = 256>
 __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int kbeg, int kend, bool first,
                                         int slab_tile = -1, int z = 0, int nz = 1) {
-    using G = PPGeo<BN>;
-    constexpr int WR = G::WR, WC = G::WC, AF = G::AF, NB = G::NB;
-    constexpr int WTM = 256 / WR, WTN = BN / WC, HR = AF * 32;         // wave tile; rows of a wave in one A half
+    using G = PPGeo<BN, BM>;
+    constexpr int WR = G::WR, WC = G::WC, AF = G::AF, NB = G::NB, NW = WR * WC;
+    constexpr int WTM = BM / WR, WTN = BN / WC, HR = AF * 32;          // wave tile; rows of a wave in one A half
     constexpr int BROWS = WC * 32;                                     // columns (tile rows) of one B part
-    using TA = OpTile<AK, 128>;
+    using TA = OpTile<AK, BM / 2>;
     using TB = OpTile<BKM, BROWS>;
-    constexpr int HT = 16384, BPB = TB::BYTES, PB = BPB / 8192;        // bytes of a B part, DMA pieces per wave and part
+    constexpr int HT = TA::BYTES, BPB = TB::BYTES, PB = BPB / (NW * 1024);   // bytes of an A half / a B part, DMA pieces per wave and part
     constexpr int BUF = 2 * HT + NB * BPB;                             // [A0 | B parts | A1]
-    constexpr int NA = 2, NBP = NB * PB;                               // DMA instructions per wave: A half, all of B
+    constexpr int NA = HT / (NW * 1024), NBP = NB * PB;                // DMA instructions per wave: A half, all of B
+    static_assert(NA == 2 && PB >= 1 && 2 * BUF <= (BM == 256 ? 131072 : 81920) && NW * 16384 <= (BM == 256 ? 131072 : 81920),
+                  "ring geometry / epilogue transposition space");
     constexpr int WAIT = 2 * NA + NBP;                                 // steady-state vmcnt (see the phase comment)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // [2 buffers][A0 | B parts | A1]
-    const int m0 = tm * 256, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
-    const int grp = wave >> 2;                     // waves 4-7 run one barrier behind waves 0-3 (one wave of each group per SIMD)
+    const int grp = NW == 8 ? wave >> 2 : 0;       // waves 4-7 run one barrier behind waves 0-3 (one wave of each group per SIMD)
 
     f32x16_t acc[2 * AF][NB];
 #pragma unroll
@@ -158,7 +165,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     [[maybe_unused]] uint32_t a_tr[AF], b_tr = 0;
     if constexpr (!AK) {
 #pragma unroll
-        for (int i = 0; i < AF; ++i) a_tr[i] = tr_lane_off<128>(wr * HR + i * 32, lane);
+        for (int i = 0; i < AF; ++i) a_tr[i] = tr_lane_off<BM / 2>(wr * HR + i * 32, lane);
     }
     if constexpr (!BKM) b_tr = tr_lane_off<BROWS>(wc * 32, lane);
     const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;
@@ -302,7 +309,9 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
     // ---- split-K through slabs: only the last arriver of this output tile goes on, with the whole sum in its registers
     const bool slabbed = slab_tile >= 0 && nz > 1;
     if (slabbed) {
-        if (!slab_exchange(p, smem, tid, slab_tile, z, nz, acc)) return;
+        if constexpr (BM == 256) {
+            if (!slab_exchange(p, smem, tid, slab_tile, z, nz, acc)) return;
+        }
         first = true;
     }
     // ---- epilogue (all fragment reads of the staging LDS are behind the last barrier)
@@ -373,6 +382,13 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
 }
 
 template <bool AK, bool BKM, int EPIK, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_pp_duo_kernel(GemmParams p) {      // 128 x BN tiles, two workgroups per CU
+    int tm, tn, z;
+    tile_coords(p, tm, tn, z);
+    pp_tile<AK, BKM, EPIK, BN, 128>(p, tm, tn, 0, p.K, true);
+}
+
+template <bool AK, bool BKM, int EPIK, int BN>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
     int tm, tn, z;
     if (p.tail_tiles > 0) {
@@ -401,33 +417,40 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
                                p.slab != nullptr ? tn * p.tiles_m + tm : -1, z, p.splitk);
 }
 
-template <bool AK, bool BKM, int EPIK, int BN = 256>
+template <bool AK, bool BKM, int EPIK, int BN = 256, int BM = 256>
 static hipError_t launch_pp_one(const GemmParams& p, int nblk, hipStream_t st) {
-    constexpr int lds = 131072;
     hipError_t e = hipSuccess;
-    auto k = gemm_bf16_pp_kernel<AK, BKM, EPIK, BN>;
     static bool attr = false;
-    if (!attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(512), lds, st, p);
+    if constexpr (BM == 128) {
+        constexpr int lds = 81920;              // two ring slots of 40 KiB; 2 x 80 KiB = the CU's 160 KiB
+        auto k = gemm_bf16_pp_duo_kernel<AK, BKM, EPIK, BN>;
+        if (!attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, st, p);
+    } else {
+        constexpr int lds = 131072;
+        auto k = gemm_bf16_pp_kernel<AK, BKM, EPIK, BN>;
+        if (!attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(512), lds, st, p);
+    }
     return e;
 }
 
 
 // fast-epilogue instances of one layout and tile width (a kind without an instance: hipErrorInvalidValue at 192, the generic
 // epilogue at 256)
-template <bool AK, bool BKM, int BN>
+template <bool AK, bool BKM, int BN, int BM = 256>
 static hipError_t launch_pp_layout(const GemmParams& p, int epik, int nblk, hipStream_t st) {
     if constexpr (AK) {
         switch (epik) {
-            case XL_EPI_NONE: return launch_pp_one<AK, BKM, XL_EPI_NONE, BN>(p, nblk, st);
-            case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU, BN>(p, nblk, st);
-            case XL_EPI_RESIDUAL: return launch_pp_one<AK, BKM, XL_EPI_RESIDUAL, BN>(p, nblk, st);
-            case XL_EPI_DGELU: return launch_pp_one<AK, BKM, XL_EPI_DGELU, BN>(p, nblk, st);
+            case XL_EPI_NONE: return launch_pp_one<AK, BKM, XL_EPI_NONE, BN, BM>(p, nblk, st);
+            case XL_EPI_GELU: return launch_pp_one<AK, BKM, XL_EPI_GELU, BN, BM>(p, nblk, st);
+            case XL_EPI_RESIDUAL: return launch_pp_one<AK, BKM, XL_EPI_RESIDUAL, BN, BM>(p, nblk, st);
+            case XL_EPI_DGELU: return launch_pp_one<AK, BKM, XL_EPI_DGELU, BN, BM>(p, nblk, st);
             case XL_EPI_GELU_DG:
-                if constexpr (BKM) return launch_pp_one<AK, BKM, XL_EPI_GELU_DG, BN>(p, nblk, st);
+                if constexpr (BKM) return launch_pp_one<AK, BKM, XL_EPI_GELU_DG, BN, BM>(p, nblk, st);
                 break;
             case XL_EPI_MULAUX:
-                if constexpr (!BKM) return launch_pp_one<AK, BKM, XL_EPI_MULAUX, BN>(p, nblk, st);
+                if constexpr (!BKM) return launch_pp_one<AK, BKM, XL_EPI_MULAUX, BN, BM>(p, nblk, st);
                 break;
             case XL_EPI_ROWMAX:
                 if constexpr (BKM && BN == 256) return launch_pp_one<AK, BKM, XL_EPI_ROWMAX, BN>(p, nblk, st);
@@ -443,5 +466,6 @@ static hipError_t launch_pp_layout(const GemmParams& p, int epik, int nblk, hipS
 hipError_t launch_pp_nt256(const GemmParams& p, int epik, int nblk, hipStream_t st);                 // gemm_pp.hip
 hipError_t launch_pp_other256(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int nblk, hipStream_t st);   // gemm_pp_nn.hip
 hipError_t launch_pp_192(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);   // gemm_pp_192.hip
+hipError_t launch_pp_duo(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);   // gemm_pp_duo.hip (128x192, two per CU)
 
 }  // namespace xl

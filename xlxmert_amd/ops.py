@@ -86,6 +86,10 @@ class HipOps:
         """persistent ping-pong kernel for multi-round, short-K launches: 1 = when eligible (default), 0 = never."""
         self._call("xl_set_gemm_persistent", int(on))
 
+    def set_gemm_duo(self, mode):
+        """128x192 tiles, two four-wave workgroups per CU: 0 never, 1 when eligible, 2 always when eligible."""
+        self._call("xl_set_gemm_duo", int(mode))
+
     def set_gemm_tail_split(self, max_tail_tiles, min_k):
         self._call("xl_set_gemm_tail_split", int(max_tail_tiles), int(min_k))
 
