@@ -1213,3 +1213,50 @@ def test_two_library_contexts_interleaved_in_one_process():
         assert torch.allclose(a, b, rtol=2e-5, atol=1e-6), (a, b)        # (fp32 atomics: not bit-identical run to run)
     assert abs(tr.grad_norm() - alone_n) < 2e-4 * alone_n
     assert (tr.store.master - alone_p).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("plan", [False, True])
+@pytest.mark.parametrize("case", ["one_example_two_tokens", "ragged_extremes", "all_full"])
+def test_edge_case_batches_match_oracle_fp32(case, plan):
+    """Batches at the corners of the input domain, every gradient against the CPU oracle (fp32, dropout off):
+    one example whose text is [CLS][SEP] only; lengths 2 / L / 5 / 3 next to an example with NO masked visual token (its feature
+    loss term is 0 / max(0, 1), its rows carry label -100), one with ALL tokens masked and one with a single masked token; and a
+    batch without any padding or any unmasked token.  The loader's optional row lists are left out, so the engine derives the
+    packed language rows itself.  With plan = True the third step is a replay of the recorded launch plan."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import PretrainStep
+    cfg = XLxmertConfig(vocab_size=100, hidden_size=64, num_attention_heads=4, intermediate_size=128,
+                        max_position_embeddings=32, visual_feat_dim=32, num_clusters=56, l_layers=2, x_layers=2, r_layers=1)
+    oc = O.OracleConfig(**{k: getattr(cfg, k) for k in CFG_KEYS})
+    sd = O.make_state_dict(oc, 11)
+    from test_trainer_cpu import EDGE_CASES, edge_batch
+    L, V = 8, 16
+    lens, masks = EDGE_CASES[case]
+    batch = edge_batch(cfg, lens, masks, L, V, seed=len(lens) * 17 + 1)
+    B = len(lens)
+    store = ParamStore(cfg, "cuda", torch.float32)
+    store.load_named(sd)
+    tr = PretrainStep(cfg, B, L, V, dtype=torch.float32, device="cuda", store=store, lr=0.0, total_steps=10, plan=plan,
+                      drop_grads=False, visual_losses="obj,feat", train_dropout=False)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    for _ in range(3):
+        losses = tr.step(dev)
+    tr.sync()
+    leaf = {k: v.clone().requires_grad_(v.is_floating_point() and k != "vis_emb.weight") for k, v in sd.items()}
+    leaf["obj_predict_head.out_cluster.weight"] = leaf["vis_emb.weight"]
+    ref = O.xlxmert_vis_mask_forward(leaf, oc, batch["input_ids"], batch["visual_pos"], batch["attention_mask"],
+                                     batch["cluster_ids"], batch["vis_mask"], batch["obj_labels"])
+    ref["total_loss"].backward()
+    assert abs(losses[0].item() - ref["obj_loss"].item()) < 1e-4 * max(1.0, abs(ref["obj_loss"].item()))
+    assert abs(losses[1].item() - ref["feat_loss"].item()) < 1e-4 * max(1.0, abs(ref["feat_loss"].item()))
+    n = 0
+    for k, v in leaf.items():
+        if v.grad is None or k == "obj_predict_head.out_cluster.weight":
+            continue
+        got, want = store.gview(k).cpu(), v.grad
+        assert torch.isfinite(got).all(), k
+        d = (got - want).abs().max().item()
+        assert d < 1e-4 * max(1.0, want.abs().max().item()), (case, k, d)
+        n += 1
+    assert n > 80

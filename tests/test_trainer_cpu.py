@@ -545,3 +545,55 @@ def test_reduce_metrics_world2_gloo(tmp_path):
     mp.spawn(_metrics_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert torch.load(tmp_path / "m0.pt") == {"feat_loss": 0.5, "n": 30.0, "obj_loss": 4.0}
     assert torch.load(tmp_path / "m1.pt") is None
+
+
+def edge_batch(cfg, lens, masks, L, V, seed):
+    """hand-made batch: text lengths `lens` ([CLS] ... [SEP] then PAD), visual masks `masks` (list of index lists)."""
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens)
+    ids = torch.randint(1, cfg.vocab_size - 2, (B, L), generator=g)
+    ids[:, 0] = cfg.vocab_size - 2
+    for b, n in enumerate(lens):
+        ids[b, n - 1] = cfg.vocab_size - 1
+        ids[b, n:] = 0
+    cid = torch.randint(0, cfg.num_clusters, (B, V), generator=g)
+    vm = torch.zeros(B, V, dtype=torch.bool)
+    for b, idx in enumerate(masks):
+        vm[b, idx] = True
+    lab = cid.clone()
+    lab[~vm] = -100
+    grid = int(V ** 0.5)
+    pos = torch.tensor([[j / grid, i / grid, (j + 1) / grid, (i + 1) / grid] for i in range(grid) for j in range(grid)])
+    am = ids > 0
+    return {"input_ids": ids, "attention_mask": am, "token_type_ids": torch.zeros_like(ids), "cluster_ids": cid, "vis_mask": vm,
+            "obj_labels": lab, "visual_pos": pos[None].expand(B, -1, -1).contiguous()}
+
+
+EDGE_CASES = {"one_example_two_tokens": ([2], [[5]]),
+              "ragged_extremes": ([2, 8, 5, 3], [[], list(range(16)), [15], [0, 3, 7, 8]]),
+              "all_full": ([8, 8], [list(range(16)), list(range(16))])}
+
+
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+def test_edge_case_batches_match_oracle(case):
+    """Corners of the input domain through the engine's host-side logic (packed language rows derived by the engine, masked-row
+    head, loss normalisers), every gradient against the oracle: a [CLS][SEP]-only text, an example without any masked visual
+    token next to one with all of them masked, no padding at all.  (GPU twin: test_engine_gpu.py, same cases on the HIP kernels.)"""
+    cfg = XLxmertConfig(**TINY)
+    lens, masks = EDGE_CASES[case]
+    L, V = 8, 16
+    batch = edge_batch(cfg, lens, masks, L, V, seed=len(lens) * 17 + 1)
+    tr, sd = make_step(cfg, len(lens), L, 4, seed=11, lr=0.0)
+    for _ in range(2):
+        losses = tr.step(batch)
+    want, out = oracle_grads(cfg, sd, batch)
+    assert abs(losses[0].item() - out["obj_loss"].item()) < 1e-5 * max(1.0, abs(out["obj_loss"].item()))
+    assert abs(losses[1].item() - out["feat_loss"].item()) < 1e-5 * max(1.0, abs(out["feat_loss"].item()))
+    n = 0
+    for k, g in want.items():
+        if k == "obj_predict_head.out_cluster.weight":
+            continue
+        d = (tr.store.gview(k) - g).abs().max().item()
+        assert d < 3e-5 * max(1.0, g.abs().max().item()), (case, k, d)
+        n += 1
+    assert n > 80
