@@ -91,8 +91,10 @@ int  xl_set_gemm_tile192(int mode);
 int  xl_set_gemm_persistent(int on);
 /* 128x192 "duo" tiles of the ping-pong kernel: four waves and 80 KiB of LDS per workgroup, TWO workgroups per CU, so that one's
  * prologue / epilogue / hand-over runs under the other's K loop and workgroups of different streams can share a CU.  Eligible:
- * forward / dX layouts, M % 128 == 0, N % 192 == 0, bf16 output through a fast epilogue.  0 = never, 1 = when eligible (and
- * K <= XL_GEMM_DUO_MAX_K), 2 = whenever eligible; env XL_GEMM_DUO.  Bit-identical results to the other tile shapes. */
+ * forward / dX layouts, M % 128 == 0, N % 192 == 0, bf16 output through a fast epilogue.  0 = never, 1 (default) = eligible
+ * launches of at most XL_GEMM_DUO_MAX_TILES (64) tiles of 256x256 -- the language stream's 3328-row contractions, which otherwise
+ * run on the 128x128 kernel at 0.10 MFMA-busy: -0.15..-0.25 ms per step --, 2 = whenever eligible (measured equal to the whole-CU
+ * tiles on the large launches); env XL_GEMM_DUO.  Bit-identical results to the other tile shapes. */
 int  xl_set_gemm_duo(int mode);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */

@@ -227,7 +227,7 @@ def test_gemm_duo_tiles_equal_whole_cu_tiles(M, N, K, bk, epi, p_drop):
                 torch.cuda.synchronize()
             out[mode] = (C, aux)
     finally:
-        ops.set_gemm_duo(0)
+        ops.set_gemm_duo(1)
         ops.set_gemm_pingpong(1)
     assert torch.equal(out[0][0], out[2][0]), (out[0][0].float() - out[2][0].float()).abs().max().item()
     assert torch.equal(out[0][1], out[2][1])
@@ -287,7 +287,7 @@ def _tiles_exact(M, N, K, epi, bk, duo):
     finally:
         ops.set_gemm_pingpong(1)
         ops.set_gemm_tile192(1)
-        ops.set_gemm_duo(0)
+        ops.set_gemm_duo(1)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -430,12 +430,14 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     }                                     //  for an fp32-output launch, which never takes the 192-wide tile)
     // 128x192 "duo" tiles, two four-wave workgroups per CU (gemm_pp_kernel.h PPGeo<192, 128>): same eligibility as the 256x192 tile
     // (forward / dX layouts, N a multiple of 192, fast epilogue, plain stores) with M a multiple of 128
-    if (cx.gemm_duo < 0) cx.gemm_duo = env_int("XL_GEMM_DUO", 0);
-    static const int duo_max_k = env_int("XL_GEMM_DUO_MAX_K", 1 << 30);
+    // mode 1: the launches of fewer than XL_GEMM_DUO_MAX_TILES 256x256 tiles (the language stream's: 3328 packed rows = 39 tiles,
+    // which otherwise go to the 128x128 kernel at 0.10 MFMA-busy); mode 2: every eligible launch
+    if (cx.gemm_duo < 0) cx.gemm_duo = env_int("XL_GEMM_DUO", 1);
+    static const int duo_max_tiles = env_int("XL_GEMM_DUO_MAX_TILES", 64);
     int bm = 256;
-    if (use_pp && cx.gemm_duo && a_kmajor && M % 128 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate && epik >= 0 &&
+    if (pp_ok && pp_mode && cx.gemm_duo && a_kmajor && M % 128 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate && epik >= 0 &&
         colsum_out == nullptr && epilogue != XL_EPI_TANH && epilogue != XL_EPI_ROWMAX && splitk == 1 && !p.atomic_out &&
-        (double)M * lda < 1e9 && (cx.gemm_duo == 2 || K <= duo_max_k)) {
+        (double)M * lda < 1e9 && (cx.gemm_duo == 2 || t256n <= duo_max_tiles)) {
         bm = 128; bn = 192;
         p.tiles_m = M / 128; p.tiles_n = N / 192;
         tiles = p.tiles_m * p.tiles_n;
@@ -481,7 +483,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         }
         XL_CHECK_ARG(e == hipErrorInvalidValue, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    if (use_pp) {
+    if (use_pp || bm == 128) {
         hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st, bm);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     } else if (mfma_ok) {

@@ -145,8 +145,15 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
     __shared__ float red[W * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NIT][VEC] = {}, ab[NIT][VEC] = {}, ax[NIT][VEC] = {};
-    __shared__ float sgamma[NIT * 64 * VEC];      // gamma lives in LDS, not in 16 registers: 4 waves per SIMD instead of 3
-    for (int c = threadIdx.x; c < NIT * 64 * VEC; c += W * 64) sgamma[c] = c < N ? gamma[c] : 0.f;
+    // gamma lives in LDS, not in 16 registers: 4 waves per SIMD instead of 3.  Layout [it][quad of 4 columns][lane][4]: a lane's
+    // 16-byte read sits next to its neighbours' (lane stride 16 B, conflict-free ds_read_b128); in column order the lane stride
+    // is 32 B and every read was a 2-way bank conflict -- 13 % of the kernel's wave cycles by SQ_LDS_BANK_CONFLICT (r03c)
+    constexpr int QD = VEC / 4;
+    __shared__ __attribute__((aligned(16))) float sgamma[NIT * 64 * VEC];
+    for (int c = threadIdx.x; c < NIT * 64 * VEC; c += W * 64) {
+        const int it = c / (64 * VEC), r = c % (64 * VEC), ln = r / VEC, i = r % VEC;
+        sgamma[((it * QD + i / 4) * 64 + ln) * 4 + (i & 3)] = c < N ? gamma[c] : 0.f;
+    }
     __syncthreads();
     for (int row = blockIdx.x * W + wave; row < M; row += gridDim.x * W) {
         // the row stays in registers as loaded (16 bytes per vector) and is unpacked in both passes: fp32 copies of x and
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
                 dr[it] = *reinterpret_cast<const uint4*>(dy + (size_t)row * N + col);
             }
         }
-        int goff = lane * VEC;
+        int goff = lane * 4;
         asm volatile("" : "+v"(goff));          // keep the LDS reads inside the loop (hoisted, they cost the registers back)
         const float mean = mean_i[row], rstd = rstd_i[row];
         float s1 = 0.f, s2 = 0.f;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const float xh = (xv[i] - mean) * rstd;
-                    const float gd = sgamma[it * 64 * VEC + goff + i] * dv[i];
+                    const float gd = sgamma[(it * QD + i / 4) * 256 + goff + (i & 3)] * dv[i];
                     s1 += gd; s2 += gd * xh;
                     ag[it][i] += dv[i] * xh;
                     ab[it][i] += dv[i];
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
                 unpack_raw(dr[it], dv);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    o[i] = rstd * (sgamma[it * 64 * VEC + goff + i] * dv[i] - c1 - (xv[i] - mean) * rstd * c2);
+                    o[i] = rstd * (sgamma[(it * QD + i / 4) * 256 + goff + (i & 3)] * dv[i] - c1 - (xv[i] - mean) * rstd * c2);
                 stvec(dx + (size_t)row * N + col, o);
                 if (dx_drop != nullptr) {          // gradient through the dropout of the dense layer feeding this LN
 #pragma unroll

@@ -87,7 +87,7 @@ class HipOps:
         self._call("xl_set_gemm_persistent", int(on))
 
     def set_gemm_duo(self, mode):
-        """128x192 tiles, two four-wave workgroups per CU: 0 never, 1 when eligible, 2 always when eligible."""
+        """128x192 tiles, two four-wave workgroups per CU: 0 never, 1 small launches (default), 2 every eligible launch."""
         self._call("xl_set_gemm_duo", int(mode))
 
     def set_gemm_tail_split(self, max_tail_tiles, min_k):
