@@ -12,6 +12,9 @@
 // so the recorded argument words are replayed verbatim.  An entry = the function's index in kFns + its arguments, one
 // 64-bit word each (pointers and integers by value, floats as their bit pattern); the typed unpacking below is generated
 // from the prototypes in include/xlxmert_hip.h, so a signature change cannot silently skew a plan.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -159,6 +162,33 @@ extern "C" int xl_plan_run(int64_t plan) {
     }
     XL_CHECK_ARG(p != nullptr, XL_ERR_BAD_ARG, "xl_plan_run: unknown plan %lld", (long long)plan);
     const size_t n = p->fn.size();
+    // debug (XL_PLAN_TRACE=<file>, XL_PLAN_TRACE_RUN=<k>): host time of every call of the k-th replay in this process -- where the
+    // runtime makes the enqueueing thread wait (tools/plan_host_trace.py)
+    static const char* trace_file = getenv("XL_PLAN_TRACE");
+    if (trace_file != nullptr) {
+        static const int trace_run = getenv("XL_PLAN_TRACE_RUN") ? atoi(getenv("XL_PLAN_TRACE_RUN")) : 8;
+        static int run = 0;
+        if (++run == trace_run) {
+            using clk = std::chrono::steady_clock;
+            std::vector<double> t(n + 1);
+            const auto t0 = clk::now();
+            for (size_t i = 0; i < n; ++i) {
+                t[i] = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+                const int rc = kFns[p->fn[i]].call(p->words.data() + p->first[i]);
+                if (rc < 0) return rc;
+            }
+            t[n] = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+            if (FILE* f = fopen(trace_file, "w")) {
+                for (size_t i = 0; i < n; ++i) {
+                    const uint64_t* w = p->words.data() + p->first[i];
+                    const uint64_t last = kFns[p->fn[i]].nargs > 0 ? w[kFns[p->fn[i]].nargs - 1] : 0;     // (the stream, for launches)
+                    fprintf(f, "%zu %s %.1f %.1f %llx\n", i, kFns[p->fn[i]].name, t[i], t[i + 1] - t[i], (unsigned long long)last);
+                }
+                fclose(f);
+            }
+            return XL_OK;
+        }
+    }
     for (size_t i = 0; i < n; ++i) {
         const int rc = kFns[p->fn[i]].call(p->words.data() + p->first[i]);
         if (rc < 0) return rc;                  // xl_last_error() carries the failing call's message
