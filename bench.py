@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="eval-parity mode (the reference trains with p=0.1)")
     ap.add_argument("--single-stream", action="store_true", help="no language/visual stream overlap (profiling)")
     ap.add_argument("--gemm-table", action="store_true", help="print the instrumented step's GEMM time by shape (stderr)")
+    ap.add_argument("--gemm-list", default=None, help="write the instrumented step's GEMM launches in launch order (shape key, algorithmic "
+                                                      "bytes, block, us) as JSON: joined with per-dispatch PMC counters by tools/gemm_overfetch.py")
     ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW on the main stream, in front of the next forward (default: behind the step on a side stream)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: test rig for N ranks SHARING one GPU, "
                     "which RCCL refuses -- with XL_BENCH_SHARE_GPU=1 every rank uses cuda:0)")
@@ -379,6 +381,9 @@ def main():
         traffic, traffic_src = round(tj["bytes_per_launch"]), tj.get("source")
     except Exception:
         pass
+    if rank == 0 and args.gemm_list:
+        json.dump([{"key": list(key), "bytes": _b, "block": _t, "us": s_.elapsed_time(e_) * 1e3, "flops": f_}
+                   for s_, e_, f_, key, _b, _t in gt.rec], open(args.gemm_list, "w"))
     if rank == 0 and args.gemm_table:
         agg = {}
         for s_, e_, f_, key, _b, _t in gt.rec:

@@ -19,7 +19,7 @@ E = lambda: torch.cuda.Event(enable_timing=True)
 eng = tr.engine
 # timing events recorded THROUGH the C ABI (xl_event_record), so that a recorded launch plan contains them
 ev = {}
-for k in ("l0", "l1", "v0", "v1", "vend", "b0", "b1", "r0", "r1"):
+for k in ("l0", "l1", "v0", "v1", "vend", "b0", "b1", "r0", "r1", "xend", "hend", "xbend", "t0", "t1"):
     ev[k] = E(); ev[k].record()
 torch.cuda.synchronize()
 def mark(k):
@@ -44,6 +44,30 @@ def join():
         state["first_join"] = False
     orig_join()
 eng.join = join
+orig_pr = eng._pr
+def pr(key):
+    if key == "heads":
+        mark("xend")
+    orig_pr(key)
+eng._pr = pr
+orig_eb = eng._encoder_backward
+def eb(*a, **k):
+    mark("hend")
+    orig_eb(*a, **k)
+eng._encoder_backward = eb
+orig_ready = eng._ready
+def ready(prefix):
+    orig_ready(prefix)
+    if prefix == "bert.encoder.x_layers.0.":
+        mark("xbend")
+eng._ready = ready
+orig_vmfb = eng.vis_mask_forward_backward
+def vmfb(*a, **k):
+    mark("t0")
+    r = orig_vmfb(*a, **k)
+    mark("t1")
+    return r
+eng.vis_mask_forward_backward = vmfb
 orig_embed_bwd = eng.ops.embed_bwd
 def embed_bwd(*a, **k):
     orig_embed_bwd(*a, **k)
@@ -72,4 +96,6 @@ for i in range(10):
         f = lambda a, b: ev[a].elapsed_time(ev[b]) * 1e3
         print(f"step {i}: {s0.elapsed_time(s1):6.2f} ms | language stack {f('l0', 'l1'):7.0f} us | visual stack: first kernel begins {f('l0', 'v0'):7.0f} us "
               f"after the language stack began, is done at {f('l0', 'v1'):7.0f} us, relational stack done at {f('l0', 'vend'):7.0f} us"
+              f" || phases on the main stream (ms): stacks fwd {f('t0', 'vend') / 1e3:.2f}, cross layers fwd {f('vend', 'xend') / 1e3:.2f}, head fwd+bwd {f('xend', 'hend') / 1e3:.2f}, "
+              f"cross layers bwd {f('hend', 'xbend') / 1e3:.2f}, stacks bwd {f('xbend', 't1') / 1e3:.2f}, total fwd+bwd {f('t0', 't1') / 1e3:.2f}"
               f" || backward: language stack {f('b0', 'b1'):7.0f} us; relational stack's first FFN block begins {f('b0', 'r0'):7.0f} us after it began, done at {f('b0', 'r1'):7.0f} us")

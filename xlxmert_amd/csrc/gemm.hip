@@ -17,6 +17,7 @@
 //       path (XL_F32: parity configuration) and the fallback for operands the MFMA loader cannot
 //       take (leading dimension not a multiple of 8 elements).
 #include <algorithm>
+#include <vector>
 #include <mutex>
 #include <unordered_map>
 #include "gemm_common.h"
@@ -568,6 +569,39 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
         acc += pr.tiles_m * pr.tiles_n;
     }
     for (int i = count; i <= 8; ++i) g.tile_start[i] = acc;
+    // Tile walk.  The launch's linear tile order is cut into 8 contiguous chunks, one per XCD (its own 4 MiB L2); all tiles of a chunk
+    // run side by side through K, so an operand column panel (K x 256) that several of them need is fetched once per chunk.  In
+    // [problem][tn][tm] order a chunk of 27 tiles cuts across problems and rows (two visual layers, 216 tiles: 64 panel fetches per
+    // layer for 48 distinct panels = the 1.33x over-fetch measured by tools/gemm_overfetch.py).  Here every problem's grid is cut into
+    // rectangles of at most one chunk that span its SHORT side completely, and the rectangles are dealt largest first: 54 fetches.
+    g.order_n = 0;
+    static const int group_order = env_int("XL_GEMM_GROUP_ORDER", 1);
+    if (group_order && acc <= kGroupOrderMax && count <= 8) {
+        struct Blk { int prob, m0, m1, n0, n1; };
+        std::vector<Blk> blks;
+        const int chunk = std::max(1, (acc * splitk + 7) / 8);
+        bool ok = true;
+        for (int i = 0; i < count; ++i) {
+            const int tm = g.prob[i].tiles_m, tn = g.prob[i].tiles_n;
+            if (tm > 63 || tn > 63) { ok = false; break; }
+            if (tm >= tn) {
+                const int bm = std::max(1, chunk / tn);
+                for (int m0 = 0; m0 < tm; m0 += bm) blks.push_back({i, m0, std::min(tm, m0 + bm), 0, tn});
+            } else {
+                const int bn = std::max(1, chunk / tm);
+                for (int n0 = 0; n0 < tn; n0 += bn) blks.push_back({i, 0, tm, n0, std::min(tn, n0 + bn)});
+            }
+        }
+        if (ok) {
+            std::stable_sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) {
+                return (a.m1 - a.m0) * (a.n1 - a.n0) > (b.m1 - b.m0) * (b.n1 - b.n0); });
+            int n = 0;
+            for (const Blk& b : blks)
+                for (int tn = b.n0; tn < b.n1; ++tn)
+                    for (int tm = b.m0; tm < b.m1; ++tm) g.order[n++] = (uint16_t)(b.prob << 12 | tm << 6 | tn);
+            g.order_n = n;          // == acc
+        }
+    }
     hipError_t e = launch_pp_group(g, acc * splitk, st);
     XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm_wgrad_group: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     XL_CHECK_LAUNCH();

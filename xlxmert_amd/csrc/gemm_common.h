@@ -700,6 +700,7 @@ __device__ __forceinline__ void epilogue_quad_accum(const GemmParams& p, float* 
     }
 }
 
+constexpr int kGroupOrderMax = 320;
 struct GroupProblem {
     const void* A; const void* B; void* C;
     int M, N, K, lda, ldb, ldc, kper, tiles_m, tiles_n, vec;      // vec: C rows 16-byte aligned (vector accumulate)
@@ -710,6 +711,11 @@ struct GroupParams {
     int rmw;                           // no K split and no two problems share any of C: plain vector read-modify-write, no atomics
     int tile_start[9];                 // prefix sums of the problems' 256x256 tile counts
     GroupProblem prob[8];
+    // tile walk (host-made, xl_gemm_wgrad_group): entry t = problem << 12 | tm << 6 | tn of the t-th tile in launch order, laid out so
+    // that the 1/8 of the tiles that lands on one XCD (one L2) is a few compact rectangles of ONE problem's tile grid -- the tiles of a
+    // rectangle run side by side and share their A / B column panels in that L2.  order_n = 0: [problem][tn][tm] order.
+    int order_n;
+    uint16_t order[kGroupOrderMax];
 };
 hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st);
 

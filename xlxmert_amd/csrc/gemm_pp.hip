@@ -14,9 +14,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     const int total = g.tile_start[g.count];
     const int z = L / total;
     const int t = L - z * total;
-    int i = 0;
+    int i = 0, otm = -1, otn = 0;
+    if (g.order_n > 0) {
+        const int code = g.order[t];
+        i = code >> 12; otm = (code >> 6) & 63; otn = code & 63;
+    } else {
 #pragma unroll 1
-    while (i + 1 < g.count && t >= g.tile_start[i + 1]) ++i;
+        while (i + 1 < g.count && t >= g.tile_start[i + 1]) ++i;
+    }
     const GroupProblem& pr = g.prob[i];
     GemmParams p;
     p.A = pr.A; p.B = pr.B; p.C = pr.C; p.bias = nullptr; p.residual = nullptr; p.aux = nullptr;
@@ -28,7 +33,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
     const int tl = t - g.tile_start[i];
     const int kbeg = z * pr.kper;
-    pp_tile<false, false, -1>(p, tl % pr.tiles_m, tl / pr.tiles_m, kbeg, min(pr.K, kbeg + pr.kper), z == 0,
+    pp_tile<false, false, -1>(p, otm >= 0 ? otm : tl % pr.tiles_m, otm >= 0 ? otn : tl / pr.tiles_m, kbeg, min(pr.K, kbeg + pr.kper), z == 0,
                               (g.slab != nullptr || g.rmw) ? t : -1, z, (pr.K + pr.kper - 1) / pr.kper);
 }
 
