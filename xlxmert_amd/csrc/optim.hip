@@ -237,7 +237,8 @@ extern "C" int xl_adamw(float* p, float* g, float* m, float* v, void* p_compute,
     // step's 202 M parameters (6.9 GB: 6.8 TB/s) against 4096 blocks of 256 threads -- fewer, longer-lived waves keep more
     // 16-byte loads in flight per CU and leave no tail of half-empty CUs.
     constexpr int TH = 1024, LDS = 131072;
-    const int grid = (int)std::min<int64_t>(256, (n4 + TH - 1) / TH);
+    static const int max_blocks = [] { const char* e = getenv("XL_ADAMW_BLOCKS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+    const int grid = (int)std::min<int64_t>(max_blocks, (n4 + TH - 1) / TH);
     static bool attr_b = false, attr_f = false;
     if (dtype == XL_BF16) {
         auto k = adamw_kernel<bf16_t, TH>;
