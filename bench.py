@@ -375,6 +375,18 @@ def main():
     with GemmTimer(tr.ops) as gt:
         tr.step(get(0))
     tr.engine.side, tr.plan_mode = side, planned
+    # what the event pair itself adds to every timed launch: the same start / end markers around a one-wave kernel (a 64-element cast);
+    # reported next to the roofline figures, never subtracted from them
+    probe, probe_o = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda", dtype=torch.bfloat16)
+    pairs = []
+    if hasattr(torch.cuda, "_sleep"):
+        torch.cuda._sleep(40000000)           # (the stream stays busy while the 200 triplets are queued: no host latency in the intervals)
+    for _ in range(200):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record(); tr.ops.cast_from_f32(probe, probe_o, 64); e_.record()
+        pairs.append((s_, e_))
+    torch.cuda.synchronize()
+    ev_floor = sorted(a.elapsed_time(b) for a, b in pairs)[100] * 1e3
     traffic, traffic_src = None, None
     try:        # HBM bytes per GEMM launch from the committed PMC profile of this build (cannot be collected live)
         tj = json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic.json")))
@@ -436,6 +448,8 @@ def main():
                          "blocks": gt.by_block(PEAK_BF16_TFLOPS),
                          "launches_per_step": gt.launches, "avg_launch_us": round(gt.total_ms * 1e3 / gt.launches, 2),
                          "gemm_ms_per_step": round(gt.total_ms, 3),
+                         "event_pair_floor_us": round(ev_floor, 2),     # start/end markers around a one-wave kernel: part of every avg_launch_us
+
                          "algorithmic_gflop_per_step": round(gt.flops / 1e9, 1),
                          "contract_gflop_per_step": round(GFLOP_PER_EXAMPLE * B, 1)},
         }

@@ -412,6 +412,28 @@ def test_gemm_wgrad_single_problem_slabs_exact(slab_ws):
         ops.set_gemm_pingpong(1)
 
 
+@pytest.mark.parametrize("K", [320, 1536])
+def test_gemm_wgrad_group_two_layer_tile_walk_exact(K):
+    """The step's own grouped launch -- the eight weight gradients of two transformer layers, 216 tiles of 256x256, one writer per
+    tile -- whose tiles the host deals in XCD-sized rectangles (GroupParams::order: full-height / full-width blocks of the tall / wide
+    problems, largest first).  Integer-valued operands: every dW must equal the host product exactly, twice in a row (+=), so a tile
+    visited twice or never by the walk cannot hide."""
+    g = torch.Generator().manual_seed(K)
+    ops = hip(torch.bfloat16)
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)] * 2
+    probs, refs = [], []
+    for m, n in shapes:
+        dY = torch.randint(-2, 3, (K, m), generator=g).to(torch.bfloat16)
+        X = torch.randint(-2, 3, (K, n), generator=g).to(torch.bfloat16)
+        refs.append(dY.float().t() @ X.float())
+        probs.append((dY.cuda(), X.cuda(), torch.zeros(m, n, device="cuda"), m, n, K, m, n, n))
+    for rep in (1, 2):
+        ops.gemm_wgrad_group(probs)
+        torch.cuda.synchronize()
+        for (m, n), pr, ref in zip(shapes, probs, refs):
+            assert torch.equal(pr[2].cpu(), ref * rep), f"rep {rep} dW {m}x{n}: max abs diff {(pr[2].cpu() - ref * rep).abs().max().item()}"
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows", [(2048, 2048, 2048), (1536, 640, 1536)])
 def test_gemm_wgrad_group(rows, dtype, slab_ws):
