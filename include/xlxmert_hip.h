@@ -99,6 +99,11 @@ int  xl_set_gemm_duo(int mode);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */
 int  xl_gemm_trace(void* buffer);
+/* debug / test: the row kernels' wave reductions run on the VALU's cross-lane paths (v_permlane32_swap, v_permlane16_swap, DPP) with
+ * the pairing of the xor-shuffle butterfly; this evaluates both forms on n_waves x 64 inputs: sum_new / max_new (cross-lane form, as
+ * used by LayerNorm / softmax / cross-entropy kernels) and sum_ref (the __shfl_xor form), each n_waves x 64 floats -- every lane's
+ * result.  The test asserts sum_new == sum_ref bit for bit. */
+int  xl_wave_reduce_check(const float* in, float* sum_new, float* max_new, float* sum_ref, int n_waves, void* stream);
 
 /* ---------------------------------------------------------------- dense contractions (nn.Linear)
  * C[M,N] = alpha * sum_k A(m,k) * B(n,k)  [+ bias[n]]  -> epilogue

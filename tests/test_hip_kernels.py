@@ -978,3 +978,25 @@ def test_gather_scatter_rows_and_row_mapped_featloss(dtype):
     torch.cuda.synchronize()
     assert abs(loss_a.item() - loss_c.item()) <= 1e-5 * max(1.0, abs(loss_a.item()))
     assert torch.equal(d_all[rows.long().cuda()], d_c)
+
+
+def test_wave_reductions_cross_lane_form_equals_shuffle_form():
+    """wave_sum / wave_max of the row kernels (LayerNorm, softmax / cross-entropy rows, norms) use v_permlane32_swap,
+    v_permlane16_swap and DPP with the xor butterfly's pairing: every lane's sum must be BIT-identical to the __shfl_xor form
+    (same partner at every step), all 64 lanes of a wave must agree, and the maximum must be the wave's maximum."""
+    ops = hip(torch.float32)
+    g = torch.Generator().manual_seed(3)
+    n = 512
+    x = torch.randn(n, 64, generator=g) * torch.logspace(-3, 3, n).view(n, 1)          # magnitudes over six decades
+    x[5] = torch.arange(64.0)                        # every lane distinct: a wrong partner at any step changes some lane's sum
+    x[6] = 2.0 ** torch.arange(64.0) * 1e-6
+    xs = x.cuda()
+    outs = [torch.zeros(n, 64, device="cuda") for _ in range(3)]
+    ops.lib.call("xl_wave_reduce_check", xs.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), n,
+                 torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    s_new, m_new, s_ref = (o.cpu() for o in outs)
+    assert torch.equal(s_new, s_ref)
+    assert (s_new == s_new[:, :1]).all()
+    assert torch.equal(m_new, x.max(1, keepdim=True).values.expand(-1, 64))
+    assert torch.equal(s_new[5], torch.full((64,), 2016.0))

@@ -90,14 +90,48 @@ __device__ __forceinline__ void stvec(bf16_t* p, const float (&v)[8]) {
 }
 
 // ------------------------------------------------------------------ wave / block reductions (wave = 64)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// The xor butterfly 32, 16, 8, 4, 2, 1 -- every lane ends with the same value -- through the cross-lane data paths of the VALU
+// instead of six ds_bpermute round trips through the LDS crossbar (what __shfl_xor compiles to: ~6 x 64 cycles of dependent
+// latency per reduction, two or four reductions per LayerNorm row).  Same partner at every step, so the sums are bit-identical to
+// the shuffle form:  32: v_permlane32_swap (x = {lo, lo}, y = {hi, hi});  16: v_permlane16_swap (even / odd rows of 16);
+// 8: DPP row_ror:8 (a rotation by half a row IS xor 8);  4: DPP row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3;
+// 2, 1: DPP quad_perm.
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf,
+                                                                 BANK_MASK, false));
+}
+__device__ __forceinline__ float lane_xor4(float v) { return dpp_f<0x114, 0xa>(dpp_f<0x104, 0x5>(v, v), v); }   // row_shl:4 | row_shr:4
+template <class Op>
+__device__ __forceinline__ float wave_butterfly(float v, Op op) {
+    // (the swap builtins are given two copies of v; the second goes through an empty asm so that the optimiser cannot see they are
+    //  equal -- with identical operands hipcc 7.0 folds the two results into one and emits op(r0, r0))
+    {
+        unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+        asm volatile("" : "+v"(b));
+        const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        const unsigned r0 = r[0], r1 = r[1];          // (__builtin_bit_cast applied to r[1] directly reads element 0: clang 22)
+        v = op(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+    }
+    {
+        unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+        asm volatile("" : "+v"(b));
+        const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        v = op(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+    }
+    v = op(v, dpp_f<0x128>(v, v));          // row_ror:8
+    v = op(v, lane_xor4(v));
+    v = op(v, dpp_f<0x4e>(v, v));           // quad_perm [2,3,0,1]
+    v = op(v, dpp_f<0xb1>(v, v));           // quad_perm [1,0,3,2]
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ float wave_sum(float v) { return wave_butterfly(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); }); }
+// reference form (tests: xl_wave_reduce_check compares the two bit for bit)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 

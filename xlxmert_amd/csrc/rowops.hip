@@ -1453,6 +1453,23 @@ extern "C" int xl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n,
     return XL_OK;
 }
 
+namespace xl {
+__global__ __launch_bounds__(64) void wave_reduce_check_kernel(const float* __restrict__ in, float* sum_new, float* max_new, float* sum_ref) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const float v = in[i];
+    sum_new[i] = wave_sum(v);
+    max_new[i] = wave_max(v);
+    sum_ref[i] = wave_sum_shfl(v);
+}
+}  // namespace xl
+
+extern "C" int xl_wave_reduce_check(const float* in, float* sum_new, float* max_new, float* sum_ref, int n_waves, void* stream) {
+    XL_CHECK_ARG(in && sum_new && max_new && sum_ref && n_waves > 0, XL_ERR_BAD_ARG, "xl_wave_reduce_check: bad args");
+    hipLaunchKernelGGL(xl::wave_reduce_check_kernel, dim3(n_waves), dim3(64), 0, (hipStream_t)stream, in, sum_new, max_new, sum_ref);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
 extern "C" int xl_dropout(const void* x, void* y, int M, int N, int ldx, int ldy, float p_drop, uint64_t seed, int dtype,
                           void* stream) {
     CHECK_ROW(N, dtype);
