@@ -92,8 +92,10 @@ __device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         __syncthreads();
+        // [i][wave][lane]: neighbouring lanes hit neighbouring banks (lane-major [wave][lane][i] was an 8-way conflict on every
+        // access: 9.5 % of the LayerNorm backward's wave cycles by SQ_LDS_BANK_CONFLICT, profiles/r03e)
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) red[(wave * 64 + lane) * VEC + i] = acc[it][i];
+        for (int i = 0; i < VEC; ++i) red[(i * W + wave) * 64 + lane] = acc[it][i];
         __syncthreads();
         if (wave == 0) {
             const int col = (it * 64 + lane) * VEC;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out
                 for (int i = 0; i < VEC; ++i) {
                     float s = 0.f;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) s += red[(w * 64 + lane) * VEC + i];
+                    for (int w = 0; w < W; ++w) s += red[(i * W + w) * 64 + lane];
                     if (ws_slot != nullptr) ws_slot[col + i] = s;
                     else atomicAdd(out + col + i, s);
                 }
@@ -176,13 +178,16 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
         for (int it = 0; it < NIT; ++it) {
             const int col = (it * 64 + lane) * VEC;
             if (col < N) {
-                float xv[VEC], dv[VEC];
+                float xv[VEC], dv[VEC], gm[VEC];
                 unpack_raw(xr[it], xv);
                 unpack_raw(dr[it], dv);
 #pragma unroll
+                for (int q = 0; q < QD; ++q)          // one ds_read_b128 per four columns (lane stride 16 B: conflict-free)
+                    *reinterpret_cast<float4*>(&gm[4 * q]) = *reinterpret_cast<const float4*>(__builtin_assume_aligned(&sgamma[(it * QD + q) * 256 + goff], 16));
+#pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const float xh = (xv[i] - mean) * rstd;
-                    const float gd = sgamma[(it * QD + i / 4) * 256 + goff + (i & 3)] * dv[i];
+                    const float gd = gm[i] * dv[i];
                     s1 += gd; s2 += gd * xh;
                     ag[it][i] += dv[i] * xh;
                     ab[it][i] += dv[i];
@@ -194,12 +199,15 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
         for (int it = 0; it < NIT; ++it) {
             const int col = (it * 64 + lane) * VEC;
             if (col < N) {
-                float xv[VEC], dv[VEC], o[VEC];
+                float xv[VEC], dv[VEC], o[VEC], gm[VEC];
                 unpack_raw(xr[it], xv);
                 unpack_raw(dr[it], dv);
 #pragma unroll
+                for (int q = 0; q < QD; ++q)
+                    *reinterpret_cast<float4*>(&gm[4 * q]) = *reinterpret_cast<const float4*>(__builtin_assume_aligned(&sgamma[(it * QD + q) * 256 + goff], 16));
+#pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    o[i] = rstd * (sgamma[(it * QD + i / 4) * 256 + goff + (i & 3)] * dv[i] - c1 - (xv[i] - mean) * rstd * c2);
+                    o[i] = rstd * (gm[i] * dv[i] - c1 - (xv[i] - mean) * rstd * c2);
                 stvec(dx + (size_t)row * N + col, o);
                 if (dx_drop != nullptr) {          // gradient through the dropout of the dense layer feeding this LN
 #pragma unroll
