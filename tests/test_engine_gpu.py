@@ -1211,7 +1211,10 @@ def test_two_library_contexts_interleaved_in_one_process():
     tr.sync()
     for a, b in zip(alone, mixed):
         assert torch.allclose(a, b, rtol=2e-5, atol=1e-6), (a, b)        # (fp32 atomics: not bit-identical run to run)
-    assert abs(tr.grad_norm() - alone_n) < 2e-4 * alone_n
+    # (the last step's gradient norm of a bf16 model four updates in: summation-order noise of the fp32 atomics is amplified by bf16
+    #  rounding flips of the updated weights -- 3.3e-4 relative seen once in ~15 runs, 1e-5..1e-4 otherwise; a context leaking
+    #  into the other -- wrong kernel switch, wrong step-seed pointer -- moves it by O(1))
+    assert abs(tr.grad_norm() - alone_n) < 2e-3 * alone_n
     assert (tr.store.master - alone_p).abs().max().item() < 2e-5
 
 
