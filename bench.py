@@ -1,6 +1,6 @@
 """Headline benchmark: masked-visual-token pretraining step throughput (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 20        (the defaults: SURVEY 8d)
     python bench.py --gpus N ...                     (no WORLD_SIZE in the environment: starts its own N ranks, as the reference's
                                                       entry point does with mp.spawn, ref pretrain/lxmert_pretrain.py:865)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -235,8 +235,8 @@ def other_workloads(cfg, dev, steps=20, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)          # >= 100 timed steps after >= 20 warm-up steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (reference --batchSize, param.py:70)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the SURVEY 8f workloads (VQA / NLVR2 / word_mask / matched / sampler)")
@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: test rig for N ranks SHARING one GPU, "
                     "which RCCL refuses -- with XL_BENCH_SHARE_GPU=1 every rank uses cuda:0)")
     ap.add_argument("--eager", action="store_true", help="enqueue every step from Python instead of replaying the recorded launch plan")
+    ap.add_argument("--collective", default=None, choices=["allreduce", "rs+ag"], help="gradient exchange at N > 1: all-reduce + "
+                    "replicated AdamW (default) or reduce-scatter -> shard-local AdamW -> all-gather (trainer.PretrainStep collective)")
     ap.add_argument("--resident-inputs", action="store_true", help="minibatches resident in HBM before the timed region (default: "
                     "pinned host memory, uploaded inside the timed step on a copy stream, one step ahead)")
     args = ap.parse_args()
@@ -316,7 +318,7 @@ def main():
                       total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout,
                       bucket_mb=float(os.environ.get("XL_BUCKET_MB", "64")),
                       plan=(not args.eager and not args.single_stream), drop_grads=True,
-                      overlap_optimizer=not (args.no_opt_overlap or args.single_stream))
+                      overlap_optimizer=not (args.no_opt_overlap or args.single_stream), collective=args.collective)
     if args.single_stream:
         tr.engine.side = None
     g = torch.Generator().manual_seed(9595)
@@ -344,13 +346,20 @@ def main():
         cur, nxt = nxt, get(i + 1)
         tr.step(cur)
     sync()
+    # one timing event per step boundary on the main stream (a marker packet, no wait): the spread of the step time inside this
+    # run (ms_per_step_p10 / p50 / p90); `value` and ms_per_step come from the wall clock around the whole region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         cur, nxt = nxt, get(args.warmup + i + 1)
         losses = tr.step(cur)
+        marks[i + 1].record()
     t_enqueue = time.perf_counter() - t0          # host time to queue the work (GPU-bound if << wall time)
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)
     tmax = torch.tensor([dt], device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -410,7 +419,8 @@ def main():
         out = {
             "metric": "pretrain examples/sec (20 text tok x 64 vis tok, bs=256)", "value": round(value, 1),
             "unit": "examples/s", "n_gpus": 1 if share_gpu else world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 3), "ms_per_step_p10": pct(0.10), "ms_per_step_p50": pct(0.50), "ms_per_step_p90": pct(0.90),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]+[2]: full X-LXMERT encoder 9L/5R/5X d=768 + obj_predict_head over 10k codebook, "
                                    "masked-visual-token step fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world,
@@ -462,13 +472,20 @@ def main():
         if world > 1 or grouped:
             out["config"]["gradient_exchange"] = {
                 "backend": args.backend + (" (= RCCL over xGMI)" if args.backend == "nccl" else " (host-staged: test rig)"),
-                "collective": "all-reduce (sum; 1/N folded into AdamW) per finished slice of the flat gradient buffer",
+                "collective": tr.collective,
+                "collective_note": ("reduce-scatter (sum) per finished slice of the flat gradient buffer -> shard-local norm + one scalar "
+                                    "all-reduce -> AdamW over this rank's shards -> all-gather of the fp32 master slices, first-needed "
+                                    "first, overlapping the next forward" if tr.sharded else
+                                    "all-reduce (sum; 1/N folded into AdamW) per finished slice of the flat gradient buffer; every rank "
+                                    "runs the whole AdamW pass"),
+                "optimizer_elements_per_rank": int(sum(b - a for a, b in tr.owned_ranges())),
+                "optimizer_elements_total": int(tr.store.n_used),
                 "element_type": "bf16" if tr.comm_buf is not None else "fp32",
                 "bucket_mb": round(tr.bucket_elems * (2 if tr.comm_buf is not None else 4) / (1 << 20), 1),
                 "bytes_per_step": int(tr.store.n_used * (2 if tr.comm_buf is not None else 4)),
                 "issued_by": ("xl_comm_* (the library's own RCCL binding: the collectives are entries of the launch plan, XL_COMM=rccl)"
                               if tr.xl_comm is not None else "torch.distributed (host operations between the segments of the launch plan)"),
-                "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3) if tr.xl_comm is None else None}
+                "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3)}
         if not args.no_extra and world == 1 and not args.single_stream:
             del tr, batches
             torch.cuda.empty_cache()

@@ -307,15 +307,19 @@ def test_gradient_ranges_are_final_when_reported():
             assert any(lane == "l" and s != main for _, _, lane, s in seen)
 
 
-@pytest.mark.parametrize("via,plan,comm_dtype", [("torch", False, None), ("torch", True, None), ("rccl", False, None),
-                                                  ("rccl", True, None), ("rccl", True, torch.bfloat16)])
-def test_exchange_on_one_rank_rccl_group_is_identity(via, plan, comm_dtype):
+@pytest.mark.parametrize("via,plan,comm_dtype,collective", [
+    ("torch", False, None, "allreduce"), ("torch", True, None, "allreduce"), ("rccl", False, None, "allreduce"),
+    ("rccl", True, None, "allreduce"), ("rccl", True, torch.bfloat16, "allreduce"),
+    ("rccl", False, None, "rs+ag"), ("rccl", True, None, "rs+ag"), ("rccl", True, torch.bfloat16, "rs+ag"), ("torch", True, None, "rs+ag")])
+def test_exchange_on_one_rank_rccl_group_is_identity(via, plan, comm_dtype, collective):
     """The data-parallel exchange through a real RCCL process group (one rank: every all-reduce is the identity): the
     collectives are queued from three streams (main, language-range reports, end of step) exactly as on N GPUs, and the
     training steps must give the same losses, gradient norm and parameters as the same steps without the exchange.
     via = "torch": torch.distributed issues the collectives (in a launch plan: host operations between plan segments);
     via = "rccl": the library's own RCCL binding (xl_comm_*, XL_COMM=rccl) -- the collectives are entries of ONE plan.
-    plan: the third step is a plan replay."""
+    plan: the third step is a plan replay.
+    collective = "rs+ag": reduce-scatter -> shard-local norm (+ scalar all-reduce) / AdamW -> all-gather of the master slices + cast
+    on the collectives' stream, the next forward waiting slice by slice (xl_comm_reduce_scatter / _allgather, events)."""
     import os
     import socket
     import torch.distributed as dist
@@ -344,18 +348,24 @@ def test_exchange_on_one_rank_rccl_group_is_identity(via, plan, comm_dtype):
                             device_id=torch.device("cuda:0"))
     try:
         tr = PretrainStep(cfg, 64, 20, 64, dtype=torch.bfloat16, device="cuda", seed=1, bucket_mb=8, plan=plan, drop_grads=False,
-                          grad_comm_dtype=comm_dtype)
-        assert tr.exchange and tr.world == 1 and (tr.xl_comm is not None) == (via == "rccl")
+                          grad_comm_dtype=comm_dtype, collective=collective)
+        assert tr.exchange and tr.world == 1 and (tr.xl_comm is not None) == (via == "rccl") and tr.collective == collective
         got = run(tr)
         assert len(tr._slices) > 4, len(tr._slices)
+        if collective == "rs+ag":           # one rank: every slice is one whole shard, no replicated tail; the forward is hooked
+            assert tr.sharded and [k for k, _, _ in tr._segments] == ["rs"] * len(tr._slices)
+            assert tr.owned_ranges() == [(a, b) for _, a, b in tr._segments]
+            assert (tr.engine.params_ready is not None) == (via == "rccl") and (via != "rccl" or len(tr._group_seg) > 5)
         lo, hi = tr.store.language_range()
         assert any(lo <= a < hi for a, _ in tr._slices)
         if plan:
             (p,) = tr._plans.values()
             if via == "rccl":               # one plan, the collectives inside it
                 assert p.n_segments == 1 and p.n_host_ops == 0
-            else:                           # segments around torch.distributed's collectives
+            elif collective == "allreduce":  # segments around torch.distributed's collectives
                 assert p.n_host_ops == len(tr._slices) + 1 and p.n_segments >= len(tr._slices)
+            else:                           # ... + the norm's scalar all-reduce and one all-gather per slice
+                assert p.n_host_ops == 2 * len(tr._slices) + 2
     finally:
         dist.destroy_process_group()
         os.environ.pop("XL_FORCE_EXCHANGE", None)
@@ -659,6 +669,47 @@ def test_language_pretraining_steps_bf16_stated_tolerance(task):
             got = eng.store.gview(k).cpu().double()
             rel = (got - ref).norm().item() / max(ref.norm().item(), 1e-4)
             assert rel < 6e-2, (k, rel, rows)
+
+
+def test_batch_uploader_slot_is_released_after_the_labels_are_copied():
+    """the label tensors of the language / VQA branches are copied into the engine's buffers INSIDE the
+    *_forward_backward calls, so the staging slot of a BatchUploader may only be handed back after them.  Four word_mask batches
+    with distinct labels through a two-slot uploader, the main stream held busy in front of every label copy (so that a slot
+    released early IS refilled by the upload of the batch two steps ahead before its labels are read): every step's loss must
+    be the loss of ITS batch (learning rate 0: the reference value is the same batch stepped directly)."""
+    from test_trainer_cpu import TINY, oracle_cfg
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import BatchUploader, PretrainStep, synthetic_batch, word_rows_of
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    B, L, grid = 4, 8, 4
+    tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cuda", task="word_mask", seed=5, lr=0.0, total_steps=100)
+    host = []
+    for i in range(4):
+        b = synthetic_batch(cfg, B, L, grid, seed=40 + i)
+        wl, _ = O.make_lang_task_labels(oc, b["input_ids"], 60 + i)
+        host.append({"input_ids": b["input_ids"], "visual_pos": b["visual_pos"], "cluster_ids": b["cluster_ids"], "word_labels": wl,
+                     "word_rows": word_rows_of(wl), "lang_rows": b["lang_rows"], "lang_off": b["lang_off"]})
+    ref = []
+    for b in host:
+        ref.append(tr.step({k: v.cuda() for k, v in b.items()}).clone())
+    torch.cuda.synchronize()
+    assert len({round(r.item(), 5) for r in ref}) == 4          # the four batches really have four different losses
+    orig = tr.engine.word_mask_forward_backward
+
+    def held(*a, **kw):
+        torch.cuda._sleep(150_000_000)                          # ~70 ms of main-stream time in front of the label copies
+        return orig(*a, **kw)
+    tr.engine.word_mask_forward_backward = held
+    up = BatchUploader("cuda")
+    packed = [BatchUploader.pin(b) for b in host]
+    nxt, got = up.upload(packed[0]), []
+    for i in range(4):
+        cur, nxt = nxt, up.upload(packed[(i + 1) % 4])
+        got.append(tr.step(cur).clone())
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert abs(got[i].item() - ref[i].item()) < 1e-5, (i, got[i].item(), [r.item() for r in ref])
 
 
 def test_word_mask_full_size_step_properties_bf16():

@@ -303,6 +303,61 @@ def test_data_parallel_world2_gloo(tmp_path):
         assert (r0[k] - p).abs().max().item() < 2e-5, k
 
 
+def _dp_worker_sharded(rank, world, port, out_dir):
+    """the same three steps through both collectives: all-reduce + replicated AdamW, and reduce-scatter ->
+    shard-local norm / AdamW -> all-gather of the master weights."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 2, 8, 4
+    res = {}
+    for name, kw in (("ar", dict(collective="allreduce")), ("rs", dict(collective="rs+ag")),
+                     ("ar_noclip", dict(collective="allreduce", clip_grad_norm=0.0)), ("rs_noclip", dict(collective="rs+ag", clip_grad_norm=0.0)),
+                     ("rs_bf16", dict(collective="rs+ag", grad_comm_dtype=torch.bfloat16)),
+                     ("ar_bf16", dict(collective="allreduce", grad_comm_dtype=torch.bfloat16))):
+        tr, sd = make_step(cfg, B, L, grid, lr=1e-2, weight_decay=0.01, bucket_mb=0.05, **kw)
+        assert tr.collective == kw["collective"] and tr.sharded == (kw["collective"] == "rs+ag")
+        for t in range(3):
+            tr.step(synthetic_batch(cfg, B, L, grid, seed=500 + 10 * t + rank))
+            if tr.sharded:
+                # this rank's pass covers its piece of every scattered slice + the replicated tails: half of the buffer, and the
+                # pieces are whole 256-element optimizer chunks
+                own = tr.owned_ranges()
+                assert all(a % 256 == 0 and b % 256 == 0 for a, b in own)
+                n_rs = sum(hi - lo for k, lo, hi in tr._segments if k == "rs")
+                n_ar = sum(hi - lo for k, lo, hi in tr._segments if k == "ar")
+                assert n_rs + n_ar == tr.store.n_used and n_ar < 256 * world * len(tr._slices)
+                assert sum(b - a for a, b in own) == n_rs // world + n_ar
+        # master weights and compute copy are whole and identical on both ranks after every step; the Adam moments once gathered
+        assert tr.verify_replicas() == [], (name, tr.verify_replicas()[:4])
+        res[name] = {k: tr.store.view(k).clone() for k in tr.store.names()}
+        res[name + ":m"] = tr.store.exp_avg[:tr.store.n_used].clone()
+        res[name + ":norm"] = tr.grad_norm()
+    torch.save(res, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_equals_allreduce_world2_gloo(tmp_path):
+    """collective="rs+ag": replicas identical, and after three steps the parameters equal the all-reduce path's -- bit for bit
+    without clipping (two ranks: a + b either way), to 1e-6 with it (the norm's summation order differs: shard-local partial
+    sums + one scalar all-reduce), also with bf16 buckets; the first moments agree as well."""
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker_sharded, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    for name in ("ar", "rs", "ar_noclip", "rs_noclip", "rs_bf16", "ar_bf16"):
+        for k in r0[name]:
+            assert torch.equal(r0[name][k], r1[name][k]), (name, k)
+        assert torch.equal(r0[name + ":m"], r1[name + ":m"]), name
+    for k in r0["ar"]:
+        assert torch.equal(r0["ar_noclip"][k], r0["rs_noclip"][k]), k
+        assert (r0["ar"][k] - r0["rs"][k]).abs().max().item() < 1e-6, k
+        assert (r0["ar_bf16"][k] - r0["rs_bf16"][k]).abs().max().item() < 1e-6, k
+    assert torch.equal(r0["ar_noclip:m"], r0["rs_noclip:m"])
+    assert abs(r0["ar:norm"] - r0["rs:norm"]) < 1e-5 * max(1.0, r0["ar:norm"])
+
+
 def _dp_worker_modes(rank, world, port, out_dir):
     """bf16 gradient buckets; VQA step; task round-robin with the QA head; per-tensor replica verification."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -350,11 +405,15 @@ def _dp_worker_modes(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_data_parallel_world2_gloo_bf16_buckets_vqa_and_round_robin(tmp_path):
+@pytest.mark.parametrize("collective", ["allreduce", "rs+ag"])
+def test_data_parallel_world2_gloo_bf16_buckets_vqa_and_round_robin(tmp_path, monkeypatch, collective):
     """world 2 over gloo: (1) bf16 gradient buckets = one AdamW step on the mean of the per-rank gradients up to the bf16
     rounding of the exchanged values; (2) VQA step and (3) task round-robin with the QA head keep the replicas bit-identical
-    and equal the oracle's mean-gradient update; (4) verify_replicas names a diverged tensor."""
+    and equal the oracle's mean-gradient update; (4) verify_replicas names a diverged tensor.  Both collectives: all-reduce with
+    the replicated optimizer pass, and reduce-scatter -> shard-local AdamW -> all-gather (per-chunk skip flags and update counts
+    sliced per shard)."""
     world, port = 2, _free_port()
+    monkeypatch.setenv("XL_COLLECTIVE", collective)          # (inherited by the spawned ranks)
     mp.spawn(_dp_worker_modes, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "m0.pt"), torch.load(tmp_path / "m1.pt")
     for mode in ("bf16", "vqa"):
@@ -467,9 +526,14 @@ def test_gradient_accumulation_update_freq():
     B, L, grid = 3, 8, 4
     tr, sd = make_step(cfg, B, L, grid, lr=1e-2, warmup_ratio=0.0)
     batches = [synthetic_batch(cfg, B, L, grid, seed=300 + i) for i in range(4)]
+    seeds = []
     for i in range(3):
         tr.step(batches[i], update=(i == 2))
         assert tr.t == (1 if i == 2 else 0)
+        seeds.append(tr.engine._seed)
+    # every micro-batch of the window draws its own dropout masks (the reference runs a fresh forward per minibatch): the step
+    # part of the seeds follows the forward counter, not the update counter
+    assert seeds == [0, 1, 2] and tr.micro == 3 and tr.state() == {"t": 1, "micro": 3}
     gs = [oracle_grads(cfg, sd, b)[0] for b in batches[:3]]
     names = sorted(gs[0])
     total = [gs[0][k] + gs[1][k] + gs[2][k] for k in names]

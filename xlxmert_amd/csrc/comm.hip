@@ -113,11 +113,20 @@ extern "C" int64_t xl_comm_init(const void* id128, int rank, int nranks, void* c
     const int rc = r->CommInitRank(&c->comm, nranks, id, rank);
     if (rc != 0) { set_error("xl_comm_init: RCCL error %d: %s", rc, r->GetErrorString(rc)); delete c; return 0; }
     bool ok = true;
+    for (int i = 0; i < 64; ++i) c->ev[i] = nullptr;
     if (comm_stream != nullptr) c->stream = (hipStream_t)comm_stream;
     else { ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = ok; }
     for (int i = 0; i < 64 && ok; ++i) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->done, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { set_error("xl_comm_init: stream / event creation failed"); return 0; }
+    if (!ok) {                     // give back everything made so far: the communicator, the events, an own stream, the object
+        set_error("xl_comm_init: stream / event creation failed");
+        (void)r->CommDestroy(c->comm);
+        for (int i = 0; i < 64; ++i) if (c->ev[i] != nullptr) (void)hipEventDestroy(c->ev[i]);
+        if (c->done != nullptr) (void)hipEventDestroy(c->done);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return 0;
+    }
     std::lock_guard<std::mutex> lk(g_comm_mu);
     g_comms.push_back(c);
     return (int64_t)g_comms.size();

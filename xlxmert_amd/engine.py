@@ -606,7 +606,8 @@ class Engine:
         LayerNorm runs over those rows, the attention cores address an example's rows through the offsets (xl_sdpa_* q_rowoff /
         k_rowoff), and the final language output is scattered back to [B, L, d] with zero rows at the [PAD] positions (the
         reference leaves don't-care values there).  Exact for the real rows and for every gradient.  Default: env XL_PACK_LANG
-        (on); the nn.Module surface passes False where it hands out per-layer hidden states."""
+        (on).  The nn.Module surface runs packed too: hidden_states() scatters the per-layer language states back to the dense
+        [B*L, d] layout on request."""
         assert cfg.l_layers >= 1 and cfg.r_layers >= 1 and cfg.x_layers >= 1
         assert L <= 64 and V <= 64, "attention kernels hold a whole (batch, head) problem on chip: n <= 64"
         self.cfg, self.store, self.ops = cfg, store, ops

@@ -5,6 +5,8 @@ torch is only the allocator / stream provider here.  Every method mirrors one `x
 (same argument meaning); tensors may be views -- the pointer passed is `tensor.data_ptr()`.
 There is no CPU or eager fallback: a CPU tensor or a missing library raises.
 """
+import threading
+
 import torch
 
 from ._lib import XlError, get_lib
@@ -39,25 +41,38 @@ class HipOps:
         if self.ctx <= 0:
             raise XlError("xl_ctx_create failed")
 
-    _bound = None                    # context currently bound to this (the only calling) thread
+    # The context bound to the CALLING THREAD, mirrored on the host so that a call binds only when it has to.  xl_ctx_bind is
+    # thread-local in the library (csrc/common.h t_ctx), so the mirror is too: autograd runs the backward of the nn.Module
+    # surface (_VqaFn / _HeadFn / _EncoderFn) on a device worker thread, which starts in the default context whatever the main
+    # thread has bound.
+    _tls = threading.local()
+
+    @staticmethod
+    def bound():
+        return getattr(HipOps._tls, "ctx", None)
+
+    @staticmethod
+    def forget_binding():
+        """the calling thread's binding is unknown (a launch plan was replayed: its last recorded bind is in effect)"""
+        HipOps._tls.ctx = None
 
     def _call(self, name, *args):
-        if HipOps._bound != self.ctx:
+        if HipOps.bound() != self.ctx:
             self.lib.call("xl_ctx_bind", self.ctx)
-            HipOps._bound = self.ctx
+            HipOps._tls.ctx = self.ctx
         return self.lib.call(name, *args)
 
     def rebind(self):
         """bind this object's context unconditionally (first entry of a recorded launch plan; after a plan replay, whose last
         recorded bind -- possibly another object's -- is the one in effect)."""
-        HipOps._bound = self.ctx
+        HipOps._tls.ctx = self.ctx
         self.lib.call("xl_ctx_bind", self.ctx)
 
     def __del__(self):
         try:                             # raw calls: a collection that happens while a plan is being recorded must not end up in it
-            if HipOps._bound == self.ctx:
+            if HipOps.bound() == self.ctx:
                 self.lib.raw("xl_ctx_bind")(0)
-                HipOps._bound = None
+                HipOps._tls.ctx = None
             self.lib.raw("xl_ctx_destroy")(self.ctx)
         except Exception:
             pass
@@ -83,7 +98,8 @@ class HipOps:
         self._call("xl_set_gemm_pingpong", int(mode))
 
     def set_gemm_persistent(self, on):
-        """persistent ping-pong kernel for multi-round, short-K launches: 1 = when eligible (default), 0 = never."""
+        """persistent ping-pong kernel for multi-round, short-K launches: 1 = when eligible, 0 = never (default; env
+        XL_GEMM_PERSIST sets the initial value)."""
         self._call("xl_set_gemm_persistent", int(on))
 
     def set_gemm_duo(self, mode):
@@ -329,6 +345,21 @@ class HipOps:
         (default: the current stream)."""
         st = after_stream.cuda_stream if after_stream is not None else self._stream()
         self._call("xl_comm_allreduce", int(comm), self._p(buf), int(n), xl_dtype(buf.dtype), st)
+
+    def comm_reduce_scatter(self, comm, buf, n, rank, world, after_stream=None):
+        """in place over buf[:n] (n a multiple of `world`): rank r's piece buf[r*n/world : (r+1)*n/world] := sum over ranks of
+        that piece; the other pieces of buf are left with partial sums (RCCL's in-place reduce-scatter layout)."""
+        per = int(n) // int(world)
+        st = after_stream.cuda_stream if after_stream is not None else self._stream()
+        self._call("xl_comm_reduce_scatter", int(comm), self._p(buf), self._p(buf) + rank * per * buf.element_size(), per,
+                   xl_dtype(buf.dtype), st)
+
+    def comm_allgather(self, comm, buf, n, rank, world, after_stream=None):
+        """in place over buf[:n]: every rank ends up with every rank's piece buf[r*n/world : (r+1)*n/world]."""
+        per = int(n) // int(world)
+        st = after_stream.cuda_stream if after_stream is not None else self._stream()
+        self._call("xl_comm_allgather", int(comm), self._p(buf) + rank * per * buf.element_size(), self._p(buf), per,
+                   xl_dtype(buf.dtype), st)
 
     def comm_wait(self, comm, stream=None):
         st = stream.cuda_stream if stream is not None else self._stream()

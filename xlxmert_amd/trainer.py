@@ -53,7 +53,7 @@ class PretrainStep:
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
                  bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None,
-                 plan=None, drop_grads=None, overlap_optimizer=None):
+                 plan=None, drop_grads=None, overlap_optimizer=None, collective=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -88,7 +88,17 @@ class PretrainStep:
         forward ~0.2 ms after the gradient norm instead of after the whole pass (-0.15...-0.4 ms per step measured; a CU-masked
         stream for the pass, hipExtStreamCreateWithCUMask, was measured too: +14 ms per step, whatever the number of hardware
         queues).  Same arithmetic per element.  Parameters / optimizer state read from another stream need `sync()` first.  Default off
-        (env XL_OPT_OVERLAP=1|0 overrides); HIP path only."""
+        (env XL_OPT_OVERLAP=1|0 overrides); HIP path only.
+        collective: how the gradients meet.  "allreduce" (default): every finished slice of the flat gradient buffer is all-reduced
+        and every rank runs the whole clip + AdamW pass (what DDP + a replicated optimizer do, ref lxmert_pretrain.py:102-106,
+        343-359).  "rs+ag" (SURVEY 5.8): every finished slice is REDUCE-SCATTERED in place (rank r keeps the sum of the r-th
+        1/N of the slice), the squared norm is the all-reduced scalar of the shard-local sums, AdamW runs over this rank's
+        shards only (1/N of the pass), and the updated fp32 master weights are ALL-GATHERED slice by slice, first-needed
+        first, on the collectives' stream -- followed there by the cast into the compute-dtype copy -- while the next forward starts
+        (it waits slice by slice: engine.params_ready).  Same bytes on the wire as the all-reduce.  Same parameters as "allreduce"
+        up to the summation order of the norm; a rank's Adam moments are current on its shards only (gather_state() makes them
+        whole: checkpoints, verify_replicas).
+        Env XL_COLLECTIVE=allreduce|rs+ag overrides."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -112,6 +122,10 @@ class PretrainStep:
         self.total_steps, self.warmup_steps = total_steps, int(total_steps * warmup_ratio)
         self.feat_loss = ("feat" in visual_losses.split(",")) if feat_loss is None else bool(feat_loss)
         self.t = 0
+        # forward passes run so far (every step() call, also the micro-batches of a gradient-accumulation window): the dropout
+        # step seed derives from it, so that each forward draws fresh masks as the reference does (tasks/vqa.py update_freq loop);
+        # equal to `t` while update_freq = 1.  Checkpoint it next to `t` (state() / load_state()).
+        self.micro = 0
         # task round-robin on one parameter set (ref lxmert_pretrain.py:296-298): per-tensor update counts, as transformers'
         # AdamW keeps them (a tensor skipped in a step does not advance its bias correction)
         self.chunk_steps = (torch.zeros(self.store.n_total // 256, dtype=torch.int32, device=self.device)
@@ -148,7 +162,13 @@ class PretrainStep:
                 import warnings
                 warnings.warn(f"xl_comm_* unavailable ({e}); the gradient exchange goes through torch.distributed")
                 self.xl_comm = None
+        want_c = os.environ.get("XL_COLLECTIVE") or collective or "allreduce"
+        assert want_c in ("allreduce", "rs+ag"), want_c
+        self.sharded = self.exchange and want_c == "rs+ag"
+        self.collective = "rs+ag" if self.sharded else "allreduce"
+        self._segments, self._seg_key, self._seg_events, self._group_seg = [], None, [], {}
         self.exposed_comm_ms = []              # per step: time the main stream waited for collectives after backward
+        self._comm_t = None                    # (xl_comm path: one re-recorded event pair = the last step's wait)
         env = os.environ.get("XL_PLAN")
         self.plan_mode = bool(int(env)) if env else bool(plan)
         self.plan_mode = self.plan_mode and isinstance(self.ops, HipOps) and task == "vis_mask"
@@ -157,6 +177,12 @@ class PretrainStep:
         env = os.environ.get("XL_OPT_OVERLAP")
         overlap = bool(int(env)) if env else bool(overlap_optimizer)
         self.opt_stream, self._opt_groups = None, None
+        if self.sharded:
+            # the sharded pass has its own order (slices, first-needed first) and its own hand-over to the next forward (the
+            # all-gathers' events): the side-stream pass of the replicated optimizer does not apply
+            overlap = False
+            if self.xl_comm is not None and self.engine._dw is not None:
+                self.engine.params_ready = self._wait_gathered
         if overlap:
             # the pass is issued group by group in forward order; on the HIP path it also moves to the side stream, with an
             # event per group (injected host ops -- the CPU test-suite -- run the same grouped pass in place)
@@ -227,6 +253,13 @@ class PretrainStep:
         if ev is not None:
             self.ops.stream_wait(ev, torch.cuda.current_stream())
 
+    def close(self):
+        """give back the library-side communicator (xl_comm_destroy waits for its stream first); the trainer is done"""
+        if self.xl_comm is not None:
+            self.sync()
+            self.ops.lib.raw("xl_comm_destroy")(int(self.xl_comm))
+            self.xl_comm = None
+
     def sync(self):
         """everything this trainer has queued (the optimizer stream included) is done."""
         if self.device.type == "cuda":
@@ -246,12 +279,14 @@ class PretrainStep:
         if st.centroids is not None and st.centroids_c is not st.centroids:
             st.centroids_c.copy_(st.centroids)
         self.t = int(self.step_dev.item())
+        self.micro = max(self.micro, self.t)
         self.engine.sync_compute_weights()
 
     def verify_replicas(self):
         """names of the tensors (parameters, Adam moments) whose per-tensor checksum differs between ranks -- [] when the
         replicas agree.  One float64 sum per tensor and buffer, MIN / MAX all-reduced: cheap enough for every N-th step."""
         self.sync()                              # (an optimizer pass running behind the step: finish it first)
+        self.gather_state()                      # (sharded exchange: every rank's fp32 state is current on its shards only)
         st = self.store
         names = [n for n in st.index if st.index[n].offset < st.n_used]
         sums = []
@@ -283,6 +318,12 @@ class PretrainStep:
         names = sorted(results.keys())
         vals = torch.stack([torch.as_tensor(results[k]).detach().float().reshape(()).to(self.device) for k in names])
         if self.world > 1:
+            if self.xl_comm is not None:
+                # torch's communicator and the library's are two RCCL communicators: a collective of one must not run while
+                # collectives of the other are in flight (concurrent communicators without an order between them can deadlock).
+                # Every xl_comm collective issued so far is finished before torch's reduce starts.
+                self.ops.comm_wait(self.xl_comm)
+                torch.cuda.current_stream().synchronize()
             dist.reduce(vals, dst=dst)
             if self.rank != dst:
                 return None
@@ -298,7 +339,7 @@ class PretrainStep:
         """replay: a recorded plan re-issues the collectives of the step it was recorded from (same slices, same order)"""
         self._works = []
         if not replay:
-            self._lanes, self._slices = {}, []
+            self._lanes, self._slices, self._segments = {}, [], []
 
     def _host_op(self, fn):
         """run `fn` now and, while a launch plan is being recorded, make it a host operation of the plan (replayed between
@@ -309,23 +350,75 @@ class PretrainStep:
             lib.record_host(fn)
 
     def _send(self, lo, hi):
+        """the finished slice [lo, hi) of the gradient buffer goes out.  Sharded exchange: its largest prefix that splits into
+        `world` equal pieces of whole 256-element optimizer chunks is reduce-scattered, the remainder (< 256 * world elements)
+        all-reduced -- a replicated tail every rank updates itself."""
+        if self.sharded:
+            gran = 256 * self.world
+            n = (hi - lo) // gran * gran
+            if n:
+                self._issue("rs", lo, lo + n)
+                self._segments.append(("rs", lo, lo + n))
+            if lo + n < hi:
+                self._issue("ar", lo + n, hi)
+                self._segments.append(("ar", lo + n, hi))
+        else:
+            self._issue("ar", lo, hi)
+        self._slices.append((lo, hi))
+
+    class _ScatterWork:
+        """reduce-scatter through a backend that wants separate buffers: wait, then put the piece where the in-place form leaves it"""
+
+        def __init__(self, work, mine, tmp):
+            self.work, self.mine, self.tmp = work, mine, tmp
+
+        def wait(self):
+            self.work.wait()
+            self.mine.copy_(self.tmp)
+
+    def _issue(self, kind, lo, hi):
         buf = self.store.grad
         if self.comm_buf is not None:           # bf16 bucket, filled on the stream that just finished the slice
             self._comm_ops.cast_from_f32(self.store.grad[lo:hi], self.comm_buf[lo:hi], hi - lo)
             buf = self.comm_buf
         piece = buf[lo:hi]
         if self.xl_comm is not None:            # a C-ABI call like any other: recorded into the plan as such
-            self._comm_ops.comm_allreduce(self.xl_comm, piece, hi - lo)
+            if kind == "ar":
+                self._comm_ops.comm_allreduce(self.xl_comm, piece, hi - lo)
+            else:
+                self._comm_ops.comm_reduce_scatter(self.xl_comm, piece, hi - lo, self.rank, self.world)
             self._works.append(None)
-            self._slices.append((lo, hi))
             return
         stream = torch.cuda.current_stream() if self.device.type == "cuda" else None      # the stream that finished the slice
+        per = (hi - lo) // self.world
+        mine = piece[self.rank * per:(self.rank + 1) * per]
+        in_place = dist.get_backend() == "nccl"          # (RCCL's in-place layout: recv = send + rank * count)
 
         def issue():
             with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-                self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+                if kind == "ar":
+                    self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+                elif in_place:
+                    self._works.append(dist.reduce_scatter_tensor(mine, piece, op=dist.ReduceOp.SUM, async_op=True))
+                else:
+                    tmp = torch.empty_like(mine)
+                    self._works.append(PretrainStep._ScatterWork(
+                        dist.reduce_scatter_tensor(tmp, piece, op=dist.ReduceOp.SUM, async_op=True), mine, tmp))
         self._host_op(issue)
-        self._slices.append((lo, hi))
+
+    def owned_ranges(self):
+        """[(lo, hi)] of the flat buffers this rank's optimizer pass covers, in issue order of their slices: its piece of every
+        reduce-scattered slice and all of every replicated tail (everything, in "allreduce" mode)."""
+        if not self.sharded:
+            return [(0, self.store.n_used)]
+        out = []
+        for kind, lo, hi in self._segments:
+            if kind == "rs":
+                per = (hi - lo) // self.world
+                out.append((lo + self.rank * per, lo + (self.rank + 1) * per))
+            else:
+                out.append((lo, hi))
+        return out
 
     def _on_grad_ready(self, lo, hi, flush=False, lane="v"):
         ln = self._lanes.get(lane)
@@ -348,10 +441,19 @@ class PretrainStep:
             pos = hi
         assert pos == self.store.n_used, (pos, self.store.n_used)
         if self.xl_comm is not None:
-            self.ops.comm_wait(self.xl_comm)        # the compute stream continues after every collective of this step
-            if self.comm_buf is not None:
-                n = self.store.n_used
-                self._comm_ops.cast_to_f32(self.comm_buf[:n], self.store.grad[:n], n)
+            # the compute stream continues after every collective of this step; the wait is bracketed by two timing events recorded
+            # THROUGH the C ABI (plan-able: a replayed step re-records them), so exposed_comm() has a figure on this path too
+            if self._comm_t is None and self.device.type == "cuda":
+                self._comm_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                for e in self._comm_t:
+                    e.record()                      # (creates the HIP event behind .cuda_event)
+            cur = torch.cuda.current_stream()
+            if self._comm_t is not None:
+                self.ops.event_record(self._comm_t[0].cuda_event, cur)
+            self.ops.comm_wait(self.xl_comm)
+            if self._comm_t is not None:
+                self.ops.event_record(self._comm_t[1].cuda_event, cur)
+            self._buckets_to_grad()
             return
         timed = self.device.type == "cuda"
 
@@ -366,13 +468,19 @@ class PretrainStep:
                 self.exposed_comm_ms.append((t0, t1))
                 del self.exposed_comm_ms[:-64]
         self._host_op(wait_all)
-        if self.comm_buf is not None:           # summed bf16 buckets back into the fp32 gradient buffer (norm + AdamW read it)
-            n = self.store.n_used
-            self._comm_ops.cast_to_f32(self.comm_buf[:n], self.store.grad[:n], n)
+        self._buckets_to_grad()
+
+    def _buckets_to_grad(self):
+        """summed bf16 buckets back into the fp32 gradient buffer (norm + AdamW read it): the ranges this rank's pass covers"""
+        if self.comm_buf is not None:
+            for a, b in self.owned_ranges():
+                self._comm_ops.cast_to_f32(self.comm_buf[a:b], self.store.grad[a:b], b - a)
 
     def exposed_comm(self):
         """mean time (ms) the compute stream spent waiting for gradient collectives at the end of backward (last <= 64 steps;
         call after a synchronize)."""
+        if self._comm_t is not None:            # xl_comm_* issuer: the pair brackets the LAST step's wait
+            return self._comm_t[0].elapsed_time(self._comm_t[1])
         ts = [a.elapsed_time(b) for a, b in self.exposed_comm_ms]
         return sum(ts) / len(ts) if ts else 0.0
 
@@ -404,10 +512,9 @@ class PretrainStep:
             # language pretraining branches (ref lxmert_pretrain.py:159-160,180-182,192-195): un-masked codebook features;
             # batch: input_ids (masked_word_id / other_word_id), visual_pos, cluster_ids, word_labels (+ optional word_rows:
             # word_rows_of(word_labels), the masked-row decoder) | matched_labels
-            eng.set_step_seed(self.t * self.world + self.rank)
+            eng.set_step_seed(self._next_seed())
             eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                            lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
-            self._mark_consumed(batch)
             eng.grad_ready = None
             if exchange:
                 self._begin_exchange()
@@ -418,6 +525,7 @@ class PretrainStep:
                 loss = eng.matched_forward_backward(batch["matched_labels"], qa_labels=qa_labels)
             else:
                 loss = eng.qa_forward_backward(qa_labels)
+            self._mark_consumed(batch)          # the label tensors are copied inside *_forward_backward: only now is the slot free
             if exchange:
                 self._finish_exchange()
             if update:
@@ -430,15 +538,15 @@ class PretrainStep:
             feats, pos = batch["visual_feats"], batch["visual_pos"]
             if run == "nlvr2":
                 feats, pos = feats.reshape(-1, *feats.shape[2:]), pos.reshape(-1, *pos.shape[2:])
-            eng.set_step_seed(self.t * self.world + self.rank)
+            eng.set_step_seed(self._next_seed())
             eng.set_inputs(ids, am, batch.get("token_type_ids"), pos, visual_feats=feats,
                            lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
-            self._mark_consumed(batch)
             eng.grad_ready = None
             if exchange:
                 self._begin_exchange()
                 eng.grad_ready = self._on_grad_ready
             loss = eng.vqa_forward_backward(batch["targets"]) if run == "vqa" else eng.nlvr2_forward_backward(batch["labels"])
+            self._mark_consumed(batch)          # (targets / labels are copied inside *_forward_backward)
             if exchange:
                 self._finish_exchange()
             if update:
@@ -448,19 +556,38 @@ class PretrainStep:
         if labels is None:
             labels = batch["cluster_ids"].clone()
             labels[~batch["vis_mask"].bool()] = -100           # ref lxmert_pretrain.py:163-166
-        eng.set_step_seed(self.t * self.world + self.rank)
+        eng.set_step_seed(self._next_seed())
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                        vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"),
                        feat_labels=batch.get("feat_labels") if self.feat_loss else None,
                        lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
-        self._mark_consumed(batch)
+        if qa_labels is None:                   # every tensor of the batch went through set_inputs: the staging slot is free
+            self._mark_consumed(batch)
         if self.plan_mode and qa_labels is None and not accumulating:
             return self._planned_step()
-        return self._eager_vis_mask(exchange, update, qa_labels)
+        losses = self._eager_vis_mask(exchange, update, qa_labels)
+        if qa_labels is not None:               # (qa_labels are copied after the encoder forward: Engine._qa_forward)
+            self._mark_consumed(batch)
+        return losses
+
+    def _next_seed(self):
+        """step part of the dropout seeds of the forward about to run: one value per (forward pass, rank)"""
+        s = self.micro * self.world + self.rank
+        self.micro += 1
+        return s
+
+    def state(self):
+        """host-side counters a resumed run needs next to the ParamStore buffers (parameters, Adam moments, step_dev)"""
+        return {"t": self.t, "micro": self.micro}
+
+    def load_state(self, st):
+        self.t, self.micro = int(st["t"]), int(st.get("micro", st["t"]))
 
     @staticmethod
     def _mark_consumed(batch):
-        """the engine's static buffers hold the batch (set_inputs is queued): a BatchUploader may refill the staging slot."""
+        """every tensor of the batch has been copied into the engine's static buffers (the copies are queued on the current
+        stream): a BatchUploader may refill the staging slot.  Called only AFTER the last such copy is queued -- the label
+        tensors of the language / VQA / QA branches are copied inside the *_forward_backward calls."""
         if batch.get("_consumed") is not None:
             batch["_consumed"].record()
 
@@ -491,7 +618,7 @@ class PretrainStep:
             if self.exchange:
                 self._begin_exchange(replay=True)       # (the recorded host operations append to this replay's work list)
             plan.run()
-            HipOps._bound = None                # (the replay ends in whichever context its last recorded bind named)
+            HipOps.forget_binding()             # (the replay ends in whichever context its last recorded bind named)
             self.t += 1
             return eng.losses
         if not self._plan_warm:
@@ -507,7 +634,111 @@ class PretrainStep:
         self.t += 1                      # host mirror of step_dev (seeds, logging): never read by a kernel
         self._optimizer_launches()
 
+    # ---- sharded optimizer (collective="rs+ag"): shard-local norm + one scalar all-reduce, AdamW over this rank's shards,
+    # all-gather of the updated compute weights slice by slice in the order the next forward needs them
+    def _allreduce_scalar(self, t):
+        if self.xl_comm is not None:
+            self._comm_ops.comm_allreduce(self.xl_comm, t, t.numel())
+            self.ops.comm_wait(self.xl_comm)
+        else:
+            self._host_op(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+
+    def _map_groups_to_segments(self):
+        """for every parameter group of the forward (ParamStore.forward_groups): the all-gather it has to wait for = the one
+        issued LAST among the slices that hold any of its parameters (the collectives' stream runs them in issue order).
+        Slices are issued last-finished first, so that is the intersecting slice with the lowest index."""
+        key = tuple(self._segments)
+        if key == self._seg_key:
+            return
+        self._seg_key = key
+        while len(self._seg_events) < len(self._segments):
+            self._seg_events.append(self.ops.new_event())
+        self._group_seg = {}
+        for gkey, lo, hi in self.store.forward_groups():
+            for i, (kind, a, b) in enumerate(self._segments):
+                if kind == "rs" and a < hi and lo < b:
+                    self._group_seg[gkey] = min(i, self._group_seg.get(gkey, i))
+
+    def _wait_gathered(self, key):
+        """engine hook (sharded exchange through xl_comm_*): the current stream is about to read the parameters of group `key`"""
+        i = self._group_seg.get(key)
+        if i is not None:
+            self.ops.stream_wait(self._seg_events[i], torch.cuda.current_stream())
+
+    def _sharded_optimizer(self):
+        st, ops = self.store, self.ops
+        b1, b2 = self.betas
+        W, r = self.world, self.rank
+        ops.schedule_step(self.step_dev, self.lr, self.warmup_steps, self.total_steps, b1, b2, self.lrs)
+        owned = self.owned_ranges()
+        if self.clip > 0:
+            ops.zero(self.sumsq)
+            for (kind, _, _), (a, b) in zip(self._segments, owned):
+                if kind == "rs":
+                    ops.sumsq(st.grad[a:b], self.sumsq, b - a, self.sumsq_scratch)
+            self._allreduce_scalar(self.sumsq)                  # the shards tile the scattered slices: sum over ranks = their norm^2
+            for (kind, _, _), (a, b) in zip(self._segments, owned):
+                if kind == "ar":                                # replicated tails: the same addends on every rank, after the all-reduce
+                    ops.sumsq(st.grad[a:b], self.sumsq, b - a, self.sumsq_scratch)
+        flags = st.decay_flags
+        cs = self.chunk_steps
+        if cs is not None:
+            flags = st.task_flags(self._step_task)
+            cs.add_(((flags & 2) == 0).to(torch.int32))
+        fp32 = st.compute_dtype == torch.float32
+        hooked = self.engine.params_ready is not None and self.xl_comm is not None
+        if hooked:
+            self._map_groups_to_segments()
+        # What travels back is the fp32 MASTER slice (biases and LayerNorm affines are read from it in fp32, the matrices through
+        # the compute-dtype copy, which every rank re-derives from the gathered slice with one cast on the collectives' stream):
+        # the same bytes on the wire as the all-reduce's second half, and every rank's master weights stay whole.
+        for i in reversed(range(len(self._segments))):          # last-finished slice first: feature encoder, embeddings, layer 0 ...
+            kind, lo, hi = self._segments[i]
+            a, b = owned[i]
+            c0, c1 = a // 256, b // 256
+            ops.adamw(st.master[a:b], st.grad[a:b], st.exp_avg[a:b], st.exp_avg_sq[a:b],
+                      st.compute[a:b] if (kind == "ar" and not fp32) else None,
+                      flags[c0:c1], self.sumsq if self.clip > 0 else None, self.lrs, b - a, b1, b2, self.eps, self.wd, self.clip,
+                      grad_scale=1.0 / W, chunk_steps=cs[c0:c1] if cs is not None else None, zero_grad=False)
+            if kind != "rs":
+                continue
+            piece = st.master[lo:hi]
+            if self.xl_comm is not None:
+                self.ops.comm_allgather(self.xl_comm, piece, hi - lo, r, W)
+                with torch.cuda.stream(self._comm_stream):
+                    if not fp32:
+                        ops.cast_from_f32(piece, st.compute[lo:hi], hi - lo)
+                    if hooked:
+                        ops.event_record(self._seg_events[i], self._comm_stream)
+            else:
+                per = (hi - lo) // W
+                self._host_op(lambda piece=piece, per=per: dist.all_gather_into_tensor(piece, piece[r * per:(r + 1) * per].clone()))
+                if not fp32:
+                    ops.cast_from_f32(piece, st.compute[lo:hi], hi - lo)
+        if self.xl_comm is not None and not hooked:
+            ops.comm_wait(self.xl_comm)
+        # the non-owned parts of the gradient buffer hold partial sums: the next backward clears the whole buffer itself
+        self.engine.grad_is_zero = False
+
+    def gather_state(self):
+        """sharded exchange: make the Adam moments whole on every rank (each rank's are current on its shards only) -- before a
+        checkpoint is written or replicas are compared.  Two all-gathers per slice; off the step."""
+        if not self.sharded or not self._segments:
+            return
+        self.sync()
+        st, W, r = self.store, self.world, self.rank
+        for kind, lo, hi in self._segments:
+            if kind != "rs":
+                continue
+            per = (hi - lo) // W
+            for buf in (st.exp_avg, st.exp_avg_sq):              # (the master weights are gathered by every step)
+                piece = buf[lo:hi]
+                dist.all_gather_into_tensor(piece, piece[r * per:(r + 1) * per].clone())
+        self.sync()
+
     def _optimizer_launches(self):
+        if self.sharded and self._segments:
+            return self._sharded_optimizer()
         st, ops = self.store, self.ops
         b1, b2 = self.betas
         ops.schedule_step(self.step_dev, self.lr, self.warmup_steps, self.total_steps, b1, b2, self.lrs)
