@@ -684,6 +684,7 @@ def test_batch_uploader_slot_is_released_after_the_labels_are_copied():
     oc = oracle_cfg(cfg)
     B, L, grid = 4, 8, 4
     tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.float32, device="cuda", task="word_mask", seed=5, lr=0.0, total_steps=100)
+    tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=torch.Generator().manual_seed(2)).relu())
     host = []
     for i in range(4):
         b = synthetic_batch(cfg, B, L, grid, seed=40 + i)

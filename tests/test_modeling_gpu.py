@@ -84,13 +84,17 @@ def test_lxmert_model_and_head_through_autograd():
         assert maxdiff(params[k].grad.cpu(), g["grad:" + k]) < 1e-4, k
 
 
-def test_vqa_model_dropin_matches_reference_fixture():
+@pytest.mark.parametrize("cls_name", ["VQAModel", "GQAModel"])
+def test_vqa_model_dropin_matches_reference_fixture(cls_name):
     """the nn.Module surface of tasks/vqa_model.py -- reference-layout state dict in, {'logit'} out, and the
-    reference's own training idiom (BCEWithLogitsLoss on the logit, .backward(), param.grad) gives the fixture's gradients."""
+    reference's own training idiom (BCEWithLogitsLoss on the logit, .backward(), param.grad) gives the fixture's gradients.
+    GQAModel (ref tasks/gqa_model.py:7-72) is the same module under the name the GQA driver imports."""
     import lxmert_oracle as O
+    import xlxmert_amd.modeling as M
     from _util import golden_cfg, golden_inputs, load_golden, maxdiff
     from xlxmert_amd.config import XLxmertConfig
-    from xlxmert_amd.modeling import VQAModel
+    VQAModel = getattr(M, cls_name)
+    assert issubclass(M.GQAModel, M.VQAModel)
     g = load_golden("vqa_tiny")
     oc = golden_cfg(g)
     A = int(g["num_answers"])
@@ -409,3 +413,86 @@ def test_output_attentions_through_the_module_api(dtype, tol):
             assert a.shape == ref.shape and a.dtype == torch.float32
             msk = torch.ones_like(ref, dtype=torch.bool) if name == "vis_att" else real[:, None, :, None].expand_as(ref)
             assert maxdiff(a[msk].cpu(), ref[msk].cpu()) < tol, (name, i)
+
+
+# ---------------------------------------------------------------- SURVEY 8f N2 through the reference's class
+def _imggen_model(g):
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.modeling import ImggenModel
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in CFG_KEYS})
+    grid = int(g["grid"])
+    m = ImggenModel(cfg, args=None, num_clusters=oc.num_clusters, dtype=torch.float32, grid_size=grid)
+    assert not hasattr(m, "cls") and not hasattr(m, "answer_head") and m.G is None and m.vis_emb is None
+    with pytest.raises(RuntimeError):
+        m.sample_image_NAR(torch.from_numpy(g["in_input_ids"]).cuda())         # no codebook yet
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    m.load_state_dict({k: v for k, v in sd.items() if k not in ("vis_emb.weight", "obj_predict_head.out_cluster.weight")})
+    m.set_visual_embedding(sd["vis_emb.weight"].numpy())                        # ref :28-39 (np.ndarray accepted)
+    assert m.obj_predict_head.out_cluster.weight is m.vis_emb.weight
+    with pytest.raises(RuntimeError):
+        m.sample_image_NAR(torch.from_numpy(g["in_input_ids"]).cuda(), n_steps=1)          # no generator yet
+    m.set_image_generator(lambda x: x)                                          # identity "GAN": the image IS the code grid
+    return m, grid
+
+
+def _as_image(code, grid):
+    """what ImggenModel returns for an identity generator: denorm(code as [B, F, g, g]) on the host"""
+    c = torch.as_tensor(code)
+    B = c.shape[0]
+    return ((c.permute(0, 2, 1).reshape(B, -1, grid, grid) + 1) / 2).clamp(0, 1)
+
+
+def test_imggen_model_nar_matches_reference_fixture():
+    """ImggenModel.sample_image_NAR (ref tasks/imggen_model.py:169-257) through the class: final image, every intermediate image
+    (return_intermediate: the running codes after each Mask-Predict step, from the fixture's per-step predictions and masks), a
+    tokenizer callable with LxmertTokenizer's call signature, and n_steps=None -> grid ** 2 steps."""
+    g = load_golden("sampler_tiny")
+    m, grid = _imggen_model(g)
+    ids = torch.from_numpy(g["in_input_ids"]).cuda()
+    T = int(g["n_steps"])
+    img = m.sample_image_NAR(ids, n_steps=T)
+    assert img.device.type == "cpu" and maxdiff(img, _as_image(g["code"], grid)) == 0.0
+    steps = m.sample_image_NAR(ids, n_steps=T, return_intermediate=True)
+    assert isinstance(steps, list) and len(steps) == T and maxdiff(steps[-1], img) == 0.0
+    cent = m.vis_emb.weight.cpu()
+    cur = torch.zeros_like(torch.from_numpy(g["step_pred_ids"][0]))
+    for i in range(T):
+        mask = torch.from_numpy(g["step_masks"][i]).bool()
+        cur = torch.where(mask, torch.from_numpy(g["step_pred_ids"][i]), cur)
+        assert maxdiff(steps[i], _as_image(cent[cur], grid)) == 0.0, i
+
+    class Tok:                                  # LxmertTokenizer's call signature (ref :56-58): sentences -> .input_ids
+        def __call__(self, sentences, max_length=None, truncation=None, return_tensors=None):
+            assert max_length == 20 and truncation is True and return_tensors == "pt" and len(sentences) == ids.shape[0]
+            return type("Enc", (), {"input_ids": ids.cpu()})()
+    with pytest.raises(RuntimeError):
+        m.sample_image_NAR(["a", "b", "c"], n_steps=T)                          # strings need a tokenizer
+    m.tokenizer = Tok()
+    assert maxdiff(m.sample_image_NAR(["a", "b", "c"], n_steps=T), img) == 0.0
+    full = m.sample_image_NAR(ids)                                              # n_steps=None: grid ** 2 refinement steps (ref :191-192)
+    assert full.shape == img.shape and int(m.bert._engine.vmask.sum().item()) == ids.shape[0] * int(1 / grid ** 2 * grid ** 2)
+
+
+@pytest.mark.parametrize("mode", ["confidence", "tlbr", "random"])
+def test_imggen_model_ar_matches_reference_fixture(mode):
+    """ImggenModel.sample_image_AR (ref :49-167): position_confidence (default) / position_TLBR / position_random(seed=7: the
+    reference's random.Random(seed).shuffle order) give the fixture's codes; the intermediate images follow the fixture's masks."""
+    g = load_golden("sampler_ar_tiny")
+    m, grid = _imggen_model(g)
+    ids = torch.from_numpy(g["in_input_ids"]).cuda()
+    kw = {"confidence": {}, "tlbr": dict(position_TLBR=True), "random": dict(position_random=True, seed=7)}[mode]
+    img = m.sample_image_AR(ids, **kw)
+    assert maxdiff(img, _as_image(g["code_" + mode], grid)) == 0.0
+    assert maxdiff(m.vis_emb.weight[m.code_ids].cpu(), g["code_" + mode]) == 0.0       # the chosen ids ARE those codes
+    steps = m.sample_image_AR(ids, return_intermediate=True, **kw)
+    V = grid * grid
+    assert len(steps) == V and maxdiff(steps[-1], img) == 0.0
+    # after step i the positions still masked hold mask_feat, the others their final code (a position is filled once)
+    mf, final = m.mask_feat.detach().cpu(), torch.from_numpy(g["code_" + mode])
+    for i in (0, V // 2, V - 2):
+        mask = torch.from_numpy(g["step_masks_" + mode][i]).bool()
+        code = torch.where(mask[..., None], mf.view(1, 1, -1), final)
+        assert maxdiff(steps[i], _as_image(code, grid)) == 0.0, i
+    with pytest.raises(ValueError):
+        m.sample_image_AR(ids, position_confidence=False)

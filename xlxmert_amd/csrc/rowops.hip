@@ -1357,6 +1357,9 @@ extern "C" int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t*
 extern "C" int xl_codebook_gather(const int64_t* cluster_ids, const uint8_t* vis_mask, const void* centroids,
                                   const float* mask_feat, void* feats, int M, int F, int dtype, void* stream) {
     CHECK_ROW(F, dtype);
+    XL_CHECK_ARG(cluster_ids != nullptr && centroids != nullptr && feats != nullptr && M > 0 && (vis_mask == nullptr || mask_feat != nullptr),
+                 XL_ERR_BAD_ARG, "xl_codebook_gather: null cluster_ids / centroids / feats (no codebook set: set_visual_embedding / "
+                 "set_centroids first), or a vis_mask without mask_feat");
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((codebook_gather_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,

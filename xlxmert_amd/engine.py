@@ -1051,6 +1051,9 @@ class Engine:
             self._vkmask_buf.copy_(visual_attention_mask.reshape(B, V) != 0, non_blocking=True)
             self.vkmask = self._vkmask_buf
         self.use_codebook = cluster_ids is not None
+        if cluster_ids is not None and self.store.centroids_c is None:
+            raise RuntimeError("cluster_ids given but the store has no codebook: set_centroids / set_visual_embedding first "
+                               "(ref lxrt/modeling.py:140-151, 185-186)")
         if cluster_ids is not None:
             self.cid.copy_(cluster_ids, non_blocking=True)
             self.has_vmask = vis_mask is not None
@@ -1496,12 +1499,14 @@ class Engine:
             self.head_forward()
             self.predict_codes()
 
-    def sample_codes_nar(self, n_steps=4):
+    def sample_codes_nar(self, n_steps=4, on_step=None):
         """Iterative Mask-Predict sampling (ref tasks/imggen_model.py:169-243) without a host round trip between steps:
         re-mask the lowest-confidence positions -> encoder -> codebook head -> softmax-max / argmax -> keep the predictions
         of the masked positions.  Text inputs come from set_inputs (cluster_ids / vis_mask there are placeholders).
         Returns (code_ids [B,V] int64, code features [B*V, F] in the compute dtype, pred_prob [B*V] fp32); the caller
-        hands `code.view(B,V,F).permute(0,2,1).view(B,F,g,g)` to the frozen GAN generator (stock PyTorch, ref :254)."""
+        hands `code.view(B,V,F).permute(0,2,1).view(B,F,g,g)` to the frozen GAN generator (stock PyTorch, ref :254).
+        on_step(i): called after step i's update (return_intermediate of the reference, :245-248: materialise_codes() gives the
+        code tensor of that moment)."""
         ops, B, V = self.ops, self.B, self.V
         st = self.store
         self.use_codebook, self.has_vmask = True, True
@@ -1522,10 +1527,20 @@ class Engine:
                 self._reuse_lang_stack = False
             self._predict_step(fused)
             ops.sampler_update(self.row_argmax, self.vmask, self.cid, B * V)
+            if on_step is not None:
+                on_step(i)
         ops.codebook_gather(self.cid, None, st.centroids_c, st.view("mask_feat"), self.feats, self.MV, self.F)
         return self.cid, self.feats, self.row_maxprob
 
-    def sample_codes_ar(self, n_steps=None, mode="confidence", positions=None, trace=None):
+    def materialise_codes(self, masked=False):
+        """the sampler's code tensor [B*V, F] (compute dtype) of this moment: centroid rows of the current code ids; masked=True
+        (autoregressive loop): `mask_feat` rows where vis_mask is still set, as the reference's `code` holds them (ref :99-102)."""
+        st = self.store
+        self.ops.codebook_gather(self.cid, self.vmask if masked else None, st.centroids_c, st.view("mask_feat"), self.feats,
+                                 self.MV, self.F)
+        return self.feats
+
+    def sample_codes_ar(self, n_steps=None, mode="confidence", positions=None, trace=None, on_step=None):
         """Autoregressive sampling (ref tasks/imggen_model.py:49-153): one grid position per image is filled per step --
         the most confident not-yet-visited one ("confidence", the reference's default), position i ("tlbr"), or the host's
         shuffled order popped from the end ("random", positions = that list).  Same device-resident state as
@@ -1559,6 +1574,8 @@ class Engine:
             ops.sampler_ar_update(self.row_maxprob, self.row_argmax, self.visited, self.vmask, self.cid, B, V, cur)
             if trace is not None:
                 trace.append(self.vmask.clone())
+            if on_step is not None:
+                on_step(i)
         ops.codebook_gather(self.cid, self.vmask, st.centroids_c, st.view("mask_feat"), self.feats, self.MV, self.F)
         return self.cid, self.feats, self.row_maxprob
 

@@ -498,6 +498,11 @@ class VQAModel(nn.Module):
         return {"logit": logit}
 
 
+class GQAModel(VQAModel):
+    """ref tasks/gqa_model.py:7-72: the same module as VQAModel under the name the GQA driver imports (tasks/gqa.py:70,150:
+    `.bert` + `.answer_head`, BCEWithLogitsLoss on the soft targets, forward returns {'logit': [B, num_answers]})."""
+
+
 class NLVR2Model(VQAModel):
     """ref tasks/nlvr2_model.py:7-93: `.bert` + `.answer_head`; forward takes visual_feats [P, 2, V, F], visual_pos
     [P, 2, V, 4] and input_ids [2P, L] (every statement repeated for its two images), flattens the pairs, and feeds
@@ -515,3 +520,110 @@ class NLVR2Model(VQAModel):
         assert n_images == 2                                                             # ref :64
         return super().forward(input_ids, visual_feats.reshape(P * 2, V, Fd), visual_pos.reshape(P * 2, V, -1), attention_mask,
                                visual_attention_mask, token_type_ids, inputs_embeds, return_dict)
+
+
+# ---------------------------------------------------------------------------------------------- image generation
+class ImggenModel(XLxmertForPretraining):
+    """ref tasks/imggen_model.py:11-257: `.bert`, `.obj_predict_head`, `.mask_feat`, `.vis_emb`, `set_visual_embedding`,
+    `set_image_generator(G)`, `sample_image_NAR` (Mask-Predict, :169-257) and `sample_image_AR` (one grid position per step:
+    position_random / position_TLBR / position_confidence, :49-167).  The loops run on the device without a host round trip
+    (Engine.sample_codes_nar / sample_codes_ar); tokenisation in front and the frozen GAN generator `G` + denorm behind stay
+    stock PyTorch, as in the reference.
+
+    `sentences`: a list of strings (needs `tokenizer`: any callable with LxmertTokenizer's call signature -- the reference
+    downloads 'unc-nlp/lxmert-base-uncased' in its constructor, :26, which an offline machine cannot) or, beyond the reference, an
+    int64 tensor of input ids [B, L] (0 = [PAD]).  grid_size / the code width follow the config (the reference hardcodes 8 / 2048)."""
+
+    def __init__(self, config: XLxmertConfig, args=None, num_clusters=10000, device=None, dtype=torch.bfloat16, tokenizer=None,
+                 grid_size=8):
+        import copy
+        config = copy.copy(config)
+        config.task_mask_lm = config.task_matched = config.task_qa = False          # the published class has the codebook head only
+        config.task_obj_predict = True
+        super().__init__(config, num_clusters=num_clusters, device=device, dtype=dtype)
+        self.args, self.tokenizer, self.grid_size = args, tokenizer, grid_size
+        self.G = None
+
+    def set_image_generator(self, generator):
+        """ref :41-42: any callable [B, code_dim, g, g] fp32 -> image batch (image_generator.src.layers.Generator in the reference)"""
+        self.G = generator
+
+    @staticmethod
+    def denorm(x):
+        """(-1, 1) => (0, 1)   (ref :44-47)"""
+        return ((x + 1) / 2).clamp(0, 1)
+
+    def _input_ids(self, sentences, max_text_length):
+        if torch.is_tensor(sentences):
+            return sentences.to(self._store.device)
+        if self.tokenizer is None:
+            raise RuntimeError("ImggenModel got sentences but no tokenizer: pass tokenizer=LxmertTokenizer.from_pretrained(...) "
+                               "(the reference downloads one in its constructor) or hand over input ids")
+        ids = self.tokenizer(sentences, max_length=max_text_length, truncation=True, return_tensors="pt").input_ids      # ref :56-58
+        return ids.to(self._store.device)
+
+    def _prepare(self, input_ids):
+        import numpy as np
+        if self.vis_emb is None:
+            raise RuntimeError("call set_visual_embedding(centroids) first")
+        self.eval()                                                 # ref :54, :180
+        g = self.grid_size
+        B, L = input_ids.shape
+        V = g * g
+        eng = self._step_engine(B, L, V)
+        pos = np.zeros((V, 4), np.float32)                          # ref utils.box_position
+        for i in range(g):
+            for j in range(g):
+                pos[i * g + j] = [j / g, i / g, (j + 1) / g, (i + 1) / g]
+        dev = input_ids.device
+        eng.set_inputs(input_ids, input_ids > 0, None, torch.from_numpy(pos).to(dev).unsqueeze(0).expand(B, -1, -1),
+                       cluster_ids=torch.zeros(B, V, dtype=torch.long, device=dev), vis_mask=torch.ones(B, V, dtype=torch.bool, device=dev))
+        return eng, B, V
+
+    def _image(self, code, B):
+        """code [B*V, F] -> G(code as [B, F, g, g]) -> denorm -> host (ref :160-165, :250-256)"""
+        if self.G is None:
+            raise RuntimeError("call set_image_generator(G) first (ref tasks/imggen_model.py:41)")
+        g = self.grid_size
+        x = code.view(B, g * g, -1).permute(0, 2, 1).reshape(B, -1, g, g).float()
+        return self.denorm(self.G(x)).cpu()
+
+    @torch.no_grad()
+    def sample_image_NAR(self, sentences, max_text_length=20, n_steps=None, return_intermediate=False):
+        """ref :169-257.  n_steps=None -> grid_size ** 2 (ref :191-192)."""
+        eng, B, V = self._prepare(self._input_ids(sentences, max_text_length))
+        n_steps = V if n_steps is None else n_steps
+        imgs = []
+        hook = (lambda i: imgs.append(self._image(eng.materialise_codes(), B))) if return_intermediate else None
+        _, code, _ = eng.sample_codes_nar(n_steps, on_step=hook)
+        self.code_ids = eng.cid.clone()                             # the chosen codebook ids [B, V] (beyond the reference: handy)
+        return imgs if return_intermediate else self._image(code, B)
+
+    @torch.no_grad()
+    def sample_image_AR(self, sentences, max_text_length=20, position_random=False, position_TLBR=False, position_confidence=True,
+                        n_steps=None, seed=None, return_intermediate=False):
+        """ref :49-167: the three position policies with the reference's precedence (random, else TLBR, else confidence) and its
+        host-side order for `position_random` (random.Random(seed).shuffle, extended for n_steps > grid ** 2, :77-89)."""
+        import random
+        eng, B, V = self._prepare(self._input_ids(sentences, max_text_length))
+        n_steps = V if n_steps is None else n_steps
+        positions = None
+        if position_random:
+            mode = "random"
+            positions = list(range(V))
+            (random.Random(seed) if seed is not None else random).shuffle(positions)
+            if n_steps > V:
+                extra = list(range(n_steps - V))
+                (random.Random(seed) if seed is not None else random).shuffle(extra)
+                positions = extra + positions
+        elif position_TLBR:
+            mode = "tlbr"
+        elif position_confidence:
+            mode = "confidence"
+        else:
+            raise ValueError("sample_image_AR: one of position_random / position_TLBR / position_confidence must be set")
+        imgs = []
+        hook = (lambda i: imgs.append(self._image(eng.materialise_codes(masked=True), B))) if return_intermediate else None
+        _, code, _ = eng.sample_codes_ar(n_steps, mode, positions=positions, on_step=hook)
+        self.code_ids = eng.cid.clone()
+        return imgs if return_intermediate else self._image(code, B)
