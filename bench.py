@@ -109,10 +109,10 @@ class GemmTimer:
                 (eb * M * N if aux is not None else 0)
             self.rec.append((s, e, 2.0 * M * N * K, (M, N, K, kw.get("a_kmajor", 1), kw.get("b_kmajor", 1), kw.get("epilogue", 0)),
                              nbytes, getattr(self.ops, "block", "")))
-        def timed_group(problems):
+        def timed_group(problems, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            self.orig_group(problems)
+            self.orig_group(problems, **kw)
             e.record()
             eb = problems[0][0].element_size()
             nbytes = sum(eb * pr[5] * (pr[3] + pr[4]) + 2 * 4 * pr[3] * pr[4] for pr in problems)      # operands + fp32 read-modify-write

@@ -136,7 +136,11 @@ int xl_gemm(const void* A, const void* B, void* C, const float* bias,
  * autograd for the Linear weights of one LXMERT block (HF:258-342).  Arrays are HOST arrays of length count. */
 int  xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const* C,
                          const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
-                         int count, int dtype, void* stream);
+                         int count, int overwrite_mask, int dtype, void* stream);
+/* overwrite_mask: bit i set -> C_i = A_i^T B_i instead of C_i += ... (a weight with exactly ONE gradient contribution per
+ * step: the training step then neither clears nor re-reads 4 bytes per parameter -- the clear moves out of xl_adamw, decay_flags
+ * bit 2, and the epilogue's read-modify-write becomes a plain store).  The semantics hold whatever strategy the launch takes: a
+ * problem whose tiles have one writer is stored plainly, one that is K-split (fp32 atomics) or has ragged tiles is cleared first. */
 
 /* Slab workspace of the ping-pong kernel: per-stream, caller-owned device memory (16-byte aligned) in which the K slices
  * of one output tile meet -- every slice's workgroup writes its partial tile, the last to arrive sums them and runs the
@@ -333,7 +337,8 @@ int xl_schedule_step(int64_t* step, float base_lr, int warmup_steps, int total_s
                      float* lr_and_steps, void* stream);
 /* transformers==4.1.1 AdamW on flat fp32 buffers with fused gradient clipping:
  * clip = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) (max_norm<=0 disables), g' = g*clip*grad_scale;
- * decay_flags: uint8 per 256-element chunk: bit 0 = apply weight decay, bit 1 = SKIP the chunk (a tensor that got no
+ * decay_flags: uint8 per 256-element chunk: bit 0 = apply weight decay, bit 2 = with zero_grad, do NOT clear this chunk's gradient
+ * (the next backward overwrites it: xl_gemm_wgrad_group overwrite_mask), bit 1 = SKIP the chunk (a tensor that got no
  * gradient this step: the reference resets .grad to None every step and AdamW skips such tensors -- the task round-robin
  * of lxmert_pretrain.py:296-298 changes the set every step).  lr_and_steps (device, fp32[4]):
  * {lr, bias_corr1 = 1-beta1^t, bias_corr2 = 1-beta2^t, unused}; chunk_steps (device int32 per chunk, may be NULL): the

@@ -115,9 +115,10 @@ class FakeOps:
     def flush_reductions(self):
         pass
 
-    def gemm_wgrad_group(self, problems):
-        for (A, B, C, M, N, K, lda, ldb, ldc) in problems:
-            self.gemm(A, B, C, None, None, None, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+    def gemm_wgrad_group(self, problems, overwrite_mask=0):
+        for i, (A, B, C, M, N, K, lda, ldb, ldc) in enumerate(problems):
+            self.gemm(A, B, C, None, None, None, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, out_f32=True,
+                      accumulate=0 if (overwrite_mask >> i) & 1 else 1)
 
     @staticmethod
     def _ln(x, g, b, eps):
@@ -449,7 +450,11 @@ class FakeOps:
         if p_compute is not None and p_compute.data_ptr() != p.data_ptr():
             p_compute[:n].copy_(p[:n])
         if zero_grad:
-            g[:n].copy_(torch.where(act, torch.zeros_like(g[:n]), g[:n]))
+            # bit 2: "the next backward overwrites this chunk": the kernel leaves such a gradient as it is; the host restatement
+            # POISONS it, so that any path that reads or accumulates into a kept chunk without overwriting it first shows up as NaN
+            keep = (fl & 4) != 0
+            cleared = torch.where(keep, torch.full_like(g[:n], float("nan")), torch.zeros_like(g[:n]))
+            g[:n].copy_(torch.where(act, cleared, g[:n]))
 
     def cast_from_f32(self, src, dst, n):
         if dst.data_ptr() != src.data_ptr():

@@ -434,6 +434,46 @@ def test_gemm_wgrad_group_two_layer_tile_walk_exact(K):
             assert torch.equal(pr[2].cpu(), ref * rep), f"rep {rep} dW {m}x{n}: max abs diff {(pr[2].cpu() - ref * rep).abs().max().item()}"
 
 
+@pytest.mark.parametrize("case", ["two_layers_one_writer", "one_layer_k_split", "ragged_and_padded", "fp32_ungrouped"])
+def test_gemm_wgrad_group_overwrite_mask(case, slab_ws):
+    """xl_gemm_wgrad_group overwrite_mask: C_i = A_i^T B_i for the masked problems whatever C held before (filled with NaN here) and
+    C_i += ... for the others, in every strategy the launch can take: 216 tiles with one writer each (plain vector stores), a K-split
+    launch (the library clears C, then fp32 atomics), ragged problems with padded leading dimensions, and the fp32 path (one xl_gemm
+    per problem).  Integer-valued operands: exact; a second launch with the same mask gives the same values again (not twice)."""
+    g = torch.Generator().manual_seed(len(case))
+    dtype = torch.float32 if case == "fp32_ungrouped" else torch.bfloat16
+    if case == "two_layers_one_writer":
+        shapes, K, pad = [(2304, 768), (768, 768), (3072, 768), (768, 3072)] * 2, 512, 0
+    elif case == "one_layer_k_split":
+        shapes, K, pad = [(2304, 768), (768, 768), (3072, 768), (768, 3072)], 2048, 0
+    elif case == "ragged_and_padded":
+        shapes, K, pad = [(768, 256), (200, 520), (256, 256)], 1536, 8
+    else:
+        shapes, K, pad = [(96, 64), (64, 200)], 300, 0
+    mask = sum(1 << i for i in range(len(shapes)) if i % 3 != 1)          # problems 1, 4, 7 keep accumulating
+    probs, refs, olds = [], [], []
+    for i, (m, n) in enumerate(shapes):
+        dY = torch.randint(-2, 3, (K, m + pad), generator=g).to(dtype)
+        X = torch.randint(-2, 3, (K, n + 2 * pad), generator=g).to(dtype)
+        old = torch.randint(-5, 6, (m, n + pad), generator=g).float()
+        C = old.clone()
+        if (mask >> i) & 1:
+            C[:, :n] = float("nan")
+        refs.append(dY[:, :m].float().t() @ X[:, :n].float())
+        olds.append(old)
+        probs.append((dY.cuda(), X.cuda(), C.cuda(), m, n, K, m + pad, n + 2 * pad, n + pad))
+    ops = hip(dtype)
+    for rep in (1, 2):
+        ops.gemm_wgrad_group(probs, overwrite_mask=mask)
+        torch.cuda.synchronize()
+        for i, ((m, n), pr, ref, old) in enumerate(zip(shapes, probs, refs, olds)):
+            want = ref if (mask >> i) & 1 else old[:, :n] + rep * ref
+            got = pr[2].cpu()
+            assert torch.equal(got[:, :n], want), f"{case} rep {rep} problem {i} ({m}x{n}): max abs diff {(got[:, :n] - want).abs().max().item()}"
+            if pad:
+                assert torch.equal(got[:, n:], old[:, n:]), "columns beyond N were touched"
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows", [(2048, 2048, 2048), (1536, 640, 1536)])
 def test_gemm_wgrad_group(rows, dtype, slab_ws):

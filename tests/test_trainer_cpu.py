@@ -469,21 +469,30 @@ def test_random_word_batch_statistics():
     assert 0.06 < kept.sum().item() / chosen.sum().item() < 0.14
 
 
-def test_optimizer_pass_clears_the_gradients_when_asked():
+@pytest.mark.parametrize("overwrite", [False, True])
+def test_optimizer_pass_clears_the_gradients_when_asked(overwrite):
     """drop_grads: xl_adamw clears the gradient buffer in its own pass and the next step's backward starts without a clear --
-    same losses and parameters as the step that clears before every backward; the gradients are gone after step()."""
+    same losses and parameters as the step that clears before every backward; the gradients are gone after step().
+    overwrite (PretrainStep overwrite_grads, the default): the weight gradients with one contribution per step are STORED by the
+    next backward, so the pass leaves them uncleared (flag bit 2) -- the host restatement of xl_adamw poisons exactly those chunks
+    with NaN, so a path that accumulated into one of them instead of overwriting it could not give the reference's numbers."""
     cfg = XLxmertConfig(**TINY)
     B, L, grid = 3, 8, 4
-    keep, _ = make_step(cfg, B, L, grid, lr=1e-2)
-    drop, _ = make_step(cfg, B, L, grid, lr=1e-2, drop_grads=True)
-    assert not keep.drop_grads and drop.drop_grads
+    keep, _ = make_step(cfg, B, L, grid, lr=1e-2, overwrite_grads=False)
+    drop, _ = make_step(cfg, B, L, grid, lr=1e-2, drop_grads=True, overwrite_grads=overwrite)
+    assert not keep.drop_grads and drop.drop_grads and drop.overwrite_grads == overwrite
     for t in range(3):
         batch = synthetic_batch(cfg, B, L, grid, seed=200 + t)
         lk, ld = keep.step(batch).clone(), drop.step(batch).clone()
         assert torch.equal(lk, ld)
         assert keep.grad_norm() == drop.grad_norm()
         assert keep.store.grad[:keep.store.n_used].abs().max().item() > 0
-        assert drop.store.grad[:drop.store.n_used].abs().max().item() == 0 and drop.engine.grad_is_zero
+        g = drop.store.grad[:drop.store.n_used]
+        kept = ((drop.store.decay_flags[:drop.store.n_used // 256] & 4) != 0).repeat_interleave(256)
+        assert bool(kept.any()) == overwrite
+        if overwrite:            # most of the buffer: every Linear weight of the encoder and the head
+            assert kept.float().mean().item() > 0.5 and torch.isnan(g[kept]).all()
+        assert g[~kept].abs().max().item() == 0 and drop.engine.grad_is_zero
         assert torch.equal(keep.store.master, drop.store.master)
     # a backward outside the trainer dirties the buffer again: the next step clears it
     drop.engine.set_inputs(batch["input_ids"], batch["attention_mask"], None, batch["visual_pos"], cluster_ids=batch["cluster_ids"],
@@ -492,6 +501,57 @@ def test_optimizer_pass_clears_the_gradients_when_asked():
     assert not drop.engine.grad_is_zero
     batch = synthetic_batch(cfg, B, L, grid, seed=300)
     assert torch.equal(keep.step(batch), drop.step(batch)) and torch.equal(keep.store.master, drop.store.master)
+
+
+@pytest.mark.parametrize("task", ["vis_mask_accum", "word_mask", "matched", "vqa", "nlvr2"])
+def test_overwritten_weight_gradients_every_task(task):
+    """PretrainStep(overwrite_grads=True, drop_grads=True) against the clear-then-accumulate step, bit for bit, for every task and
+    for gradient-accumulation windows (first micro-batch overwrites, the others add).  The host restatement of xl_adamw writes
+    NaN into every chunk it is told not to clear: a weight gradient that some branch accumulated instead of storing -- or did not
+    touch at all -- would poison the parameters (ParamStore.mark_overwritten is the static claim, this is its check)."""
+    cfg = XLxmertConfig(**TINY)
+    oc = oracle_cfg(cfg)
+    B, L, grid = 2, 8, 4
+    A = 29
+
+    def make(overwrite):
+        kw = dict(dtype=torch.float32, device="cpu", ops=FakeOps(torch.float32), total_steps=20, lr=1e-2, weight_decay=0.01,
+                  drop_grads=True, overwrite_grads=overwrite)
+        if task == "vis_mask_accum":
+            tr, _ = make_step(cfg, B, L, grid, lr=1e-2, weight_decay=0.01, drop_grads=True, overwrite_grads=overwrite)
+            return tr
+        if task in ("vqa", "nlvr2"):
+            store = ParamStore(cfg, "cpu", torch.float32, task=task, num_answers=A if task == "vqa" else 0)
+            store.load_named(O.make_vqa_state_dict(oc, A, 5) if task == "vqa" else O.make_nlvr2_state_dict(oc, 5))
+            return PretrainStep(cfg, B if task == "vqa" else 2 * B, L, grid * grid, store=store, task=task,
+                                num_answers=A if task == "vqa" else 0, **kw)
+        store = ParamStore(cfg, "cpu", torch.float32, task=task)
+        store.load_named(O.make_cls_state_dict(oc, 5))
+        return PretrainStep(cfg, B, L, grid * grid, store=store, task=task, **kw)
+
+    def batch_of(t):
+        if task == "vqa":
+            return O.make_vqa_inputs(oc, A, 600 + t, B, L, grid)
+        if task == "nlvr2":
+            return O.make_nlvr2_inputs(oc, 650 + t, B, L, grid)
+        b = synthetic_batch(cfg, B, L, grid, seed=700 + t)
+        if task in ("word_mask", "matched"):
+            wl, ml = O.make_lang_task_labels(oc, b["input_ids"], 800 + t)
+            b.update(word_labels=wl, matched_labels=ml)
+        return b
+
+    ref, got = make(False), make(True)
+    assert got.overwrite_grads and not ref.overwrite_grads and got.drop_grads
+    for t in range(4):
+        update = task != "vis_mask_accum" or t % 2 == 1          # accumulation: windows of two micro-batches
+        b = batch_of(t)
+        lr_, lg = ref.step(b, update=update), got.step(b, update=update)
+        assert torch.equal(torch.as_tensor(lr_).float(), torch.as_tensor(lg).float()), t
+        assert torch.equal(ref.store.master, got.store.master), t
+        assert torch.isfinite(got.store.master).all()
+    n = got.store.n_used
+    kept = ((got.store.decay_flags[:n // 256] & 4) != 0).float().mean().item()
+    assert kept > 0.4, kept                                        # the Linear weights: most of the buffer (tiny model: ~60 %)
 
 
 @pytest.mark.parametrize("task,num_answers", [("vis_mask", 0), ("vqa", 29), ("nlvr2", 0), ("all", 0), ("word_mask", 13)])

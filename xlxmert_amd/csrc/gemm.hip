@@ -349,7 +349,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.step_seed = cx.step_seed; p.ablate = ablate;
     p.trace = cx.gemm_trace;
     p.colsum_ws = nullptr;
-    p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0;
+    p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0; p.overwrite = 0;
     if (colsum_out != nullptr)
         XL_CHECK_ARG(colsum_ws != nullptr && !accumulate && (long)((M + 63) / 64) * N <= xl_workspace_floats(N), XL_ERR_BAD_ARG,
                      "xl_gemm: colsum_out needs a workspace (xl_workspace_floats), accumulate = 0 and M <= 262144");
@@ -509,7 +509,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
 
 extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const* C,
                                    const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
-                                   int count, int dtype, void* stream) {
+                                   int count, int overwrite_mask, int dtype, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     XL_CHECK_ARG(count >= 1 && count <= 8, XL_ERR_BAD_ARG, "xl_gemm_wgrad_group: count %d (1..8)", count);
     XL_CHECK_ARG(A && B && C && M && N && K && lda && ldb && ldc, XL_ERR_BAD_ARG, "xl_gemm_wgrad_group: null argument");
@@ -533,8 +533,9 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
     if (grouped && total * splitk < group_min_blocks) grouped = false;
     if (!grouped) {          // one launch per problem (fp32 parity path, operands the ping-pong kernel does not take, tiny groups)
         for (int i = 0; i < count; ++i) {
+            const int acc_i = (overwrite_mask >> i) & 1 ? 0 : 1;          // overwrite: xl_gemm stores (or clears + atomics when it splits K)
             int rc = xl_gemm(A[i], B[i], C[i], nullptr, nullptr, nullptr, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], 0, 0,
-                             0, 0, dtype, XL_F32, XL_EPI_NONE, 1.0f, 1, 0.f, 0, nullptr, nullptr, stream);
+                             0, 0, dtype, XL_F32, XL_EPI_NONE, 1.0f, acc_i, 0.f, 0, nullptr, nullptr, stream);
             if (rc != XL_OK) return rc;
         }
         return XL_OK;
@@ -563,6 +564,17 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
         pr.lda = lda[i]; pr.ldb = ldb[i]; pr.ldc = ldc[i];
         pr.tiles_m = (M[i] + 255) / 256; pr.tiles_n = (N[i] + 255) / 256;
         pr.vec = aligned16(C[i]) && ldc[i] % 4 == 0;
+        // overwrite: plain stores when every tile of the problem has ONE writer that takes the vector epilogue (no K split or the
+        // slab path, interior tiles, aligned rows); otherwise C is cleared here and the launch accumulates as usual
+        pr.overwrite = 0;
+        if ((overwrite_mask >> i) & 1) {
+            const bool one_writer = (g.rmw || g.slab != nullptr) && pr.vec && M[i] % 256 == 0 && N[i] % 256 == 0;
+            if (one_writer) pr.overwrite = 1;
+            else {
+                hipError_t e = hipMemset2DAsync(C[i], (size_t)ldc[i] * sizeof(float), 0, (size_t)N[i] * sizeof(float), M[i], st);
+                XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm_wgrad_group: memset failed: %s", hipGetErrorString(e));
+            }
+        }
         int kper = (K[i] + splitk - 1) / splitk;
         pr.kper = (kper + 63) / 64 * 64;
         g.tile_start[i] = acc;

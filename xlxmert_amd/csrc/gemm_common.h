@@ -21,6 +21,7 @@ struct GemmParams {
     float* slab;                      // split-K through slabs (slab_exchange): partial tiles [tile][split][64 Ki floats], or null
     int* tickets;                     // ... and one arrival counter per output tile (zero between launches)
     int tail_tiles, tail_kper;        // tail split (ping-pong kernel): the last tail_tiles tiles run as `splitk` K slices each
+    int overwrite;                    // grouped weight gradients, one writer per tile: store instead of read-modify-write
 };
 
 // ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)
@@ -704,6 +705,7 @@ constexpr int kGroupOrderMax = 320;
 struct GroupProblem {
     const void* A; const void* B; void* C;
     int M, N, K, lda, ldb, ldc, kper, tiles_m, tiles_n, vec;      // vec: C rows 16-byte aligned (vector accumulate)
+    int overwrite;                                                // C = result (plain stores by the tile's one writer) instead of C +=
 };
 struct GroupParams {
     int count, splitk;

@@ -321,8 +321,8 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int tm, int tn, int
             // one writer per tile (no split, or the slab path's last arriver), interior tile, aligned rows: vector accumulate
             if ((slab_tile >= 0) && p.vec_epi && mw + 128 <= p.M && nw + 64 <= p.N) {
                 float* wb = reinterpret_cast<float*>(smem + wave * 16384);
-                epilogue_quad_accum(p, wb, lane, mw, nw, true, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
-                epilogue_quad_accum(p, wb, lane, mw + 64, nw, true, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+                epilogue_quad_accum(p, wb, lane, mw, nw, !p.overwrite, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+                epilogue_quad_accum(p, wb, lane, mw + 64, nw, !p.overwrite, acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
                 return;
             }
         }

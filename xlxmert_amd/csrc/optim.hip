@@ -114,7 +114,8 @@ __global__ __launch_bounds__(TH) void adamw_kernel(float* __restrict__ p, float*
         }
         const float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
-        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the step's optimizer.zero_grad(), in this pass
+        if (zero_grad && !(fl & 4)) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the step's optimizer.zero_grad(), in
+                                                                                                         // this pass (bit 2: overwritten next step)
         const float4 mv = reinterpret_cast<float4*>(m)[i];
         const float4 vv = reinterpret_cast<float4*>(v)[i];
         const bool dec = wd > 0.f && (fl & 1);

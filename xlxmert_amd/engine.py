@@ -533,7 +533,8 @@ class LangHeads:
         M = self.n_rows if self.n_rows else e.MLd
         emb = "bert.embeddings.word_embeddings.weight"
         ops.colsum(self.dscores, self._gvb_pad(), M, Vp, Vp, ws=e.ws)
-        e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, M, Vp, d, d)              # tied decoder: d(word embeddings)
+        e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, M, Vp, d, d, once=False)  # tied decoder: d(word embeddings) also
+                                                                                            # receives the embedding scatter-add
         dhn = e.tmp("dctx", e.MLd, d)
         ops.gemm(self.dscores, st.cview(emb), dhn, None, None, None, M, d, Vn, Vp, d, d, a_kmajor=1, b_kmajor=0)
         dh = e.tmp("dz", e.MLd, d)
@@ -638,6 +639,7 @@ class Engine:
         self._seed = 0
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)       # step part of the dropout seeds
         self._tmp = {}
+        self.overwritten = set()
         self._pending = {"v": [], "l": []}
         self._held, self._held_layers, self._gen = {"v": [], "l": []}, {"v": 0, "l": 0}, {"v": 0, "l": 0}
         self._pending_block = {"v": "", "l": ""}
@@ -846,10 +848,23 @@ class Engine:
         if self.side is not None:
             self.ops.stream_fork(self.side, torch.cuda.current_stream())
 
-    def wgrad_defer(self, dY, X, dW, M, N, K, lda, ldb, ldc):
-        """register dW[M,N] += dY[K,M]^T X[K,N]; launched with the block's other weight gradients by wgrad_flush()."""
-        self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc))
+    # Set by the trainer for a backward that starts from gradients nobody needs (the first backward after an optimizer pass):
+    # every weight gradient with ONE contribution per step is stored instead of accumulated (xl_gemm_wgrad_group overwrite_mask),
+    # so its part of the buffer is neither cleared by the optimizer pass nor re-read by the epilogue (4 + 4 bytes per parameter).
+    # `overwritten` collects the flat ranges written that way (the trainer marks them "do not clear": ParamStore.mark_overwritten).
+    dw_overwrite = False
+
+    def wgrad_defer(self, dY, X, dW, M, N, K, lda, ldb, ldc, once=True):
+        """register dW[M,N] += dY[K,M]^T X[K,N]; launched with the block's other weight gradients by wgrad_flush().
+        once: this tensor gets no other gradient contribution in the step (False: the MLM decoder tied to the word embeddings)."""
+        self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc, bool(once and self.dw_overwrite)))
         self._pending_block[self._tag] = getattr(self.ops, "block", "")
+
+    def _note_overwritten(self, dW, M, N, ldc):
+        if ldc == N and dW.dtype == torch.float32:
+            off = (dW.data_ptr() - self.store.grad.data_ptr()) // 4
+            if 0 <= off and off + M * N <= self.store.n_total:
+                self.overwritten.add((off, off + M * N))
 
     PAIR_LAYERS = int(os.environ.get("XL_WGRAD_PAIR", "2"))          # layers per weight-gradient launch (1: every layer its own)
 
@@ -879,13 +894,18 @@ class Engine:
         self.ops.block = self._pending_block[tag]
         dw = self._dw.get(tag) if (self._dw is not None and self.side is not None) else None
         for i in range(0, len(probs), 8):       # (xl_gemm_wgrad_group takes up to 8 problems)
-            chunk = probs[i:i + 8]
+            chunk = [pr[:9] for pr in probs[i:i + 8]]
+            mask = sum(1 << j for j, pr in enumerate(probs[i:i + 8]) if pr[9])
+            for pr in probs[i:i + 8]:
+                if pr[9]:
+                    self._note_overwritten(pr[2], pr[3], pr[4], pr[8])
+            kw = {"overwrite_mask": mask} if mask else {}
             if dw is None:
-                self.ops.gemm_wgrad_group(chunk)
+                self.ops.gemm_wgrad_group(chunk, **kw)
                 continue
             self.ops.stream_fork(torch.cuda.current_stream(), dw)
             with torch.cuda.stream(dw):
-                self.ops.gemm_wgrad_group(chunk)
+                self.ops.gemm_wgrad_group(chunk, **kw)
             self._dw_busy[tag] = True
 
     def wgrad_sync(self):
@@ -1731,7 +1751,9 @@ class Engine:
                         st.gview(v + ".box_fc.weight"), st.gview(v + ".box_fc.bias"), st.gview(v + ".visn_fc.bias"),
                         MV, d, self.P, ws=self.ws)
         ops.gemm(dxv, self.feats, st.gview(v + ".visn_fc.weight"), None, None, None, d, self.F, MV, d, self.F, self.F,
-                 a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)
+                 a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=0 if self.dw_overwrite else 1)
+        if self.dw_overwrite:
+            self._note_overwritten(st.gview(v + ".visn_fc.weight"), d, self.F, self.F)
         if self.use_codebook and self.has_vmask:
             # d(mask_feat) = (sum over masked rows of d(xv)) W_visn   (ref lxrt/modeling.py:190-193: mask_feat is a Parameter)
             ops.zero(self.mf_tmp)

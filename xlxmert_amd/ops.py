@@ -170,15 +170,16 @@ class HipOps:
                       XL_F32 if out_f32 else self.dt, epilogue, float(alpha), int(accumulate), float(p_drop),
                       int(seed), self._p(colsum), self._p(ws if colsum is not None else None), self._stream())
 
-    def gemm_wgrad_group(self, problems):
-        """problems: list of (dY [K, M], X [K, N], dW [M, N] fp32, M, N, K, lda, ldb, ldc): dW += dY^T X, one launch."""
+    def gemm_wgrad_group(self, problems, overwrite_mask=0):
+        """problems: list of (dY [K, M], X [K, N], dW [M, N] fp32, M, N, K, lda, ldb, ldc): dW += dY^T X, one launch; bit i of
+        overwrite_mask: dW_i = dY_i^T X_i instead (a weight with one gradient contribution per step)."""
         import ctypes
         n = len(problems)
         vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
         cols = list(zip(*problems))
         ptrs = [vp(*[self._p(t) for t in cols[j]]) for j in range(3)]
         ints = [ia(*[int(v) for v in cols[j]]) for j in range(3, 9)]
-        self._call("xl_gemm_wgrad_group", *ptrs, *ints, n, self.dt, self._stream())
+        self._call("xl_gemm_wgrad_group", *ptrs, *ints, n, int(overwrite_mask), self.dt, self._stream())
 
     def set_gemm_wgrad_slabs(self, on):
         """weight-gradient K splits through the slab workspace (fixed summation order) instead of fp32 atomics."""

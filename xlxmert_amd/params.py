@@ -218,16 +218,35 @@ class ParamStore:
                 flags[u.offset // CHUNK:(u.offset + u.padded) // CHUNK] = 1
         self.decay_flags = flags.to(dev)
         self._task_flags = {}
+        self._kept = set()
         # frozen centroid codebook (vis_emb.weight == obj_predict_head.out_cluster.weight, ref modeling.py:140-151)
         self.centroids = None          # fp32 [K, F]
         self.centroids_c = None        # compute dtype
+
+    def mark_overwritten(self, ranges):
+        """ranges [(lo, hi)] of the flat gradient buffer that every backward OVERWRITES (weight gradients with one contribution per
+        step, xl_gemm_wgrad_group overwrite_mask): the optimizer pass need not clear them -- bit 2 of the per-chunk flags for every
+        256-element chunk that lies inside one of them.  In place: recorded launch plans hold the flag tensors' pointers."""
+        new = [r for r in ranges if r not in self._kept]
+        if not new:
+            return
+        self._kept.update(new)
+        fl = torch.zeros(self.n_total // CHUNK, dtype=torch.uint8)
+        for lo, hi in new:
+            c0, c1 = (lo + CHUNK - 1) // CHUNK, hi // CHUNK
+            if c1 > c0:
+                fl[c0:c1] = 4
+        fl = fl.to(self.device)
+        self.decay_flags |= fl
+        for t in self._task_flags.values():
+            t |= fl
 
     def task_flags(self, task):
         """per-chunk optimizer flags for one step of `task` on a multi-task ("all") store: bit 0 = weight decay, bit 1 = skip
         (tensors that get no gradient in that branch of the reference: .grad stays None and AdamW leaves them alone)."""
         if task not in self._task_flags:
             active = {m.name for u in build_units(self.cfg, task, self.num_answers, self.pair) if u.used for m in u.members}
-            fl = self.decay_flags.clone()
+            fl = self.decay_flags.clone()          # (with the keep bits marked so far; later ones are OR-ed into every clone)
             for u in self.units:
                 if not all(m.name in active for m in u.members):
                     fl[u.offset // CHUNK:(u.offset + u.padded) // CHUNK] |= 2

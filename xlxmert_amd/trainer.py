@@ -53,7 +53,7 @@ class PretrainStep:
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
                  bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None,
-                 plan=None, drop_grads=None, overlap_optimizer=None, collective=None):
+                 plan=None, drop_grads=None, overlap_optimizer=None, collective=None, overwrite_grads=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -98,7 +98,13 @@ class PretrainStep:
         (it waits slice by slice: engine.params_ready).  Same bytes on the wire as the all-reduce.  Same parameters as "allreduce"
         up to the summation order of the norm; a rank's Adam moments are current on its shards only (gather_state() makes them
         whole: checkpoints, verify_replicas).
-        Env XL_COLLECTIVE=allreduce|rs+ag overrides."""
+        Env XL_COLLECTIVE=allreduce|rs+ag overrides.
+        overwrite_grads: weight gradients with exactly one contribution per step (every Linear weight but the MLM decoder tied to
+        the word embeddings) are STORED by the first backward after an optimizer pass instead of accumulated into a cleared buffer
+        (engine.dw_overwrite -> xl_gemm_wgrad_group overwrite_mask): the optimizer pass does not clear them (decay_flags bit 2,
+        ParamStore.mark_overwritten) and the weight-gradient epilogue does not read them back -- 8 bytes per parameter and step
+        less HBM traffic.  Gradient accumulation (step(update=False)) overwrites with the window's first micro-batch and
+        accumulates the others.  Same gradients either way.  Default on; env XL_GRAD_OVERWRITE=0|1 overrides."""
         self.cfg = cfg
         self.task = task
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -172,6 +178,8 @@ class PretrainStep:
         env = os.environ.get("XL_PLAN")
         self.plan_mode = bool(int(env)) if env else bool(plan)
         self.plan_mode = self.plan_mode and isinstance(self.ops, HipOps) and task == "vis_mask"
+        env = os.environ.get("XL_GRAD_OVERWRITE")
+        self.overwrite_grads = bool(int(env)) if env else (True if overwrite_grads is None else bool(overwrite_grads))
         self._accum_pending = False            # gradient accumulation (step(update=False)): the buffer holds earlier micro-batches
         self.drop_grads = (self.plan_mode if drop_grads is None else bool(drop_grads)) and task != "all"
         env = os.environ.get("XL_OPT_OVERLAP")
@@ -494,6 +502,7 @@ class PretrainStep:
         if batch.get("_ready") is not None:           # staged by a BatchUploader: the copies must have landed
             torch.cuda.current_stream().wait_event(batch["_ready"])
         eng.accumulate = self._accum_pending          # earlier micro-batches are in the gradient buffer: do not clear it
+        eng.dw_overwrite = self.overwrite_grads and not eng.accumulate      # ... and add to it; otherwise one-writer gradients are stored
         accumulating = self._accum_pending or not update
         self._accum_pending = not update
         exchange = self.exchange and update
@@ -632,6 +641,8 @@ class PretrainStep:
 
     def optimizer_step(self):
         self.t += 1                      # host mirror of step_dev (seeds, logging): never read by a kernel
+        if self.engine.overwritten:      # ranges the backward stores rather than accumulates: the pass leaves them uncleared
+            self.store.mark_overwritten(sorted(self.engine.overwritten))
         self._optimizer_launches()
 
     # ---- sharded optimizer (collective="rs+ag"): shard-local norm + one scalar all-reduce, AdamW over this rank's shards,
