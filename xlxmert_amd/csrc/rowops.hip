@@ -97,18 +97,59 @@ __device__ __forceinline__ void flush_colsums(float (&acc)[NIT][VEC], float* out
 #pragma unroll
         for (int i = 0; i < VEC; ++i) red[(i * W + wave) * 64 + lane] = acc[it][i];
         __syncthreads();
-        if (wave == 0) {
+        // every wave finishes the columns i = wave, wave + W, ... of the lanes' vectors (one wave doing all VEC of them was a
+        // serial chain of VEC x W LDS reads per flush: ~4 us of the LayerNorm backward's fixed cost); same order of the W addends
+        {
             const int col = (it * 64 + lane) * VEC;
             if (col < N)
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    float s = 0.f;
+                for (int i0 = 0; i0 < VEC; i0 += W) {
+                    const int i = i0 + wave;
+                    if (i < VEC) {
+                        float s = 0.f;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) s += red[(i * W + w) * 64 + lane];
-                    if (ws_slot != nullptr) ws_slot[col + i] = s;
-                    else atomicAdd(out + col + i, s);
+                        for (int w = 0; w < W; ++w) s += red[(i * W + w) * 64 + lane];
+                        if (ws_slot != nullptr) ws_slot[col + i] = s;
+                        else atomicAdd(out + col + i, s);
+                    }
                 }
         }
+    }
+}
+
+// Three accumulator sets at once (LayerNorm backward: d gamma, d beta, d bias of the dense layer in front): one pair of barriers per
+// vector index instead of three -- the flush is pure latency at the end of every block (12 barrier round trips -> 4).
+// red: [3][VEC][W][64] floats.  Same addends in the same order as three flush_colsums calls.
+template <int NIT, int VEC, int W>
+__device__ __forceinline__ void flush_colsums3(float (&a0)[NIT][VEC], float (&a1)[NIT][VEC], float (&a2)[NIT][VEC], bool with2,
+                                               float* o0, float* o1, float* o2, int N, float* red, float* ws_slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[((0 * VEC + i) * W + wave) * 64 + lane] = a0[it][i];
+            red[((1 * VEC + i) * W + wave) * 64 + lane] = a1[it][i];
+            red[((2 * VEC + i) * W + wave) * 64 + lane] = a2[it][i];
+        }
+        __syncthreads();
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N)
+#pragma unroll
+            for (int j0 = 0; j0 < 3 * VEC; j0 += W) {            // 3 * VEC (set, column) pairs dealt to the W waves
+                const int j = j0 + wave;
+                if (j < 3 * VEC) {
+                    const int v = j / VEC, i = j % VEC;
+                    if (v < 2 || with2) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) sum += red[(j * W + w) * 64 + lane];
+                        if (ws_slot != nullptr) ws_slot[(size_t)v * N + col + i] = sum;
+                        else atomicAdd((v == 0 ? o0 : v == 1 ? o1 : o2) + col + i, sum);
+                    }
+                }
+            }
     }
 }
 
@@ -144,7 +185,7 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
                                                      const uint64_t* __restrict__ step_seed) {
     constexpr int VEC = Elem<T>::VEC;
     seed = with_step_seed(seed, step_seed);
-    __shared__ float red[W * 64 * VEC];
+    __shared__ float red[3 * W * 64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NIT][VEC] = {}, ab[NIT][VEC] = {}, ax[NIT][VEC] = {};
     // gamma lives in LDS, not in 16 registers: 4 waves per SIMD instead of 3.  Layout [it][quad of 4 columns][lane][4]: a lane's
@@ -221,9 +262,190 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
         }
     }
     float* slot = ws ? ws + (size_t)blockIdx.x * 3 * N : nullptr;
-    flush_colsums<NIT, VEC, W>(ag, dgamma, N, red, slot);
-    flush_colsums<NIT, VEC, W>(ab, dbeta, N, red, slot ? slot + N : nullptr);
-    if (dbias_prev != nullptr) flush_colsums<NIT, VEC, W>(ax, dbias_prev, N, red, slot ? slot + 2 * N : nullptr);
+    flush_colsums3<NIT, VEC, W>(ag, ab, ax, dbias_prev != nullptr, dgamma, dbeta, dbias_prev, N, red, slot);
+}
+
+// The same kernel with the NEXT row of a wave requested by LDS-DMA (buffer_load ... lds: global -> LDS without passing through
+// registers) while the current row is processed: per row the plain kernel is a dependent chain -- two row loads, two wave
+// reductions, two passes, the stores -- with ONE row's loads in flight per wave, and at four waves per SIMD the launch sits at
+// ~3 TB/s (100 MB in 33 us at 16384 rows).  A software pipeline through registers costs the occupancy it needs (measured, round 3:
+// 37 us); through LDS it costs none: a wave owns two 4 KiB slots [x | dy][NIT][64 lanes x 16 B] (lane-linear, so the row comes
+// back with one ds_read_b128 per vector), 64 KiB per 8-wave block, two blocks per CU.  Stores and loads share vmcnt on gfx950 and
+// complete out of order with each other, so the pipeline is: wait for EVERYTHING outstanding (this row's DMA and the previous
+// row's stores) -> request the next row -> read this row from LDS -> reductions, both passes, stores: the next row's latency
+// runs under this row's arithmetic.  bf16 rows of at most NIT x 1 KiB; same arithmetic in the same order as ln_bwd_kernel
+// (bit-identical results: tests/test_hip_kernels.py).
+#ifndef XL_LNB_DEBUG
+#define XL_LNB_DEBUG 0
+#endif
+template <int NIT, int W>
+__global__ __launch_bounds__(W * 64, 4) void ln_bwd_dma_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                         const float* __restrict__ rstd_i, bf16_t* __restrict__ dx,
+                                                         float* dgamma, float* dbeta, float* dbias_prev, int M, int N, float* ws,
+                                                         bf16_t* __restrict__ dx_drop, float p_drop, float inv_keep, uint64_t seed,
+                                                         const uint64_t* __restrict__ step_seed) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int VEC = 8, QD = 2;
+    constexpr int SLOT = 2 * NIT * 1024;                 // bytes of one row pair: [x | dy][NIT][64 x 16]
+    seed = with_step_seed(seed, step_seed);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lnb_lds[];      // [W][2 slots][SLOT] | gamma;  `red` reuses the ring
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    static_assert(NIT <= 2, "two 1 KiB vectors per tensor and row");
+    uint8_t* ring = lnb_lds + wave * 2 * SLOT;
+    const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)ring;
+    float* sgamma = reinterpret_cast<float*>(lnb_lds + W * 2 * SLOT);
+    float* red = reinterpret_cast<float*>(lnb_lds);
+    float ag[NIT][VEC] = {}, ab[NIT][VEC] = {}, ax[NIT][VEC] = {};
+    for (int c = threadIdx.x; c < NIT * 64 * VEC; c += W * 64) {
+        const int it = c / (64 * VEC), r = c % (64 * VEC), ln = r / VEC, i = r % VEC;
+        sgamma[((it * QD + i / 4) * 64 + ln) * 4 + (i & 3)] = c < N ? gamma[c] : 0.f;
+    }
+    const auto rsrc_of = [](const void* ptr, uint32_t bytes) {
+        const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    const uint32_t bytes = (uint32_t)((size_t)M * N * 2);
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(x, bytes), rd = rsrc_of(dy, bytes);
+    uint32_t lane_off[NIT];                              // byte offset of the lane's vector inside a row; out of range -> zeros
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) lane_off[it] = (it * 64 + lane) * VEC < N ? (uint32_t)((it * 64 + lane) * VEC * 2) : 0x7FFFFFF0u;
+    const auto request = [&](int row, int slot) {
+        const uint32_t base = (uint32_t)row * (uint32_t)N * 2u;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const uint32_t vo = lane_off[it] == 0x7FFFFFF0u ? 0x7FFFFFF0u : base + lane_off[it];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(ring + slot * SLOT + it * 1024), 16,
+                                                     (int)vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(ring + slot * SLOT + (NIT + it) * 1024), 16,
+                                                     (int)vo, 0, 0, 0);
+        }
+    };
+    __syncthreads();                                     // gamma is in place
+    // gamma, too, is read through inline assembly (see the row reads below): [it][quad][lane][4] floats, 1 KiB per (it, quad)
+    const uint32_t g_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)lnb_lds + (uint32_t)(W * 2 * SLOT) + (uint32_t)lane * 16u;
+    const auto read_gamma = [&](int it, float (&gm)[VEC]) {
+        u32x4 a, b;
+        // (the reads and their wait are ONE statement: as separate asm statements hipcc moved the second read behind the wait)
+        if (it == 0)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a), "=&v"(b) : "v"(g_addr) : "memory");
+        else
+            asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a), "=&v"(b) : "v"(g_addr) : "memory");
+        gm[0] = __uint_as_float(a.x); gm[1] = __uint_as_float(a.y); gm[2] = __uint_as_float(a.z); gm[3] = __uint_as_float(a.w);
+        gm[4] = __uint_as_float(b.x); gm[5] = __uint_as_float(b.y); gm[6] = __uint_as_float(b.z); gm[7] = __uint_as_float(b.w);
+    };
+    const int stride = gridDim.x * W;
+    int row = blockIdx.x * W + wave, slot = 0;
+    if (row < M) request(row, 0);
+    for (; row < M; row += stride, slot ^= 1) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this row has landed; the previous row's stores are out
+        if (row + stride < M) request(row + stride, slot ^ 1);
+        // (the row comes out of LDS through inline assembly: in front of a plain LDS read hipcc drains every outstanding
+        //  buffer_load ... lds -- it cannot see that the slot being read and the slot being filled differ -- which would wait
+        //  for the row just requested; cf. gemm_common.h TrFrag)
+        u32x4 xq[NIT], dq[NIT];
+        const uint32_t rd_addr = ring_lds + (uint32_t)(slot * SLOT) + (uint32_t)lane * 16u;
+#if XL_LNB_DEBUG == 3
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+            if (col < N) { a = *reinterpret_cast<const uint4*>(x + (size_t)row * N + col); b = *reinterpret_cast<const uint4*>(dy + (size_t)row * N + col); }
+            xq[it].x = a.x; xq[it].y = a.y; xq[it].z = a.z; xq[it].w = a.w;
+            dq[it].x = b.x; dq[it].y = b.y; dq[it].z = b.z; dq[it].w = b.w;
+        }
+#elif XL_LNB_DEBUG == 1
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const uint4 a = *reinterpret_cast<const uint4*>(ring + slot * SLOT + it * 1024 + lane * 16);
+            const uint4 b = *reinterpret_cast<const uint4*>(ring + slot * SLOT + (NIT + it) * 1024 + lane * 16);
+            xq[it].x = a.x; xq[it].y = a.y; xq[it].z = a.z; xq[it].w = a.w;
+            dq[it].x = b.x; dq[it].y = b.y; dq[it].z = b.z; dq[it].w = b.w;
+        }
+#else
+#if XL_LNB_DEBUG == 2
+        asm volatile("s_sleep 4" ::: "memory");
+#endif
+        if constexpr (NIT == 1)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(xq[0]), "=&v"(dq[0]) : "v"(rd_addr) : "memory");
+        else
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                         "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(xq[0]), "=&v"(xq[NIT - 1]), "=&v"(dq[0]), "=&v"(dq[NIT - 1]) : "v"(rd_addr) : "memory");
+#endif
+        uint4 xr[NIT], dr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            xr[it] = make_uint4(xq[it].x, xq[it].y, xq[it].z, xq[it].w);
+            dr[it] = make_uint4(dq[it].x, dq[it].y, dq[it].z, dq[it].w);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N) {
+                float xv[VEC], dv[VEC], gm[VEC];
+                unpack_raw(xr[it], xv);
+                unpack_raw(dr[it], dv);
+                read_gamma(it, gm);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float xh = (xv[i] - mean) * rstd;
+                    const float gd = gm[i] * dv[i];
+                    s1 += gd; s2 += gd * xh;
+                    ag[it][i] += dv[i] * xh;
+                    ab[it][i] += dv[i];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)N, c2 = wave_sum(s2) / (float)N;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N) {
+                float xv[VEC], dv[VEC], o[VEC], gm[VEC];
+                unpack_raw(xr[it], xv);
+                unpack_raw(dr[it], dv);
+                read_gamma(it, gm);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    o[i] = rstd * (gm[i] * dv[i] - c1 - (xv[i] - mean) * rstd * c2);
+                stvec(dx + (size_t)row * N + col, o);
+                if (dx_drop != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        o[i] *= dropout_scale(seed, (uint32_t)row, (uint32_t)(col + i), p_drop, inv_keep);
+                    stvec(dx_drop + (size_t)row * N + col, o);
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) ax[it][i] += o[i];
+            }
+        }
+    }
+    float* slot_ws = ws ? ws + (size_t)blockIdx.x * 3 * N : nullptr;
+    flush_colsums3<NIT, VEC, W>(ag, ab, ax, dbias_prev != nullptr, dgamma, dbeta, dbias_prev, N, red, slot_ws);
+}
+
+template <int NIT>
+static hipError_t launch_ln_bwd_dma(int grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
+                                    const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev, int M, int N,
+                                    float* workspace, void* dx_dropped, float p_drop, uint64_t seed) {
+    constexpr int lds = LNB_W * 2 * (2 * NIT * 1024) + NIT * 64 * 8 * 4;
+    auto k = ln_bwd_dma_kernel<NIT, LNB_W>;
+    static bool attr = false;
+    hipError_t e = hipSuccess;
+    if (!attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(LNB_W * 64), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx,
+                       dgamma, dbeta, dbias_prev, M, N, workspace, (bf16_t*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed,
+                       xl::ctx().step_seed);
+    return e;
 }
 
 // ------------------------------------------------------------------ visual feature encoder tail (HF:468-476)
@@ -1256,10 +1478,21 @@ extern "C" int xl_layernorm_bwd(const void* dy, const void* x, const float* gamm
     if (p_drop == 0.f) dx_dropped = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int grid = min((M + LNB_W - 1) / LNB_W, 512);        // 2 blocks x 8 waves per CU = the 4 waves per SIMD the kernel is built for
-    DISPATCH_T(dtype, DISPATCH_NIT(T, N,
-        hipLaunchKernelGGL((ln_bwd_kernel<T, NIT, LNB_W>), dim3(grid), dim3(LNB_W * 64), 0, st,
-                           (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace,
-                           (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed, xl::ctx().step_seed);));
+    // rows that take several passes of the grid and fit two 1 KiB vectors per wave: the variant that requests a wave's next row by
+    // LDS-DMA under the current row's arithmetic (XL_LN_BWD_DMA=0: the plain kernel; XL_LN_BWD_DMA_MIN_ROWS: default 2 passes)
+    static const int dma_mode = [] { const char* e = getenv("XL_LN_BWD_DMA"); return e ? atoi(e) : 1; }();
+    static const int dma_min_rows = [] { const char* e = getenv("XL_LN_BWD_DMA_MIN_ROWS"); return e ? atoi(e) : 2 * 512 * LNB_W; }();
+    if (dma_mode && dtype == XL_BF16 && N <= 1024 && N % 8 == 0 && M >= dma_min_rows && (double)M * N * 2 < 2.0e9 &&
+        aligned16(dy) && aligned16(x)) {
+        const hipError_t e = N <= 512 ? launch_ln_bwd_dma<1>(grid, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, workspace, dx_dropped, p_drop, seed)
+                                      : launch_ln_bwd_dma<2>(grid, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias_prev, M, N, workspace, dx_dropped, p_drop, seed);
+        XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_layernorm_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    } else {
+        DISPATCH_T(dtype, DISPATCH_NIT(T, N,
+            hipLaunchKernelGGL((ln_bwd_kernel<T, NIT, LNB_W>), dim3(grid), dim3(LNB_W * 64), 0, st,
+                               (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, dbias_prev, M, N, workspace,
+                               (T*)dx_dropped, p_drop, 1.0f / (1.0f - p_drop), seed, xl::ctx().step_seed);));
+    }
     XL_CHECK_LAUNCH();
     if (workspace) {
         ReduceOuts o = {};
