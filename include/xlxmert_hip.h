@@ -79,9 +79,10 @@ int  xl_set_step_seed_ptr(const uint64_t* step_seed);
 /* GEMM kernel choice for bf16 operands: 0 = 128x128 kernel only, 1 = by shape (default), 2 = the 256x256 ping-pong
  * kernel whenever the operands allow it (tuning / test switch; env XL_GEMM_PP sets the initial value) */
 int  xl_set_gemm_pingpong(int mode);
-/* 256x192 output tiles of the ping-pong kernel (forward / dX layouts, N a multiple of 192, M of 256, bf16 output): 0 = never,
- * 1 = when they shorten the launch (default: N = 768 gives 192 tiles of 256x256 on 256 CUs but 256 of 256x192), 2 = whenever
- * eligible (test switch; env XL_GEMM_BN192 sets the initial value) */
+/* 256x192 output tiles of the ping-pong kernel (forward / dX layouts, N a multiple of 192, M of 256, bf16 output): 0 = never
+ * (default since round 4: in the four-stream step a main-chain launch that leaves a quarter of the CUs to the other streams is worth
+ * more than the full round it forgoes, -0.27 .. -0.37 ms per step), 1 = when they shorten the launch taken alone (N = 768 gives 192
+ * tiles of 256x256 on 256 CUs but 256 of 256x192), 2 = whenever eligible (test switch); env XL_GEMM_BN192 sets the initial value */
 int  xl_set_gemm_tile192(int mode);
 /* persistent variant of the ping-pong kernel for launches of several rounds of 256x256 tiles with a short contraction (the FFN's
  * first Linear and the gradient through its GELU: N = 3072, K = 768): one workgroup per CU walks its tiles and requests the next
@@ -96,6 +97,13 @@ int  xl_set_gemm_persistent(int on);
  * run on the 128x128 kernel at 0.10 MFMA-busy: -0.15..-0.25 ms per step --, 2 = whenever eligible (measured equal to the whole-CU
  * tiles on the large launches); env XL_GEMM_DUO.  Bit-identical results to the other tile shapes. */
 int  xl_set_gemm_duo(int mode);
+/* K split of a launch WITH an epilogue (forward / dX layouts, bf16 in and out, fast epilogue): a launch of at most
+ * XL_GEMM_SPLIT_EPI_MAX_TILES (80) output tiles of 256x192 / 256x256 whose contraction is at least XL_GEMM_SPLIT_EPI_MIN_K (1536)
+ * deep runs every tile as 2..4 K slices of >= 12 K tiles on whole-CU workgroups; the slices meet in the stream's slab workspace
+ * (xl_gemm_set_workspace: needed), are summed in slice order by the last arriver (deterministic), which runs the epilogue.  The
+ * language stream's 3328 packed rows against the d x dff and d x 3d weights are the case: 56 tiles, K = 3072 / 2304 -- 47 -> ~25 us.
+ * 1 = when eligible (default; env XL_GEMM_SPLIT_EPI), 0 = never.  Same values as the unsplit launch up to the fp32 summation order. */
+int  xl_set_gemm_split_epi(int on);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */
 int  xl_gemm_trace(void* buffer);

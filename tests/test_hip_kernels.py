@@ -290,6 +290,65 @@ def _tiles_exact(M, N, K, epi, bk, duo):
         ops.set_gemm_duo(1)
 
 
+@pytest.mark.parametrize("bk", [1, 0])
+@pytest.mark.parametrize("epi", [0, 2, 3, 7])
+@pytest.mark.parametrize("M,N,K", [(3584, 768, 3072), (3328, 768, 2304), (1024, 768, 1536), (512, 256, 4096)])
+def test_gemm_split_k_with_epilogue_exact_and_deterministic(M, N, K, epi, bk):
+    """K split of a few-tile, deep-K launch WITH an epilogue (xl_set_gemm_split_epi: the language stream's 3328..3584 packed rows
+    against d x dff / d x 3d weights): every output tile as 2..4 K slices on whole-CU workgroups, partial accumulators through the
+    stream's slab workspace, the last arriver runs the epilogue.  (i) integer-valued operands: exactly the host product / the host
+    restatement of the epilogue, like the unsplit tiles; (ii) random operands: the same bits as a second and third launch (the
+    slices are summed in slice order whoever arrives last) and within fp32 re-association of the unsplit launch; (iii) without a
+    workspace on the stream the launch falls back to the unsplit kernels."""
+    ops = hip(torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = int(ops.lib.raw("xl_gemm_workspace_bytes")(256))
+    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    g = torch.Generator().manual_seed(M + N + K + epi * 3 + bk)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+    B = torch.randint(-3, 4, ((N, K) if bk else (K, N)), generator=g).to(torch.bfloat16)
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    res = torch.randint(-8, 9, (M, N), generator=g).to(torch.bfloat16)
+    aux = (torch.randint(-8, 9, (M, N), generator=g).float() * 0.25).to(torch.bfloat16)
+    alpha = 2.0 ** -6 if epi in (3, 7) else 1.0
+    try:
+        ops.lib.call("xl_gemm_set_workspace", ws.data_ptr(), nbytes, st)
+        ops.set_gemm_split_epi(1)
+        for rep in range(2):
+            C = torch.full((M, N), 7.0, dtype=torch.bfloat16)
+            cpu, gpu = run_both(torch.bfloat16, "gemm", [A, B, C, bias, res if epi == 2 else None, aux.clone() if epi in (3, 7) else None,
+                                                         M, N, K, K, (K if bk else N), N],
+                                dict(ldr=N, ldx=N, b_kmajor=bk, epilogue=epi, alpha=alpha, p_drop=0.0))
+            if epi in (0, 2):
+                assert torch.equal(gpu[2], cpu[2]), f"rep {rep}: max abs diff {(gpu[2].float() - cpu[2].float()).abs().max().item()}"
+            else:
+                close(gpu[2], cpu[2], torch.bfloat16, f"split-K epilogue {epi}", bf16_tol=1e-2)
+        # random operands: run-to-run determinism, and agreement with the unsplit launch
+        Ar = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        Br = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.05).to(torch.bfloat16).cuda()
+        resg, auxg, biasg = res.cuda(), aux.cuda(), bias.cuda()
+
+        def launch():
+            C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(Ar, Br, C, biasg, resg if epi == 2 else None, auxg.clone() if epi in (3, 7) else None, M, N, K, K, K if bk else N, N,
+                     ldr=N, ldx=N, a_kmajor=1, b_kmajor=bk, epilogue=epi, p_drop=0.1 if epi == 2 else 0.0, seed=31)
+            torch.cuda.synchronize()
+            return C
+        runs = [launch() for _ in range(3)]
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+        ops.set_gemm_split_epi(0)
+        plain = launch()
+        d = (runs[0].float() - plain.float()).abs()
+        assert d.max().item() <= 2 ** -6 * plain.float().abs().max().item() and (d > 0).float().mean().item() < 0.05
+        ops.set_gemm_split_epi(1)
+        ops.lib.call("xl_gemm_set_workspace", None, 0, st)               # no workspace: the unsplit kernels, bit for bit
+        assert torch.equal(launch(), plain)
+    finally:
+        ops.set_gemm_split_epi(1)
+        ops.lib.call("xl_gemm_set_workspace", None, 0, st)
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N", [(512, 256), (256, 512), (200, 136)])
 def test_gemm_fused_column_sums(M, N, dtype, pingpong):

@@ -301,6 +301,11 @@ extern "C" int xl_set_gemm_persistent(int on) {
     return XL_OK;
 }
 
+extern "C" int xl_set_gemm_split_epi(int on) {
+    ctx().gemm_split_epi = on ? 1 : 0;
+    return XL_OK;
+}
+
 extern "C" int xl_set_gemm_duo(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_duo: mode %d", mode);
     ctx().gemm_duo = mode;
@@ -349,7 +354,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed; p.step_seed = cx.step_seed; p.ablate = ablate;
     p.trace = cx.gemm_trace;
     p.colsum_ws = nullptr;
-    p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0; p.overwrite = 0;
+    p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0; p.overwrite = 0; p.slab_det = 0;
     if (colsum_out != nullptr)
         XL_CHECK_ARG(colsum_ws != nullptr && !accumulate && (long)((M + 63) / 64) * N <= xl_workspace_floats(N), XL_ERR_BAD_ARG,
                      "xl_gemm: colsum_out needs a workspace (xl_workspace_floats), accumulate = 0 and M <= 262144");
@@ -376,7 +381,11 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // estimated as rounds over the 256 CUs x relative tile cost (a 256x192 tile does 3/4 of the MFMA work plus the same
     // fixed prologue / epilogue latency: ~0.8).  N = 768: 64 row tiles give 192 tiles of 256x256 (a quarter of the chip
     // idle) or 256 of 256x192; N = 2304: 576 (2.25 rounds) or 768 (3 rounds of 0.8); N = 3072 stays at 256x256.
-    if (cx.gemm_bn192 < 0) cx.gemm_bn192 = env_int("XL_GEMM_BN192", 1);     // 0 never, 1 by cost, 2 whenever eligible
+    // Default 0 since round 4: alone, N = 768 as 256 tiles of 256x192 beats 192 tiles of 256x256 (one full round instead of 3/4 of the
+    // chip) and the isolated GEMM sum is 2 % better with mode 1 -- but the step runs four streams, and a main-chain launch that takes
+    // every CU makes the language stream's and the weight-gradient stream's workgroups wait for a whole tile: measured on three boxes,
+    // A/B/A: 17.23 -> 16.96, 17.35 -> 17.07, 17.85 -> 17.48 ms per step with 256x256 tiles only (mode 2, always 192-wide: 17.52).
+    if (cx.gemm_bn192 < 0) cx.gemm_bn192 = env_int("XL_GEMM_BN192", 0);     // 0 never, 1 by cost, 2 whenever eligible
     const int bn192_mode = cx.gemm_bn192;
     int bn = 256;
     if (use_pp && bn192_mode && a_kmajor && M % 256 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate &&
@@ -429,6 +438,38 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         p.tiles_n = (N + tile - 1) / tile;
         tiles = p.tiles_m * p.tiles_n;    // (the tail split below and the grid size count THESE tiles; the K split above was sized
     }                                     //  for an fp32-output launch, which never takes the 192-wide tile)
+    // K split of a launch WITH an epilogue (forward / dX layouts, bf16 out): a launch of few output tiles and a deep contraction
+    // -- the language stream's 3328 packed rows against d x dff / d x 3d weights: 52-56 tiles of 256x192, K = 3072 / 2304 -- runs every
+    // tile as `splitk` K slices on whole-CU ping-pong workgroups whose partial accumulators meet in the stream's slab workspace
+    // (slab_exchange, summed in slice order: deterministic); the last arriver runs the ordinary fast epilogue.  The same FLOPs on
+    // 4x the CUs for a quarter of the time: as 112 half-CU "duo" workgroups, each alone on a CU with one wave per SIMD, these
+    // launches ran at 0.14 of the MFMA peak (47 us for 16.9 GFLOP).  XL_GEMM_SPLIT_EPI=0 disables; thresholds below.
+    if (cx.gemm_split_epi < 0) cx.gemm_split_epi = env_int("XL_GEMM_SPLIT_EPI", 0);
+    const int split_epi = cx.gemm_split_epi;
+    static const int split_epi_min_k = env_int("XL_GEMM_SPLIT_EPI_MIN_K", 1536);
+    static const int split_epi_max_tiles = env_int("XL_GEMM_SPLIT_EPI_MAX_TILES", 80);
+    bool epi_split = false;
+    if (split_epi && pp_ok && pp_mode && a_kmajor && epik >= 0 && epik != XL_EPI_ROWMAX && out_dtype == in_dtype && !accumulate &&
+        colsum_out == nullptr && splitk == 1 && !p.atomic_out && K >= split_epi_min_k && K % 64 == 0 && M % 256 == 0 &&
+        (double)M * lda < 1e9) {
+        const int e_bn = (N % 192 == 0 && (N % 256 != 0 || (M / 256) * (N / 192) <= 256)) ? 192 : (N % 256 == 0 ? 256 : 0);
+        if (e_bn) {
+            const int e_tiles = (M / 256) * (N / e_bn);
+            static const int split_epi_max_s = env_int("XL_GEMM_SPLIT_EPI_MAX_S", 4);
+            int S = std::min(std::min(256 / std::max(e_tiles, 1), K / 768), split_epi_max_s);     // >= 12 K tiles per slice
+            if (e_tiles <= split_epi_max_tiles && S >= 2) {
+                int kper_e = ((K + S - 1) / S + 63) / 64 * 64;
+                S = (K + kper_e - 1) / kper_e;
+                if (S >= 2 && slab_workspace(st, e_tiles, (long)e_tiles * S, &p.slab, &p.tickets)) {
+                    epi_split = true;
+                    bn = e_bn;
+                    p.tiles_m = M / 256; p.tiles_n = N / e_bn;
+                    tiles = e_tiles;
+                    p.splitk = S; p.kper = kper_e; p.slab_det = 1;
+                }
+            }
+        }
+    }
     // 128x192 "duo" tiles, two four-wave workgroups per CU (gemm_pp_kernel.h PPGeo<192, 128>): same eligibility as the 256x192 tile
     // (forward / dX layouts, N a multiple of 192, fast epilogue, plain stores) with M a multiple of 128
     // mode 1: the launches of fewer than XL_GEMM_DUO_MAX_TILES 256x256 tiles (the language stream's: 3328 packed rows = 39 tiles,
@@ -436,7 +477,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     if (cx.gemm_duo < 0) cx.gemm_duo = env_int("XL_GEMM_DUO", 1);
     static const int duo_max_tiles = env_int("XL_GEMM_DUO_MAX_TILES", 64);
     int bm = 256;
-    if (pp_ok && pp_mode && cx.gemm_duo && a_kmajor && M % 128 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate && epik >= 0 &&
+    if (!epi_split && pp_ok && pp_mode && cx.gemm_duo && a_kmajor && M % 128 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate && epik >= 0 &&
         colsum_out == nullptr && epilogue != XL_EPI_TANH && epilogue != XL_EPI_ROWMAX && splitk == 1 && !p.atomic_out &&
         (double)M * lda < 1e9 && (cx.gemm_duo == 2 || t256n <= duo_max_tiles)) {
         bm = 128; bn = 192;
@@ -447,14 +488,14 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     const bool colsum_fused = colsum_out != nullptr && mfma_ok && epik >= 0 && splitk == 1 && a_kmajor && M % tile == 0 &&
                               N % tile == 0;
     if (colsum_fused) p.colsum_ws = colsum_ws;
-    int nblk = p.tiles_m * p.tiles_n * splitk;
+    int nblk = p.tiles_m * p.tiles_n * (epi_split ? p.splitk : splitk);
     // tail split (gemm_pp.hip): more than one round of tiles, a nearly empty last round, a deep contraction, and a slab
     // workspace on this stream (xl_gemm_set_workspace)
     // (measured at the masked-row head, 8448 rows: d(feat) = d(logits) C, K = 10000, 264 tiles: 466 -> 332 us; the logits
     // contraction, K = 2048, 1320 tiles, does not gain -- 338 -> 368 us -- hence the depth threshold)
     if (cx.tail_max < 0) { cx.tail_max = env_int("XL_GEMM_TAIL_MAX", 64); cx.tail_min_k = env_int("XL_GEMM_TAIL_MIN_K", 4096); }
     const int tail_max = cx.tail_max, tail_min_k = cx.tail_min_k;
-    if (use_pp && bm == 256 && splitk == 1 && !p.atomic_out && tiles > 256 && tiles % 256 <= tail_max && tiles % 256 > 0 && K >= tail_min_k) {
+    if (use_pp && !epi_split && bm == 256 && splitk == 1 && !p.atomic_out && tiles > 256 && tiles % 256 <= tail_max && tiles % 256 > 0 && K >= tail_min_k) {
         const int rem = tiles % 256;
         int S = std::min(std::min(256 / rem, K / 512), 8);          // >= 8 K tiles per slice, <= 7 slabs for the last arriver to add
         if (S >= 2) {
@@ -484,7 +525,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         }
         XL_CHECK_ARG(e == hipErrorInvalidValue, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    if (use_pp || bm == 128) {
+    if (use_pp || bm == 128 || epi_split) {
         hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st, bm);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     } else if (mfma_ok) {

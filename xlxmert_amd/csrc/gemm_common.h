@@ -22,6 +22,7 @@ struct GemmParams {
     int* tickets;                     // ... and one arrival counter per output tile (zero between launches)
     int tail_tiles, tail_kper;        // tail split (ping-pong kernel): the last tail_tiles tiles run as `splitk` K slices each
     int overwrite;                    // grouped weight gradients, one writer per tile: store instead of read-modify-write
+    int slab_det;                     // slab exchange: the last arriver sums ALL slices from memory in slice order (its own included)
 };
 
 // ------------------------------------------------------------------ scalar epilogue (generic kernel, ragged edges)
@@ -647,8 +648,19 @@ __device__ __forceinline__ bool slab_exchange(const GemmParams& p, uint8_t* smem
     const int ticket = *flag;
     __syncthreads();                  // the ticket word lies in wave 0's epilogue buffer: everyone has read it before anyone goes on
     if (ticket != nz - 1) return false;
+    // slab_det (launches whose OUTPUT feeds the forward pass: K split of a launch with an epilogue): which slice arrives last varies
+    // from run to run, and fp32 addition is not associative -- so the last arriver drops its registers and adds every slice's slab
+    // in slice order, its own (already written above, still in L2) included: the same bits every run
+    if (p.slab_det) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < C; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
     for (int o = 0; o < nz; ++o) {
-        if (o == z) continue;
+        if (o == z && !p.slab_det) continue;
         const float4* s = reinterpret_cast<const float4*>(p.slab + ((size_t)tile * p.splitk + o) * SLAB_FLOATS) + tid;
 #pragma unroll
         for (int i = 0; i < R; ++i) {

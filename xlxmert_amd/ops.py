@@ -106,6 +106,10 @@ class HipOps:
         """128x192 tiles, two four-wave workgroups per CU: 0 never, 1 small launches (default), 2 every eligible launch."""
         self._call("xl_set_gemm_duo", int(mode))
 
+    def set_gemm_split_epi(self, on):
+        """K split of few-tile, deep-K launches with an epilogue through the stream's slab workspace: 1 when eligible (default), 0 never."""
+        self._call("xl_set_gemm_split_epi", int(on))
+
     def set_gemm_tail_split(self, max_tail_tiles, min_k):
         self._call("xl_set_gemm_tail_split", int(max_tail_tiles), int(min_k))
 
