@@ -205,6 +205,10 @@ int xl_visn_ln_bwd(const void* dy, const void* xv, const float* pos, const float
  * stream in one launch.  While deferred, every such call needs a workspace region of its own. */
 int xl_set_deferred_reduce(int on);
 int xl_flush_reductions(void* stream);
+/* the same combine launch for everything pending from `producer_stream`, issued on `launch_stream` (which the caller has ordered
+ * after the producers: xl_stream_fork): the training step rides its per-layer combines on the weight-gradient companion stream, off
+ * the dX dependency chain (~25 six-microsecond launches and their launch gaps per step) */
+int xl_flush_reductions_on(void* producer_stream, void* launch_stream);
 
 /* ---------------------------------------------------------------- embeddings (HF:191-214)
  * y[b,l] = LN(word[ids[b,l]] + pos[l] + type[tt[b,l]]); tables in `dtype`; saves pre-LN sum + stats. */

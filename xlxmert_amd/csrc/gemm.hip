@@ -569,7 +569,8 @@ extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, v
         max_split = std::min(max_split, std::max(1, K[i] / 512));
     }
     static const int group_min_blocks = env_int("XL_GEMM_GROUP_MIN_BLOCKS", 96);
-    int splitk = total >= 256 ? 1 : (int)std::min<long>(256 / total, max_split);
+    static const int group_max_wgs = env_int("XL_GEMM_GROUP_MAX_WGS", 256);       // workgroups a K-split group launch may put up
+    int splitk = total >= group_max_wgs ? 1 : (int)std::min<long>(group_max_wgs / total, max_split);
     if (splitk < 1) splitk = 1;
     if (grouped && total * splitk < group_min_blocks) grouped = false;
     if (!grouped) {          // one launch per problem (fp32 parity path, operands the ping-pong kernel does not take, tiny groups)

@@ -1435,13 +1435,15 @@ extern "C" int xl_set_deferred_reduce(int on) {
     return XL_OK;
 }
 
-extern "C" int xl_flush_reductions(void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+extern "C" int xl_flush_reductions(void* stream) { return xl_flush_reductions_on(stream, stream); }
+
+extern "C" int xl_flush_reductions_on(void* producer_stream, void* launch_stream) {
+    hipStream_t st = (hipStream_t)launch_stream;
     std::vector<PendingReduce> todo;
     {
         Ctx& c = ctx();
         std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.pending.find(st);
+        auto it = c.pending.find((hipStream_t)producer_stream);
         if (it == c.pending.end() || it->second.empty()) return XL_OK;
         todo.swap(it->second);
     }

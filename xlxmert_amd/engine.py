@@ -424,7 +424,7 @@ class AnswerHead:
         e, d, B, A, Ap, din = self.e, self.e.d, self.Bh, self.A, self.Ap, self.din
         ops, st = e.ops, e.store
         pooled, dpooled = pooled.view(B, din), self.dpooled.view(B, din)
-        ops.colsum(self.dlogit, self.gb3_pad(), B, Ap, Ap, ws=e.ws)      # pad columns of dlogit are zero
+        ops.colsum(self.dlogit, self.gb3_pad(), B, Ap, Ap, ws=e.ws_wide("answer", Ap))      # pad columns of dlogit are zero
         e.wgrad_defer(self.dlogit, self.hn, self.gw3, A, 2 * d, B, Ap, 2 * d, 2 * d)
         ops.gemm(self.dlogit, self.w3, self.dhn, None, None, None, B, 2 * d, A, Ap, 2 * d, 2 * d, a_kmajor=1, b_kmajor=0)
         ops.layernorm_bwd(self.dhn, self.h, self.g, self.mean, self.rstd, self.dh, self.gg, self.gb, None, B, 2 * d, ws=e.ws)
@@ -532,7 +532,7 @@ class LangHeads:
         ops, st = e.ops, e.store
         M = self.n_rows if self.n_rows else e.MLd
         emb = "bert.embeddings.word_embeddings.weight"
-        ops.colsum(self.dscores, self._gvb_pad(), M, Vp, Vp, ws=e.ws)
+        ops.colsum(self.dscores, self._gvb_pad(), M, Vp, Vp, ws=e.ws_wide("mlm", Vp))
         e.wgrad_defer(self.dscores, self.hn, st.gview(emb), Vn, d, M, Vp, d, d, once=False)  # tied decoder: d(word embeddings) also
                                                                                             # receives the embedding scatter-add
         dhn = e.tmp("dctx", e.MLd, d)
@@ -737,10 +737,15 @@ class Engine:
         # two-stage column reductions: one workspace per stream (language / visual work runs concurrently)
         # (the second stages are deferred and combined per layer -- flush_reductions -- so every producer between two flushes
         # gets a workspace region of its own: _WS_REGIONS per stream)
-        self._ws_len = {"v": ops.workspace_floats(max(3 * d, self.dff, self.F, self.Kp)),
-                        "l": ops.workspace_floats(max(3 * d, self.dff))}
-        self._ws = {t: self.f32(self._WS_REGIONS * n) for t, n in self._ws_len.items()}
+        # regions are allocated when first used, per (stream, scratch generation, index): a generation's regions are rewritten only
+        # after the launch that combined them is known to be done (wgrad_sync).  The 10k-codebook head's column sum (the only
+        # producer wider than dff) has a workspace of its own.
+        self._ws_len = {"v": ops.workspace_floats(max(3 * d, self.dff, self.F)), "l": ops.workspace_floats(max(3 * d, self.dff))}
+        self._ws, self._ws_wide = {}, None
         self._ws_i = {"v": 0, "l": 0}
+        self._red_gens = {"v": set(), "l": set()}      # generations with column-sum partials not yet combined
+        self._gen_guard = {"v": {}, "l": {}}           # generation -> event after the companion-stream launch that read / combined it
+        self._guard_ring, self._guard_next = {"v": [], "l": []}, {"v": 0, "l": 0}
         self._deferred = False
         # The language stream (B*20 rows) fills less than half the chip per kernel; its layers are independent of the
         # visual stream inside the L/R stacks and between two cross-attention blocks, so they run on a second HIP stream.
@@ -783,18 +788,36 @@ class Engine:
     def f32(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
-    _WS_REGIONS = 10
+    _WS_REGIONS = 16
+
+    def _ws_region(self, t, g, i):
+        key = (t, g, i)
+        if key not in self._ws:
+            self._ws[key] = self.f32(self._ws_len[t])
+        return self._ws[key]
 
     @property
     def ws(self):
         """workspace of the next two-stage column reduction on the current stream (a fresh region while deferred)."""
         t = self._tag
         if not self._deferred:
-            return self._ws[t][:self._ws_len[t]]
+            return self._ws_region(t, 0, 0)
         i = self._ws_i[t]
-        assert i < self._WS_REGIONS, "too many column reductions between two flush_reductions()"
+        assert i < self._WS_REGIONS, "too many column reductions in one scratch generation"
         self._ws_i[t] = i + 1
-        return self._ws[t][i * self._ws_len[t]:(i + 1) * self._ws_len[t]]
+        self._red_gens[t].add(self._gen[t])
+        return self._ws_region(t, self._gen[t], i)
+
+    def ws_wide(self, name, N):
+        """workspace of a column sum wider than dff (the 10k-codebook head's, the MLM decoder's, the answer head's): one per user,
+        one producer per step each, combined before the next step's producer runs"""
+        if self._ws_wide is None:
+            self._ws_wide = {}
+        if name not in self._ws_wide:
+            self._ws_wide[name] = self.f32(self.ops.workspace_floats(N))
+        if self._deferred:
+            self._red_gens[self._tag].add(self._gen[self._tag])
+        return self._ws_wide[name]
 
     def defer_reductions(self, on):
         """backward of a training step: second stages of the column reductions are combined per layer (one launch)."""
@@ -808,9 +831,17 @@ class Engine:
             self.ops.set_deferred_reduce(1 if on else 0)
 
     def flush_reductions(self):
+        """combine everything pending from the current stream, on the current stream (in order behind the producers)"""
         if self._deferred:
             self.ops.flush_reductions()
-            self._ws_i[self._tag] = 0
+            self._red_gens[self._tag].clear()
+
+    def _flush_if_reporting(self):
+        """per-layer combine on the CURRENT stream -- only when somebody is told that the layer's gradients are final (gradient
+        exchange).  Otherwise the pending combines ride on the weight-gradient companion stream with the next grouped launch
+        (wgrad_flush), off the dX dependency chain; the end of the backward combines what is left."""
+        if self.grad_ready is not None or self._dw is None or self.side is None:
+            self.flush_reductions()
 
     class _LangStream:
         def __init__(self, eng):
@@ -857,7 +888,7 @@ class Engine:
     def wgrad_defer(self, dY, X, dW, M, N, K, lda, ldb, ldc, once=True):
         """register dW[M,N] += dY[K,M]^T X[K,N]; launched with the block's other weight gradients by wgrad_flush().
         once: this tensor gets no other gradient contribution in the step (False: the MLM decoder tied to the word embeddings)."""
-        self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc, bool(once and self.dw_overwrite)))
+        self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc, bool(once and self.dw_overwrite), self._gen[self._tag]))
         self._pending_block[self._tag] = getattr(self.ops, "block", "")
 
     def _note_overwritten(self, dW, M, N, ldc):
@@ -867,6 +898,28 @@ class Engine:
                 self.overwritten.add((off, off + M * N))
 
     PAIR_LAYERS = int(os.environ.get("XL_WGRAD_PAIR", "2"))          # layers per weight-gradient launch (1: every layer its own)
+    # Backward scratch generations.  The weight-gradient launches read a layer's scratch (dz, dqkv, dpre ...) from the companion
+    # stream long after the dX chain has moved on, so the chain writes every layer's scratch into the NEXT of NGEN buffer sets and,
+    # before it reuses a set, waits for the launch that read it (an event per launch, _gen_guard) -- NGEN layers later, when that
+    # launch is long done.  With two sets (rounds 1-3) the chain waited for every grouped launch at the start of the very next
+    # block: 0.37 ms of weight gradients on 216 CUs with nothing else running, then the chain's LayerNorm / attention kernels with
+    # the matrix units idle.  8 sets cost ~6 GB of the 288.
+    NGEN = max(2, int(os.environ.get("XL_SCRATCH_GENS", "8")))
+
+    def _advance_gen(self, tag):
+        g = (self._gen[tag] + 1) % self.NGEN
+        if g in self._red_gens[tag]:            # its column-sum partials were never combined (no launch since): do it now, in order
+            self.flush_reductions()
+        self._gen[tag] = g
+        self._ws_i[tag] = 0
+
+    def _guard_event(self, tag):
+        ring = self._guard_ring[tag]
+        if len(ring) < 2 * self.NGEN:
+            ring.append(self.ops.new_event())
+            return ring[-1]
+        self._guard_next[tag] += 1
+        return ring[self._guard_next[tag] % len(ring)]
 
     def wgrad_flush(self, pair=False, force=False):
         """queue the registered weight gradients as ONE grouped launch on the companion stream of the current stream
@@ -875,16 +928,16 @@ class Engine:
         pair=True (self-attention + FFN layers): the layer's four problems are HELD and launched together with the next
         layer's -- 216 output tiles of 256x256 fill the chip without a K split, so every tile has one writer and the launch needs
         no atomics (two launches with a K split of 2 and a pass of fp32 atomics each: 2 x 247 us per visual layer pair, one
-        launch: ~390 us).  The held problems read backward scratch of their layer, so the scratch alternates between two sets
-        (tmp(): generation); force=True launches whatever is held (end of a stream's backward)."""
+        launch: ~390 us).  Every call closes a scratch generation (NGEN above); force=True launches whatever is held (end of a
+        stream's backward)."""
         tag = self._tag
         if pair:
             self._held[tag] += self._pending[tag]
             self._pending[tag] = []
             self._held_layers[tag] += 0 if force else 1
-            if not force:
-                self._gen[tag] ^= 1             # the next layer writes the other scratch set
             if not self._held[tag] or (self._held_layers[tag] < self.PAIR_LAYERS and not force):
+                if not force:
+                    self._advance_gen(tag)      # the next layer writes the next scratch set
                 return
             probs, self._held[tag], self._held_layers[tag] = self._held[tag], [], 0
         else:
@@ -893,6 +946,7 @@ class Engine:
             return
         self.ops.block = self._pending_block[tag]
         dw = self._dw.get(tag) if (self._dw is not None and self.side is not None) else None
+        ride = dw is not None and self._deferred and self.grad_ready is None
         for i in range(0, len(probs), 8):       # (xl_gemm_wgrad_group takes up to 8 problems)
             chunk = [pr[:9] for pr in probs[i:i + 8]]
             mask = sum(1 << j for j, pr in enumerate(probs[i:i + 8]) if pr[9])
@@ -903,21 +957,45 @@ class Engine:
             if dw is None:
                 self.ops.gemm_wgrad_group(chunk, **kw)
                 continue
-            self.ops.stream_fork(torch.cuda.current_stream(), dw)
+            cur = torch.cuda.current_stream()
+            self.ops.stream_fork(cur, dw)
             with torch.cuda.stream(dw):
                 self.ops.gemm_wgrad_group(chunk, **kw)
+                if ride and i + 8 >= len(probs):
+                    # the column-sum combines pending on this stream ride behind the weight gradients, off the dX chain
+                    self.ops.flush_reductions_on(cur)
             self._dw_busy[tag] = True
+        if dw is not None:
+            ev = self._guard_event(tag)
+            self.ops.event_record(ev, dw)
+            gens = {pr[10] for pr in probs}
+            if ride:
+                gens |= self._red_gens[tag]
+                self._red_gens[tag].clear()
+            for g in gens:
+                self._gen_guard[tag][g] = ev
+        if not force:
+            self._advance_gen(tag)
 
     def wgrad_sync(self):
-        """current stream waits for the weight-gradient GEMMs queued so far by this stream (nothing to wait for when none
-        was queued since the last wait: an event of a stream that has not joined a stream capture must not be waited on)."""
-        if self._dw_busy[self._tag]:
-            self.ops.stream_fork(self._dw[self._tag], torch.cuda.current_stream())
-            self._dw_busy[self._tag] = False
+        """the current stream is about to write the current scratch generation: wait for the companion-stream launch that read it
+        (weight gradients) or combined its column-sum partials, if there was one since the generation was last waited for."""
+        tag = self._tag
+        ev = self._gen_guard[tag].pop(self._gen[tag], None)
+        if ev is not None:
+            self.ops.stream_wait(ev, torch.cuda.current_stream())
+
+    def wgrad_sync_all(self):
+        """current stream waits for EVERYTHING queued so far on its companion stream (gradients final: reports, end of backward)"""
+        tag = self._tag
+        if self._dw_busy[tag]:
+            self.ops.stream_fork(self._dw[tag], torch.cuda.current_stream())
+            self._dw_busy[tag] = False
+        self._gen_guard[tag].clear()
 
     def tmp(self, name, M, N):
-        """backward scratch, shared by all blocks of one stream (sized for the largest user); two sets per stream, alternating
-        with the layers whose weight gradients are held for a paired launch (wgrad_flush)."""
+        """backward scratch, shared by all blocks of one stream (sized for the largest user); NGEN sets per stream, one per scratch
+        generation (wgrad_flush)."""
         key = (name, N, self._tag, self._gen[self._tag])
         if key not in self._tmp:
             self._tmp[key] = torch.zeros(self.MXc, N, dtype=self.cdtype, device=self.dev)
@@ -986,8 +1064,10 @@ class Engine:
 
     def _ready_upto(self, hi):
         assert not self._pending["v"] and not self._pending["l"], "weight gradients registered but never flushed"
+        if self.grad_ready is None and self._dw is not None and self.side is not None:
+            return                  # nobody to report to: no combine, no wait here (see _flush_if_reporting)
         self.flush_reductions()
-        self.wgrad_sync()
+        self.wgrad_sync_all()
         if self.grad_ready is not None and not self._held["v"] and not self._held["l"]:   # (a held layer's weight gradients are
             self._report("v", hi)                                    #  not final yet: the next report covers its range)
 
@@ -1004,7 +1084,7 @@ class Engine:
         if self.grad_ready is None or (self._held["l"] and not flush):
             return
         assert not self._held["l"]
-        self.wgrad_sync()
+        self.wgrad_sync_all()
         self._report("l", hi, flush)
 
     def sync_compute_weights(self):
@@ -1621,6 +1701,8 @@ class Engine:
         self.defer_reductions(True)
         assert not self._held["v"] and not self._held["l"]
         self._gen = {"v": 0, "l": 0}
+        self._ws_i = {"v": 0, "l": 0}
+        self._gen_guard = {"v": {}, "l": {}}    # (the previous backward ended with wgrad_sync_all on both streams)
         self.grad_is_zero = False
         self._lane_lo = {"v": 0, "l": self.store.language_range()[0]}
 
@@ -1631,7 +1713,7 @@ class Engine:
         ops.block = "head"
         M = self._head_rows()
         hd = self.hd
-        ops.colsum(self.dlogits, hd["bc"][1], M, self.Kp, self.Kp, ws=self.ws)      # pad columns are zero; the bias unit is padded
+        ops.colsum(self.dlogits, hd["bc"][1], M, self.Kp, self.Kp, ws=self.ws_wide("codebook", self.Kp))      # pad columns are zero; the bias unit is padded
         dfeat = self.tmp("dfeat", MV, F)
         if self.with_feat_loss:
             ops.gemm(self.dlogits, self.store.centroids_c, dfeat, None, self.dfeat, None, M, F, K, self.Kp, F, F, ldr=F,
@@ -1690,8 +1772,9 @@ class Engine:
                     blk["sa_l"].bwd(L_(GB), L_(GA))
                     if i == 0:                  # the language side of the cross layers is reported by the main stream (below):
                         self.wgrad_flush(pair=True, force=True)      # nothing of it may stay held into the language stack
-                    self.flush_reductions()
-                    self.wgrad_sync()
+                    if self.grad_ready is not None:     # (the main stream reports this layer, language side included)
+                        self._flush_if_reporting()
+                        self.wgrad_sync_all()
             if blk["vis_on"]:
                 blk["ffn_v"].bwd(V_(GA), V_(GB))
                 blk["sa_v"].bwd(V_(GB), V_(GA))
@@ -1706,7 +1789,7 @@ class Engine:
                 sa, ffn = self.lang_layers[i]
                 ffn.bwd(L_(GA), L_(GB))
                 sa.bwd(L_(GB), L_(GA))
-                self.flush_reductions()
+                self._flush_if_reporting()
                 self._ready_lang(st.range_of(f"bert.encoder.layer.{i}.")[1])
             self.wgrad_flush(pair=True, force=True)      # an odd layer left over
             e = "bert.embeddings"
@@ -1729,7 +1812,7 @@ class Engine:
                           self.B, self.L, d)
             self.flush_reductions()
             self._ready_lang(st.language_range()[1], flush=True)
-            self.wgrad_sync()
+            self.wgrad_sync_all()
         # ---- relational (visual) stack
         for i in reversed(range(cfg.r_layers)):
             sa, ffn = self.vis_layers[i]
@@ -1763,7 +1846,7 @@ class Engine:
             ops.gemm(self.mf_tmp_c, st.cview(v + ".visn_fc.weight"), st.gview("mask_feat"), None, None, None, 1, self.F, d,
                      d, self.F, self.F, a_kmajor=1, b_kmajor=0, out_f32=True, accumulate=1)
         self.flush_reductions()
-        self.wgrad_sync()
+        self.wgrad_sync_all()
         self.join()                          # language-stack gradients are final from here on
         self.defer_reductions(False)
         if self.grad_ready is not None:

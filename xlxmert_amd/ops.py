@@ -165,6 +165,10 @@ class HipOps:
     def flush_reductions(self):
         self._call("xl_flush_reductions", self._stream())
 
+    def flush_reductions_on(self, producer_stream):
+        """combine everything pending from `producer_stream` with a launch on the CURRENT stream (ordered after the producers by the caller)"""
+        self._call("xl_flush_reductions_on", producer_stream.cuda_stream, self._stream())
+
     # -- dense contractions
     def gemm(self, A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
              out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0, colsum=None, ws=None):
