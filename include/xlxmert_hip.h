@@ -145,6 +145,9 @@ int xl_gemm(const void* A, const void* B, void* C, const float* bias,
 int  xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const* C,
                          const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
                          int count, int overwrite_mask, int dtype, void* stream);
+/* the K split a grouped launch of these problems takes (1: every output tile has one writer -- what overwrite_mask wants: a split
+ * launch honours the mask by clearing C first, which costs more than the optimizer pass's clear it replaces) */
+int  xl_gemm_wgrad_group_splitk(const int* M, const int* N, const int* K, int count);
 /* overwrite_mask: bit i set -> C_i = A_i^T B_i instead of C_i += ... (a weight with exactly ONE gradient contribution per
  * step: the training step then neither clears nor re-reads 4 bytes per parameter -- the clear moves out of xl_adamw, decay_flags
  * bit 2, and the epilogue's read-modify-write becomes a plain store).  The semantics hold whatever strategy the launch takes: a

@@ -118,6 +118,9 @@ class FakeOps:
     def flush_reductions_on(self, producer_stream):
         pass
 
+    def wgrad_group_one_writer(self, problems):
+        return True
+
     def gemm_wgrad_group(self, problems, overwrite_mask=0):
         for i, (A, B, C, M, N, K, lda, ldb, ldc) in enumerate(problems):
             self.gemm(A, B, C, None, None, None, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, out_f32=True,

@@ -548,6 +548,19 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     return XL_OK;
 }
 
+extern "C" int xl_gemm_wgrad_group_splitk(const int* M, const int* N, const int* K, int count) {
+    if (M == nullptr || N == nullptr || K == nullptr || count < 1 || count > 8) return 0;
+    static const int group_max_wgs = env_int("XL_GEMM_GROUP_MAX_WGS", 256);
+    long total = 0;
+    int max_split = 1 << 20;
+    for (int i = 0; i < count; ++i) {
+        total += (long)((M[i] + 255) / 256) * ((N[i] + 255) / 256);
+        max_split = std::min(max_split, std::max(1, K[i] / 512));
+    }
+    const int splitk = total >= group_max_wgs ? 1 : (int)std::min<long>(group_max_wgs / total, max_split);
+    return std::max(splitk, 1);
+}
+
 extern "C" int xl_gemm_wgrad_group(const void* const* A, const void* const* B, void* const* C,
                                    const int* M, const int* N, const int* K, const int* lda, const int* ldb, const int* ldc,
                                    int count, int overwrite_mask, int dtype, void* stream) {

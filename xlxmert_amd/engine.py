@@ -950,8 +950,10 @@ class Engine:
         for i in range(0, len(probs), 8):       # (xl_gemm_wgrad_group takes up to 8 problems)
             chunk = [pr[:9] for pr in probs[i:i + 8]]
             mask = sum(1 << j for j, pr in enumerate(probs[i:i + 8]) if pr[9])
-            for pr in probs[i:i + 8]:
-                if pr[9]:
+            if mask and not self.ops.wgrad_group_one_writer(chunk):
+                mask = 0                        # a K-split launch would have to clear C first: leave that to the optimizer pass
+            for j, pr in enumerate(probs[i:i + 8]):
+                if (mask >> j) & 1:
                     self._note_overwritten(pr[2], pr[3], pr[4], pr[8])
             kw = {"overwrite_mask": mask} if mask else {}
             if dw is None:
@@ -1818,7 +1820,10 @@ class Engine:
             sa, ffn = self.vis_layers[i]
             ffn.bwd(V_(GA), V_(GB))
             sa.bwd(V_(GB), V_(GA))
-            if i == 0:
+            # the last (odd) layer's weight gradients: at once when its range is reported to a gradient exchange; otherwise behind
+            # the feature encoder's backward below -- launched first they take 216 CUs for 0.2-0.4 ms and the encoder's last three
+            # kernels on the chain crawl beside them (visn_ln_bwd: 55 us alone, 333 us measured in the step, profiles/r04a)
+            if i == 0 and self.grad_ready is not None:
                 self.wgrad_flush(pair=True, force=True)
             self._ready(f"bert.encoder.r_layers.{i}.")
         # ---- visual feature encoder (HF:468-476) + codebook input
@@ -1833,10 +1838,10 @@ class Engine:
                         st.gview(v + ".box_layer_norm.weight"), st.gview(v + ".box_layer_norm.bias"),
                         st.gview(v + ".box_fc.weight"), st.gview(v + ".box_fc.bias"), st.gview(v + ".visn_fc.bias"),
                         MV, d, self.P, ws=self.ws)
+        if self.grad_ready is None:
+            self.wgrad_flush(pair=True, force=True)          # (the visual stack's last held layer: see above)
         ops.gemm(dxv, self.feats, st.gview(v + ".visn_fc.weight"), None, None, None, d, self.F, MV, d, self.F, self.F,
-                 a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=0 if self.dw_overwrite else 1)
-        if self.dw_overwrite:
-            self._note_overwritten(st.gview(v + ".visn_fc.weight"), d, self.F, self.F)
+                 a_kmajor=0, b_kmajor=0, out_f32=True, accumulate=1)      # (a K-split launch: into the cleared buffer, like every split one)
         if self.use_codebook and self.has_vmask:
             # d(mask_feat) = (sum over masked rows of d(xv)) W_visn   (ref lxrt/modeling.py:190-193: mask_feat is a Parameter)
             ops.zero(self.mf_tmp)

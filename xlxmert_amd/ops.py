@@ -189,6 +189,19 @@ class HipOps:
         ints = [ia(*[int(v) for v in cols[j]]) for j in range(3, 9)]
         self._call("xl_gemm_wgrad_group", *ptrs, *ints, n, int(overwrite_mask), self.dt, self._stream())
 
+    def wgrad_group_one_writer(self, problems):
+        """True when the grouped launch of `problems` gives every output tile one writer (no K split) and every tile is whole:
+        the launch then honours an overwrite_mask with plain stores (otherwise by clearing C first)."""
+        import ctypes
+        n = len(problems)
+        ia = ctypes.c_int * n
+        M, N, K = (ia(*[int(pr[j]) for pr in problems]) for j in (3, 4, 5))
+        if self.dt != XL_BF16:
+            return True                      # (fp32: one plain xl_gemm per problem, never split)
+        one = int(self.lib.raw("xl_gemm_wgrad_group_splitk")(ctypes.cast(M, ctypes.c_void_p), ctypes.cast(N, ctypes.c_void_p),
+                                                             ctypes.cast(K, ctypes.c_void_p), n)) == 1
+        return one and all(pr[3] % 256 == 0 and pr[4] % 256 == 0 for pr in problems)
+
     def set_gemm_wgrad_slabs(self, on):
         """weight-gradient K splits through the slab workspace (fixed summation order) instead of fp32 atomics."""
         self._call("xl_set_gemm_wgrad_slabs", int(on))
