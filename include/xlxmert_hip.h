@@ -268,7 +268,9 @@ int xl_sampler_ar_update(const float* prob, const int* pred_ids, void* visited, 
                          int B, int V, int fixed_pos, void* stream);
 
 /* ---------------------------------------------------------------- attention core (HF:247-263)
- * per (b,h): O = softmax(Q K^T * scale, keys with key_mask==0 excluded) V ; nq,nk <= 64.
+ * per (b,h): O = softmax(Q K^T * scale, keys with key_mask==0 excluded) V ; nq, nk <= 64 on the on-chip kernels (the path's
+ * shapes: 20 text tokens, 8x8 grid); 65..512 (--max_text_length up to the position table, ref param.py:140) on plain long-sequence
+ * kernels (fp32 arithmetic, one lane per query / key; xl_sdpa_bwd then needs `workspace`).
  * q/k/v/o are [B, n, H*dh]-shaped views with row strides ldq/ldk/ldv/ldo (elements); head h
  * occupies columns [h*dh, (h+1)*dh).  key_mask: uint8 [B,nk] or NULL.  lse: fp32 [B,H,nq]
  * (log-sum-exp of the scaled scores) saved for backward.  Probability dropout (HF:258):

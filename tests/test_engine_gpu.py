@@ -713,6 +713,40 @@ def test_batch_uploader_slot_is_released_after_the_labels_are_copied():
         assert abs(got[i].item() - ref[i].item()) < 1e-5, (i, got[i].item(), [r.item() for r in ref])
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 6e-2)])
+def test_text_longer_than_64_tokens_step_matches_oracle(dtype, tol):
+    """--max_text_length above 64 (ref param.py:140): one step at L = 72 (language self-attention 72 x 72, cross-attention 72 x 16 and
+    16 x 72 on the long-sequence attention kernels, packed rows) against the oracle: loss and every gradient (fp32 1e-4; bf16: relative
+    L2 per tensor)."""
+    from test_trainer_cpu import TINY, oracle_cfg, oracle_grads
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig(**dict(TINY, max_position_embeddings=128))
+    B, L, grid = 2, 72, 4
+    sd = O.make_state_dict(oracle_cfg(cfg), 3)
+    store = ParamStore(cfg, "cuda", dtype, task="vis_mask")
+    store.load_named(sd)
+    tr = PretrainStep(cfg, B, L, grid * grid, dtype=dtype, device="cuda", store=store, total_steps=10, lr=1e-2, visual_losses="obj,feat")
+    for seed, ragged in ((94, False), (95, True)):
+        batch = synthetic_batch(cfg, B, L, grid, seed=seed, ragged=ragged)
+        losses = tr.engine  # noqa: F841
+        tr.engine.set_inputs(*(batch[k].cuda() for k in ("input_ids", "attention_mask", "token_type_ids", "visual_pos")),
+                             cluster_ids=batch["cluster_ids"].cuda(), vis_mask=batch["vis_mask"].cuda(), obj_labels=batch["obj_labels"].cuda())
+        out = tr.engine.vis_mask_forward_backward(True)
+        torch.cuda.synchronize()
+        grads, ref = oracle_grads(cfg, sd, batch)
+        assert abs(out[0].item() - ref["obj_loss"].item()) < (3e-5 if dtype == torch.float32 else 3e-2)
+        for k, g in grads.items():
+            if k == "obj_predict_head.out_cluster.weight":
+                continue
+            got = store.gview(k).cpu().double()
+            if dtype == torch.float32:
+                assert (got - g.double()).abs().max().item() < tol * max(1.0, g.abs().max().item()), k
+            else:
+                assert (got - g.double()).norm().item() <= tol * max(g.double().norm().item(), 1e-3), k
+
+
 def test_word_mask_full_size_step_properties_bf16():
     """full encoder, 30522-way tied decoder at bs 64: loss ~ ln(30522) at init, finite gradients, the word-embedding
     gradient has a non-zero row 0 (decoder side; the embedding scatter skips padding_idx 0)."""

@@ -984,6 +984,69 @@ def test_sdpa_dropout_fwd_bwd(nq, nk, dh, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nq,nk,dh,packed,masked", [(100, 100, 64, True, False), (65, 64, 64, False, True), (64, 130, 16, False, True),
+                                                     (200, 20, 64, True, False), (512, 70, 32, False, False)])
+def test_sdpa_long_sequences(nq, nk, dh, packed, masked, dtype):
+    """--max_text_length above 64 (ref param.py:140): xl_sdpa_fwd / _bwd / xl_attn_probs take nq, nk up to 512 on the plain
+    long-sequence kernels (online softmax forward, two-launch backward through a delta scratch in the caller's workspace).  Same
+    conventions as the on-chip kernels -- dropout counters, log-sum-exp layout, key masks, packed rows with zeroed pad rows, bias
+    gradients -- against the host restatement."""
+    g = torch.Generator().manual_seed(nq * 7 + nk + dh)
+    B, H = 3, 2
+    d = H * dh
+    scale, pd, seed = 1.0 / math.sqrt(dh), 0.1, 991
+    qoff = koff = None
+    q_rows, k_rows, q_pad, k_pad = B * nq, B * nk, 0, 0
+    if packed:                                       # packed query side (and key side when self-attention-shaped)
+        lens = torch.tensor([1, nq, max(1, nq // 3)])
+        qoff = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(torch.int32)
+        q_pad = (int(qoff[-1]) + 31) // 32 * 32 + 32
+        q_rows = q_pad
+        if nq == nk:
+            koff, k_pad, k_rows = qoff, q_pad, q_pad
+    q = rnd(g, q_rows, d, dtype=dtype)
+    k, v = (q, rnd(g, k_rows, d, dtype=dtype)) if (packed and nq == nk) else (rnd(g, k_rows, d, dtype=dtype), rnd(g, k_rows, d, dtype=dtype))
+    km = None
+    if masked:
+        km = torch.ones(B, nk, dtype=torch.uint8)
+        km[1, nk // 2:] = 0
+        km[2, 1:] = 0
+    kw = dict(p_drop=pd, seed=seed, q_off=qoff, k_off=koff, q_pad=q_pad, k_pad=k_pad)
+    o, lse = torch.full((q_rows, d), 7.0, dtype=dtype), torch.zeros(B * H * nq)
+    cpu, gpu = run_both(dtype, "sdpa_fwd", [q, k, v, km, o, lse, B, H, nq, nk, dh, d, d, d, d, scale], kw)
+    close(gpu[4], cpu[4], dtype, f"long sdpa o {nq}x{nk}")
+    valid = torch.ones(B, H, nq, dtype=torch.bool)      # (queries beyond a packed example's length do not exist: their lse is not written)
+    if qoff is not None:
+        valid = (torch.arange(nq)[None, :] < (qoff[1:] - qoff[:-1])[:, None])[:, None, :].expand(B, H, nq)
+    close(gpu[5].view(B, H, nq)[valid], cpu[5].view(B, H, nq)[valid], torch.float32, "long sdpa lse", f32_tol=1e-5 if dtype == torch.float32 else 2e-2)
+    dout = rnd(g, q_rows, d, dtype=dtype)
+    dq, dk, dv = (torch.full((r, d), 3.0, dtype=dtype) for r in (q_rows, k_rows, k_rows))
+    cbg = torch.zeros(3 * d)
+    FakeOps(dtype).sdpa_bwd(q, k, v, km, dout, cpu[5], dq.clone(), dk.clone(), dv.clone(), B, H, nq, nk, dh, d, d, d, d, d, d, d, scale,
+                            bias_grad=cbg, **kw)
+    cq, ck, cv = dq.clone(), dk.clone(), dv.clone()
+    FakeOps(dtype).sdpa_bwd(q, k, v, km, dout, cpu[5], cq, ck, cv, B, H, nq, nk, dh, d, d, d, d, d, d, d, scale, **kw)
+    ops = hip(dtype)
+    gkw = dict(kw, q_off=qoff.cuda() if qoff is not None else None, k_off=koff.cuda() if koff is not None else None)
+    gq, gk, gv = dq.cuda(), dk.cuda(), dv.cuda()
+    gbg, gws = torch.zeros(3 * d, device="cuda"), torch.zeros(ops.workspace_floats(d), device="cuda")
+    qg = q.cuda()
+    kg = qg if k is q else k.cuda()
+    ops.sdpa_bwd(qg, kg, v.cuda(), km.cuda() if km is not None else None, dout.cuda(), cpu[5].cuda(), gq, gk, gv, B, H, nq, nk, dh,
+                 d, d, d, d, d, d, d, scale, bias_grad=gbg, ws=gws, **gkw)
+    torch.cuda.synchronize()
+    for got, want, nm in ((gq, cq, "dq"), (gk, ck, "dk"), (gv, cv, "dv")):
+        close(got.cpu(), want, dtype, f"long sdpa {nm} {nq}x{nk}", bf16_tol=2.5e-2)
+    close(gbg.cpu(), cbg, torch.float32, "long sdpa bias grads", f32_tol=2e-4 if dtype == torch.float32 else 4e-2)
+    probs = torch.zeros(B, H, nq, nk)
+    cpu3, gpu3 = run_both(dtype, "attn_probs", [q, k, km, cpu[5], probs, B, H, nq, nk, dh, d, d, scale],
+                          dict(p_drop=pd, seed=seed, q_off=qoff, k_off=koff))
+    close(gpu3[4], cpu3[4], torch.float32, "long attention probabilities", f32_tol=1e-5 if dtype == torch.float32 else 2e-2)
+    with pytest.raises(Exception):                   # beyond 512: rejected with a message
+        ops.sdpa_fwd(qg, kg, v.cuda(), None, o.cuda(), lse.cuda(), B, H, 513, nk, dh, d, d, d, d, scale)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_layernorm_bwd_fused_dropout(dtype):
     """LN backward that also emits the dropout-masked gradient of the dense layer and its bias gradient."""
     g = torch.Generator().manual_seed(41)

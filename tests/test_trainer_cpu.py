@@ -78,6 +78,23 @@ def test_two_steps_match_closed_form(monkeypatch, head_pad):
     assert torch.equal(tr.store.view("bert.pooler.dense.weight"), sd["bert.pooler.dense.weight"])
 
 
+def test_text_longer_than_64_tokens_step_matches_oracle():
+    """--max_text_length above 64 (ref param.py:140): the engine's buffers, packed rows and attention calls at L = 72 (language
+    self-attention 72 x 72, cross-attention 72 x 16 and 16 x 72) -- one step against the oracle's gradients (host restatement of the
+    kernels here; the long-sequence kernels themselves against the same restatement in tests/test_hip_kernels.py)."""
+    cfg = XLxmertConfig(**dict(TINY, max_position_embeddings=128))
+    B, L, grid = 2, 72, 4
+    tr, sd = make_step(cfg, B, L, grid, lr=1e-2)
+    batch = synthetic_batch(cfg, B, L, grid, seed=94, ragged=False)          # every sentence 72 tokens long
+    assert int(batch["attention_mask"].sum(1).min()) == 72
+    losses = tr.step(batch)
+    grads, out = oracle_grads(cfg, sd, batch)
+    assert abs(losses[0].item() - out["obj_loss"].item()) < 3e-5
+    for k, g in grads.items():
+        if k != "obj_predict_head.out_cluster.weight":
+            assert (tr.store.gview(k) - g).abs().max().item() < 3e-5, k
+
+
 def test_visual_losses_default_is_obj_only_and_feat_labels_are_used():
     """--visualLosses obj (scripts/pretrain.bash:15) is the default: no feature loss, gradients = those of obj_loss alone.
     With "obj,feat" and batch["feat_labels"] (the real grid features, ref lxmert_pretrain.py:177-179) the SmoothL1 term

@@ -150,6 +150,139 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
     }
 }
 
+// ================================================================== long sequences (nq or nk in 65..512)
+// --max_text_length above 64 (ref param.py:140; the position table has 512 rows): not the benchmarked shapes, so these are the
+// plain kernels -- one lane per query (resp. key), fp32 arithmetic, the other side streamed from global memory -- built for
+// correctness at any length up to MAXLONG, with the same conventions as the kernels above (dropout counters, log-sum-exp layout,
+// packed rows, zeroed pad rows).  Forward: online softmax (running max / sum, the accumulator rescaled), dropout applied to the
+// un-normalised terms (linear).  Backward in two launches: per query, delta_i = sum_j p_ij dp_ij and dQ_i (delta also goes to a
+// caller-owned fp32 scratch [B, H, nq]); per key, dK_j and dV_j over all queries with the saved delta -- no atomics.
+constexpr int MAXLONG = 512;
+
+template <typename T>
+__global__ __launch_bounds__(64) void sdpa_fwd_long(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                    const uint8_t* __restrict__ key_mask, T* __restrict__ o, float* __restrict__ lse,
+                                                    int H, int nq, int nk, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                                    float p_drop, float inv_keep, uint64_t seed, const uint64_t* __restrict__ step_seed,
+                                                    VarLen vl) {
+    seed = with_step_seed(seed, step_seed);
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int qi = blockIdx.y * 64 + threadIdx.x;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    if (blockIdx.y == 0) zero_pad_rows<T>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, o, ldo, h * dh, dh, threadIdx.x, 64);
+    if (qi >= nq) return;
+    const T* qr = q + (size_t)(q0 + qi) * ldq + h * dh;
+    float qv[MAXN], acc[MAXN];
+    for (int d = 0; d < dh; ++d) { qv[d] = Elem<T>::ld(qr + d); acc[d] = 0.f; }
+    float mx = -INFINITY, sum = 0.f;
+    for (int j = 0; j < nk; ++j) {
+        if (key_mask && !key_mask[b * nk_cap + j]) continue;
+        const T* kr = k + (size_t)(k0 + j) * ldk + h * dh;
+        float s0 = 0.f;
+        for (int d = 0; d < dh; ++d) s0 = fmaf(qv[d], Elem<T>::ld(kr + d), s0);
+        s0 *= scale;
+        const float nm = fmaxf(mx, s0);
+        const float corr = mx == -INFINITY ? 0.f : expf(mx - nm), e = expf(s0 - nm);
+        sum = sum * corr + e;
+        float pe = e;
+        if (p_drop > 0.f) pe *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)j, p_drop, inv_keep);
+        const T* vr = v + (size_t)(k0 + j) * ldv + h * dh;
+        for (int d = 0; d < dh; ++d) acc[d] = fmaf(pe, Elem<T>::ld(vr + d), acc[d] * corr);
+        mx = nm;
+    }
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    T* orow = o + (size_t)(q0 + qi) * ldo + h * dh;
+    for (int d = 0; d < dh; ++d) Elem<T>::st(orow + d, acc[d] * inv);
+    lse[(size_t)bh * nq_cap + qi] = (mx == -INFINITY ? 0.f : mx) + logf(sum);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void sdpa_bwd_long_q(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                      const uint8_t* __restrict__ key_mask, const T* __restrict__ dout,
+                                                      const float* __restrict__ lse, T* __restrict__ dq, float* __restrict__ delta_out,
+                                                      int H, int nq, int nk, int dh, int ldq, int ldk, int ldv, int ldo, int lddq,
+                                                      float scale, float p_drop, float inv_keep, uint64_t seed,
+                                                      const uint64_t* __restrict__ step_seed, VarLen vl) {
+    seed = with_step_seed(seed, step_seed);
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int qi = blockIdx.y * 64 + threadIdx.x;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    if (blockIdx.y == 0) zero_pad_rows<T>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, dq, lddq, h * dh, dh, threadIdx.x, 64);
+    if (qi >= nq) return;
+    const T* qr = q + (size_t)(q0 + qi) * ldq + h * dh;
+    const T* dor = dout + (size_t)(q0 + qi) * ldo + h * dh;
+    float qv[MAXN], dov[MAXN], dqv[MAXN];
+    for (int d = 0; d < dh; ++d) { qv[d] = Elem<T>::ld(qr + d); dov[d] = Elem<T>::ld(dor + d); dqv[d] = 0.f; }
+    const float l = lse[(size_t)bh * nq_cap + qi];
+    float delta = 0.f;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int j = 0; j < nk; ++j) {
+            if (key_mask && !key_mask[b * nk_cap + j]) continue;
+            const T* kr = k + (size_t)(k0 + j) * ldk + h * dh;
+            const T* vr = v + (size_t)(k0 + j) * ldv + h * dh;
+            float s0 = 0.f, g = 0.f;
+            for (int d = 0; d < dh; ++d) { s0 = fmaf(qv[d], Elem<T>::ld(kr + d), s0); g = fmaf(dov[d], Elem<T>::ld(vr + d), g); }
+            const float pj = expf(s0 * scale - l);
+            if (p_drop > 0.f) g *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)j, p_drop, inv_keep);
+            if (pass == 0) delta += pj * g;
+            else {
+                const float ds = pj * (g - delta) * scale;
+                for (int d = 0; d < dh; ++d) dqv[d] = fmaf(ds, Elem<T>::ld(kr + d), dqv[d]);
+            }
+        }
+    T* dqr = dq + (size_t)(q0 + qi) * lddq + h * dh;
+    for (int d = 0; d < dh; ++d) Elem<T>::st(dqr + d, dqv[d]);
+    delta_out[(size_t)bh * nq_cap + qi] = delta;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void sdpa_bwd_long_k(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                      const uint8_t* __restrict__ key_mask, const T* __restrict__ dout,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta_in,
+                                                      T* __restrict__ dk, T* __restrict__ dv, int H, int nq, int nk, int dh,
+                                                      int ldq, int ldk, int ldv, int ldo, int lddk, int lddv, float scale,
+                                                      float p_drop, float inv_keep, uint64_t seed, const uint64_t* __restrict__ step_seed,
+                                                      VarLen vl) {
+    seed = with_step_seed(seed, step_seed);
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int kj = blockIdx.y * 64 + threadIdx.x;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    if (blockIdx.y == 0) {
+        zero_pad_rows<T>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dk, lddk, h * dh, dh, threadIdx.x, 64);
+        zero_pad_rows<T>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dv, lddv, h * dh, dh, threadIdx.x, 64);
+    }
+    if (kj >= nk) return;
+    const T* kr = k + (size_t)(k0 + kj) * ldk + h * dh;
+    const T* vr = v + (size_t)(k0 + kj) * ldv + h * dh;
+    float kv[MAXN], vv[MAXN], dkv[MAXN], dvv[MAXN];
+    for (int d = 0; d < dh; ++d) { kv[d] = Elem<T>::ld(kr + d); vv[d] = Elem<T>::ld(vr + d); dkv[d] = 0.f; dvv[d] = 0.f; }
+    const bool masked = key_mask && !key_mask[b * nk_cap + kj];
+    if (!masked)
+        for (int i = 0; i < nq; ++i) {
+            const T* qr = q + (size_t)(q0 + i) * ldq + h * dh;
+            const T* dor = dout + (size_t)(q0 + i) * ldo + h * dh;
+            float s0 = 0.f, g = 0.f;
+            for (int d = 0; d < dh; ++d) { s0 = fmaf(Elem<T>::ld(qr + d), kv[d], s0); g = fmaf(Elem<T>::ld(dor + d), vv[d], g); }
+            const float pj = expf(s0 * scale - lse[(size_t)bh * nq_cap + i]);
+            float msk = 1.f;
+            if (p_drop > 0.f) msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + i), (uint32_t)kj, p_drop, inv_keep);
+            const float ds = pj * (g * msk - delta_in[(size_t)bh * nq_cap + i]) * scale, pt = pj * msk;
+            for (int d = 0; d < dh; ++d) {
+                dkv[d] = fmaf(ds, Elem<T>::ld(qr + d), dkv[d]);
+                dvv[d] = fmaf(pt, Elem<T>::ld(dor + d), dvv[d]);
+            }
+        }
+    T* dkr = dk + (size_t)(k0 + kj) * lddk + h * dh;
+    T* dvr = dv + (size_t)(k0 + kj) * lddv + h * dh;
+    for (int d = 0; d < dh; ++d) { Elem<T>::st(dkr + d, dkv[d]); Elem<T>::st(dvr + d, dvv[d]); }
+}
+
 // attention probabilities of one layer, recomputed from the saved log-sum-exp (LxmertModel.forward(output_attentions=True),
 // HF:238-266 returns softmax(scores) AFTER its dropout): probs[b, h, q, key] fp32, dense [B, H, nq, nk] whatever the row
 // packing; rows of queries / columns of keys beyond a packed example's length and masked keys are zeros.  Not on the hot path.
@@ -161,7 +294,7 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const T* __restrict__ q,
                                                         const uint64_t* __restrict__ step_seed, VarLen vl) {
     seed = with_step_seed(seed, step_seed);
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int qi = threadIdx.x;
+    const int qi = blockIdx.y * 64 + threadIdx.x;
     const int nq_cap = nq, nk_cap = nk;
     if (qi >= nq_cap) return;
     const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
@@ -682,8 +815,8 @@ static bool mfma_eligible(const SdpaArgs& a, bool bwd) {
 
 static int check_common(const SdpaArgs& a, int dtype, const char* fn) {
     XL_CHECK_ARG(dtype == XL_F32 || dtype == XL_BF16, XL_ERR_BAD_DTYPE, "%s: bad dtype %d", fn, dtype);
-    XL_CHECK_ARG(a.B > 0 && a.H > 0 && a.nq > 0 && a.nk > 0 && a.nq <= MAXN && a.nk <= MAXN, XL_ERR_BAD_SHAPE,
-                 "%s: need 1 <= nq,nk <= %d (got %d,%d)", fn, MAXN, a.nq, a.nk);
+    XL_CHECK_ARG(a.B > 0 && a.H > 0 && a.nq > 0 && a.nk > 0 && a.nq <= MAXLONG && a.nk <= MAXLONG, XL_ERR_BAD_SHAPE,
+                 "%s: need 1 <= nq,nk <= %d (got %d,%d)", fn, MAXLONG, a.nq, a.nk);
     XL_CHECK_ARG(a.dh > 0 && a.dh <= MAXN, XL_ERR_BAD_SHAPE, "%s: head size %d not in 1..%d", fn, a.dh, MAXN);
     XL_CHECK_ARG(a.p_drop >= 0.f && a.p_drop < 1.f, XL_ERR_BAD_ARG, "%s: p_drop %f", fn, a.p_drop);
     return XL_OK;
@@ -707,6 +840,17 @@ extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const ui
     if (rc) return rc;
     XL_CHECK_ARG(q && k && v && o && lse, XL_ERR_BAD_ARG, "xl_sdpa_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (nq > MAXN || nk > MAXN) {                 // long sequences: the plain kernels (any dtype)
+        const dim3 grid(B * H, (nq + 63) / 64);
+        if (dtype == XL_BF16)
+            hipLaunchKernelGGL((sdpa_fwd_long<bf16_t>), grid, dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask,
+                               (bf16_t*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);
+        else
+            hipLaunchKernelGGL((sdpa_fwd_long<float>), grid, dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, key_mask,
+                               (float*)o, lse, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);
+        XL_CHECK_LAUNCH();
+        return XL_OK;
+    }
     if (dtype == XL_BF16 && mfma_eligible(a, false)) {
         if (dh == 64) dispatch_frags<true, 64>(a, st);
         else if (dh == 32) dispatch_frags<true, 32>(a, st);
@@ -742,9 +886,30 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
     XL_CHECK_ARG(q && k && v && dout && lse && dq && dk && dv, XL_ERR_BAD_ARG, "xl_sdpa_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int HD = H * dh;
-    const bool fused_bias = bias_grad != nullptr && workspace != nullptr && dtype == XL_BF16 && mfma_eligible(a, true) &&
+    const bool is_long = nq > MAXN || nk > MAXN;
+    const bool fused_bias = !is_long && bias_grad != nullptr && workspace != nullptr && dtype == XL_BF16 && mfma_eligible(a, true) &&
                             (int64_t)B * 3 * HD <= xl_workspace_floats(HD);
-    if (dtype == XL_BF16 && mfma_eligible(a, true)) {
+    if (is_long) {
+        // delta [B, H, nq] goes through the caller's workspace (free again before the bias column sums below use it)
+        XL_CHECK_ARG(workspace != nullptr && (int64_t)B * H * nq <= xl_workspace_floats(HD), XL_ERR_BAD_ARG,
+                     "xl_sdpa_bwd: sequences longer than %d need the workspace (xl_workspace_floats(H * dh) floats)", MAXN);
+        const dim3 gq(B * H, (nq + 63) / 64), gk(B * H, (nk + 63) / 64);
+        if (dtype == XL_BF16) {
+            hipLaunchKernelGGL((sdpa_bwd_long_q<bf16_t>), gq, dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask,
+                               (const bf16_t*)dout, lse, (bf16_t*)dq, workspace, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, scale, p_drop,
+                               a.inv_keep, seed, ctx().step_seed, a.vl);
+            hipLaunchKernelGGL((sdpa_bwd_long_k<bf16_t>), gk, dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask,
+                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddk, lddv,
+                               scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);
+        } else {
+            hipLaunchKernelGGL((sdpa_bwd_long_q<float>), gq, dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, key_mask,
+                               (const float*)dout, lse, (float*)dq, workspace, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, scale, p_drop,
+                               a.inv_keep, seed, ctx().step_seed, a.vl);
+            hipLaunchKernelGGL((sdpa_bwd_long_k<float>), gk, dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, key_mask,
+                               (const float*)dout, lse, workspace, (float*)dk, (float*)dv, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddk, lddv,
+                               scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);
+        }
+    } else if (dtype == XL_BF16 && mfma_eligible(a, true)) {
         a.cs_ws = fused_bias ? workspace : nullptr;
         if (dh == 64) dispatch_frags<false, 64>(a, st);
         else if (dh == 32) dispatch_frags<false, 32>(a, st);
@@ -787,10 +952,10 @@ extern "C" int xl_attn_probs(const void* q, const void* k, const uint8_t* key_ma
     const float inv_keep = 1.0f / (1.0f - p_drop);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == XL_BF16)
-        hipLaunchKernelGGL((attn_probs_kernel<bf16_t>), dim3(B * H), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k, key_mask, lse,
+        hipLaunchKernelGGL((attn_probs_kernel<bf16_t>), dim3(B * H, (nq + 63) / 64), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k, key_mask, lse,
                            probs, H, nq, nk, dh, ldq, ldk, scale, p_drop, inv_keep, seed, ctx().step_seed, vl);
     else
-        hipLaunchKernelGGL((attn_probs_kernel<float>), dim3(B * H), dim3(64), 0, st, (const float*)q, (const float*)k, key_mask, lse,
+        hipLaunchKernelGGL((attn_probs_kernel<float>), dim3(B * H, (nq + 63) / 64), dim3(64), 0, st, (const float*)q, (const float*)k, key_mask, lse,
                            probs, H, nq, nk, dh, ldq, ldk, scale, p_drop, inv_keep, seed, ctx().step_seed, vl);
     XL_CHECK_LAUNCH();
     return XL_OK;

@@ -610,7 +610,8 @@ class Engine:
         (on).  The nn.Module surface runs packed too: hidden_states() scatters the per-layer language states back to the dense
         [B*L, d] layout on request."""
         assert cfg.l_layers >= 1 and cfg.r_layers >= 1 and cfg.x_layers >= 1
-        assert L <= 64 and V <= 64, "attention kernels hold a whole (batch, head) problem on chip: n <= 64"
+        # (text longer than 64 tokens -- ref param.py:140 --max_text_length -- runs on the plain long-sequence attention kernels)
+        assert L <= 512 and V <= 64, "text length <= 512 (position table), visual grid <= 64 tokens (samplers / on-chip attention)"
         self.cfg, self.store, self.ops = cfg, store, ops
         self.dev, self.cdtype = store.device, store.compute_dtype
         self.B, self.L, self.V = B, L, V
