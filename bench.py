@@ -337,6 +337,9 @@ def main():
         get = lambda i: up.upload(batches[i % 4])
 
     def sync():
+        # device first: the step's collectives run on the library's own RCCL communicator, the barrier on torch's -- two communicators
+        # must not have kernels in flight at the same time (no order between them: a known deadlock hazard)
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -362,6 +365,7 @@ def main():
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)
     tmax = torch.tensor([dt], device="cuda")
     if world > 1:
+        torch.cuda.synchronize()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     loss_val = losses[0].item()
@@ -494,7 +498,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if grouped:
+        torch.cuda.synchronize()          # (the library's collectives are done before torch's communicator runs: see sync())
         dist.barrier()
+        try:
+            tr.close()                    # xl_comm_destroy, while the process group that carried its id is still up
+        except NameError:
+            pass                          # (rank 0 at N = 1 with the extra workloads: the trainer is gone already)
         dist.destroy_process_group()
 
 
