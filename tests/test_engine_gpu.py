@@ -1267,6 +1267,7 @@ def test_two_library_contexts_interleaved_in_one_process():
         tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=5, lr=1e-3, total_steps=100, train_dropout=True,
                           plan=True, drop_grads=False)
         tr.set_centroids(cents)
+        tr.ops.set_gemm_wgrad_slabs(1)              # K-split weight gradients through slabs, summed in slice order: no atomics noise there
         return tr
 
     def sampler():
@@ -1304,8 +1305,13 @@ def test_two_library_contexts_interleaved_in_one_process():
     # (the last step's gradient norm of a bf16 model four updates in: summation-order noise of the fp32 atomics is amplified by bf16
     #  rounding flips of the updated weights -- 3.3e-4 relative seen once in ~15 runs, 1e-5..1e-4 otherwise; a context leaking
     #  into the other -- wrong kernel switch, wrong step-seed pointer -- moves it by O(1))
+    # Round 4 (tools/race_probe.py: the same four steps 40 times in one process, with and without random stalls on the side streams):
+    # the outcome is BIMODAL -- deviation ~1e-8, or exactly 3.32e-4 on the norm / 1.92e-5 on the parameters, in ~45 % of the runs whatever
+    # the stalls.  Its source after step 1 is fp32 summation order at the 1e-7 level in two column sums of the feature encoder's backward
+    # (reduce slices added by atomics: two orders), which flips the bf16 rounding of a few updated weights -- not a missing stream
+    # dependency.  The weight gradients themselves are order-free here (slabs summed in slice order).
     assert abs(tr.grad_norm() - alone_n) < 2e-3 * alone_n
-    assert (tr.store.master - alone_p).abs().max().item() < 2e-5
+    assert (tr.store.master - alone_p).abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("plan", [False, True])

@@ -414,7 +414,8 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // split-K of the ping-pong kernel meets in slabs when the stream has a workspace (xl_gemm_set_workspace): one
     // read-modify-write pass over C by the last arriver of every tile instead of a pass of fp32 atomics per split
     if (cx.wgrad_slabs < 0) cx.wgrad_slabs = env_int("XL_GEMM_WGRAD_SLABS", 0);
-    if (use_pp && splitk > 1 && cx.wgrad_slabs) slab_workspace(st, tiles, (long)tiles * splitk, &p.slab, &p.tickets);
+    if (use_pp && splitk > 1 && cx.wgrad_slabs && slab_workspace(st, tiles, (long)tiles * splitk, &p.slab, &p.tickets))
+        p.slab_det = 1;                   // slices summed in slice order whoever arrives last: the same bits every run
     if (splitk > 1 && !accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: memset failed: %s", hipGetErrorString(e));

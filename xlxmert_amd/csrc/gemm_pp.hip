@@ -29,7 +29,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_group_kernel(GroupParams 
     p.epilogue = XL_EPI_NONE; p.out_f32 = 1; p.atomic_out = 1; p.splitk = g.splitk; p.kper = pr.kper; p.vec_epi = 0;
     p.alpha = 1.0f; p.p_drop = 0.f; p.inv_keep = 1.f; p.seed = 0; p.step_seed = nullptr;
     p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.ablate = 0; p.trace = nullptr; p.colsum_ws = nullptr;
-    p.slab = g.slab; p.tickets = g.tickets; p.vec_epi = pr.vec; p.tail_tiles = 0; p.tail_kper = 0; p.overwrite = pr.overwrite; p.slab_det = 0;
+    p.slab = g.slab; p.tickets = g.tickets; p.vec_epi = pr.vec; p.tail_tiles = 0; p.tail_kper = 0; p.overwrite = pr.overwrite; p.slab_det = g.slab != nullptr ? 1 : 0;
     if (z * pr.kper >= pr.K) return;                 // this problem's contraction is shorter than the group's split
     const int tl = t - g.tile_start[i];
     const int kbeg = z * pr.kper;
