@@ -27,7 +27,7 @@ def test_argument_validation_without_gpu():
     with pytest.raises(XlError, match="bad shape"):
         lib.call("xl_gemm", None, None, None, None, None, None, 0, 4, 4, 4, 4, 4, 0, 0, 1, 1, 1, 1, 0, 1.0, 0, 0.0, 0, None, None, None)
     with pytest.raises(XlError, match="nq,nk"):
-        lib.call("xl_sdpa_fwd", 16, 16, 16, None, 16, 16, 1, 1, 65, 8, 64, 64, 64, 64, 64, 1.0, 0.0, 0, None, None, 0, 0, 1, None)
+        lib.call("xl_sdpa_fwd", 16, 16, 16, None, 16, 16, 1, 1, 513, 8, 64, 64, 64, 64, 64, 1.0, 0.0, 0, None, None, 0, 0, 1, None)   # (<= 512: long kernels)
 
 
 def test_no_cpu_fallback():
