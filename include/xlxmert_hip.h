@@ -101,8 +101,10 @@ int  xl_set_gemm_duo(int mode);
  * XL_GEMM_SPLIT_EPI_MAX_TILES (80) output tiles of 256x192 / 256x256 whose contraction is at least XL_GEMM_SPLIT_EPI_MIN_K (1536)
  * deep runs every tile as 2..4 K slices of >= 12 K tiles on whole-CU workgroups; the slices meet in the stream's slab workspace
  * (xl_gemm_set_workspace: needed), are summed in slice order by the last arriver (deterministic), which runs the epilogue.  The
- * language stream's 3328 packed rows against the d x dff and d x 3d weights are the case: 56 tiles, K = 3072 / 2304 -- 47 -> ~25 us.
- * 1 = when eligible (default; env XL_GEMM_SPLIT_EPI), 0 = never.  Same values as the unsplit launch up to the fp32 summation order. */
+ * language stream's 3328 packed rows against the d x dff and d x 3d weights are the case: 56 tiles, K = 3072 / 2304 -- measured 47 ->
+ * 50 us at every split factor (the slab hand-over costs what the shorter K loop saves), hence OFF by default.
+ * 0 = never (default; env XL_GEMM_SPLIT_EPI), 1 = when eligible (needs the stream's slab workspace, xl_gemm_set_workspace; without
+ * one the launch runs unsplit).  Same values as the unsplit launch up to the fp32 summation order. */
 int  xl_set_gemm_split_epi(int on);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */

@@ -1064,7 +1064,8 @@ def test_layernorm_bwd_fused_dropout(dtype):
     close(gpu2[8], cpu2[8], torch.float32, "dbias of the masked gradient", f32_tol=3e-5, bf16_tol=2e-2)
 
 
-@pytest.mark.parametrize("M,N,p_drop", [(16384, 768, 0.1), (8200, 768, 0.0), (12000, 512, 0.1), (9000, 1024, 0.0), (8192, 264, 0.1)])
+@pytest.mark.parametrize("M,N,p_drop", [(16384, 768, 0.1), (8200, 768, 0.0), (12000, 512, 0.1), (9000, 1024, 0.0), (8192, 264, 0.1),
+                                        (12000, 512, 0.0), (8192, 264, 0.0), (8448, 512, 0.0)])     # NIT = 1 rows WITH the dbias check
 def test_layernorm_bwd_lds_prefetch_kernel_equals_plain_kernel(M, N, p_drop):
     """xl_layernorm_bwd takes, for bf16 rows that need several passes of the grid (M >= 8192), the kernel that requests a wave's
     NEXT row by LDS-DMA while the current one is processed (csrc/rowops.hip ln_bwd_dma_kernel).  Same arithmetic in the same

@@ -520,6 +520,62 @@ def test_optimizer_pass_clears_the_gradients_when_asked(overwrite):
     assert torch.equal(keep.step(batch), drop.step(batch)) and torch.equal(keep.store.master, drop.store.master)
 
 
+def test_overwrite_mode_survives_a_k_split_launch_on_a_kept_range():
+    """Round-4 advisor finding: the grouped weight-gradient launch decides per launch whether it has one writer per tile
+    (xl_gemm_wgrad_group_splitk, a function of K = the packed language row count, which moves across the K / 512 threshold from
+    batch to batch).  The engine used to DROP the overwrite mask for a K-split launch -- into a range the optimizer pass no longer
+    clears: the launch then accumulated onto the previous step's gradient.  Here the one-writer answer alternates from step to
+    step; the drop_grads + overwrite trainer must stay bit-identical to the clear-then-accumulate trainer (a range already kept
+    keeps its mask bit: xl_gemm_wgrad_group clears C itself in front of a split launch)."""
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 3, 8, 4
+    ref, _ = make_step(cfg, B, L, grid, lr=1e-2, overwrite_grads=False)
+    got, _ = make_step(cfg, B, L, grid, lr=1e-2, drop_grads=True, overwrite_grads=True)
+    state = {"t": 0, "asked": 0}
+
+    def one_writer(problems):
+        state["asked"] += 1
+        return state["t"] % 2 == 0          # even steps: one writer per tile; odd steps: "this launch splits K"
+    got.ops.wgrad_group_one_writer = one_writer
+    for t in range(5):
+        state["t"] = t
+        batch = synthetic_batch(cfg, B, L, grid, seed=900 + t)
+        lr_, lg = ref.step(batch).clone(), got.step(batch).clone()
+        assert torch.equal(lr_, lg), t
+        assert torch.equal(ref.store.master, got.store.master), t
+        assert torch.isfinite(got.store.master).all()
+    assert state["asked"] > 0
+
+
+def test_kept_range_that_a_step_does_not_write_sees_a_zero_gradient():
+    """Round-4 advisor finding: mark_overwritten is permanent, so a step that skips a producer (here: a weight-gradient launch the
+    test suppresses on one step) would re-apply the previous step's gradient.  optimizer_step zeroes every kept range no backward
+    has stored since the last pass: the parameters must equal those of the clear-then-accumulate trainer, whose buffer was cleared."""
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 3, 8, 4
+    ref, _ = make_step(cfg, B, L, grid, lr=1e-2, overwrite_grads=False)
+    got, _ = make_step(cfg, B, L, grid, lr=1e-2, drop_grads=True, overwrite_grads=True)
+    skip = {"on": False}
+    for tr in (ref, got):
+        orig = tr.ops.gemm_wgrad_group
+
+        def grouped(problems, overwrite_mask=0, _orig=orig, _eng=tr.engine):
+            if skip["on"]:                               # the first problem of every launch "has no producer" on this step
+                if overwrite_mask & 1:
+                    _eng.written_now.discard(_eng._flat_range(problems[0][2], problems[0][3], problems[0][4], problems[0][8]))
+                problems, overwrite_mask = problems[1:], overwrite_mask >> 1
+                if not problems:
+                    return
+            _orig(problems, overwrite_mask=overwrite_mask)
+        tr.ops.gemm_wgrad_group = grouped
+    for t in range(4):
+        skip["on"] = t == 2
+        batch = synthetic_batch(cfg, B, L, grid, seed=950 + t)
+        lr_, lg = ref.step(batch).clone(), got.step(batch).clone()
+        assert torch.equal(lr_, lg), t
+        assert torch.equal(ref.store.master, got.store.master), t
+
+
 @pytest.mark.parametrize("task", ["vis_mask_accum", "word_mask", "matched", "vqa", "nlvr2"])
 def test_overwritten_weight_gradients_every_task(task):
     """PretrainStep(overwrite_grads=True, drop_grads=True) against the clear-then-accumulate step, bit for bit, for every task and

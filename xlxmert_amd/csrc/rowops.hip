@@ -278,6 +278,10 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_kernel(const T* __restrict__
 #ifndef XL_LNB_DEBUG
 #define XL_LNB_DEBUG 0
 #endif
+// LDS in front of gamma: the row ring [W][2 slots][2 NIT KiB] or the flush buffer [3][8][W][64] floats, whichever is larger
+constexpr int lnb_dma_ring_bytes(int nit, int w) {
+    return w * 2 * (2 * nit * 1024) > 3 * 8 * w * 64 * 4 ? w * 2 * (2 * nit * 1024) : 3 * 8 * w * 64 * 4;
+}
 template <int NIT, int W>
 __global__ __launch_bounds__(W * 64, 4) void ln_bwd_dma_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean_i,
@@ -288,14 +292,18 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_dma_kernel(const bf16_t* __r
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int VEC = 8, QD = 2;
     constexpr int SLOT = 2 * NIT * 1024;                 // bytes of one row pair: [x | dy][NIT][64 x 16]
+    // the ring doubles as the column-sum flush buffer `red` ([3][VEC][W][64] floats = 48 KiB at W = 8): at NIT = 1 the ring alone
+    // (32 KiB) is SMALLER than that, so the region in front of gamma is the larger of the two (lnb_dma_ring_bytes, launcher)
+    constexpr int RING = lnb_dma_ring_bytes(NIT, W);
+    static_assert(RING >= W * 2 * SLOT && RING >= 3 * VEC * W * 64 * 4, "ring region holds the row slots and the flush buffer");
     seed = with_step_seed(seed, step_seed);
-    extern __shared__ __attribute__((aligned(16))) uint8_t lnb_lds[];      // [W][2 slots][SLOT] | gamma;  `red` reuses the ring
+    extern __shared__ __attribute__((aligned(16))) uint8_t lnb_lds[];      // [W][2 slots][SLOT] (+ pad) | gamma;  `red` reuses the ring
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     static_assert(NIT <= 2, "two 1 KiB vectors per tensor and row");
     uint8_t* ring = lnb_lds + wave * 2 * SLOT;
     const uint32_t ring_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)ring;
-    float* sgamma = reinterpret_cast<float*>(lnb_lds + W * 2 * SLOT);
+    float* sgamma = reinterpret_cast<float*>(lnb_lds + RING);
     float* red = reinterpret_cast<float*>(lnb_lds);
     float ag[NIT][VEC] = {}, ab[NIT][VEC] = {}, ax[NIT][VEC] = {};
     for (int c = threadIdx.x; c < NIT * 64 * VEC; c += W * 64) {
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(W * 64, 4) void ln_bwd_dma_kernel(const bf16_t* __r
     };
     __syncthreads();                                     // gamma is in place
     // gamma, too, is read through inline assembly (see the row reads below): [it][quad][lane][4] floats, 1 KiB per (it, quad)
-    const uint32_t g_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)lnb_lds + (uint32_t)(W * 2 * SLOT) + (uint32_t)lane * 16u;
+    const uint32_t g_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)lnb_lds + (uint32_t)RING + (uint32_t)lane * 16u;
     const auto read_gamma = [&](int it, float (&gm)[VEC]) {
         u32x4 a, b;
         // (the reads and their wait are ONE statement: as separate asm statements hipcc moved the second read behind the wait)
@@ -437,7 +445,7 @@ template <int NIT>
 static hipError_t launch_ln_bwd_dma(int grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
                                     const float* rstd, void* dx, float* dgamma, float* dbeta, float* dbias_prev, int M, int N,
                                     float* workspace, void* dx_dropped, float p_drop, uint64_t seed) {
-    constexpr int lds = LNB_W * 2 * (2 * NIT * 1024) + NIT * 64 * 8 * 4;
+    constexpr int lds = lnb_dma_ring_bytes(NIT, LNB_W) + NIT * 64 * 8 * 4;
     auto k = ln_bwd_dma_kernel<NIT, LNB_W>;
     static bool attr = false;
     hipError_t e = hipSuccess;

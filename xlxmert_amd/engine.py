@@ -640,7 +640,8 @@ class Engine:
         self._seed = 0
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)       # step part of the dropout seeds
         self._tmp = {}
-        self.overwritten = set()
+        self.overwritten = set()          # flat gradient ranges some backward has STORED (overwrite mode): never cleared again
+        self.written_now = set()          # ... and the ones the backward(s) since the last optimizer pass stored
         self._pending = {"v": [], "l": []}
         self._held, self._held_layers, self._gen = {"v": [], "l": []}, {"v": 0, "l": 0}, {"v": 0, "l": 0}
         self._pending_block = {"v": "", "l": ""}
@@ -892,11 +893,22 @@ class Engine:
         self._pending[self._tag].append((dY, X, dW, M, N, K, lda, ldb, ldc, bool(once and self.dw_overwrite), self._gen[self._tag]))
         self._pending_block[self._tag] = getattr(self.ops, "block", "")
 
-    def _note_overwritten(self, dW, M, N, ldc):
+    def _flat_range(self, dW, M, N, ldc):
         if ldc == N and dW.dtype == torch.float32:
             off = (dW.data_ptr() - self.store.grad.data_ptr()) // 4
             if 0 <= off and off + M * N <= self.store.n_total:
-                self.overwritten.add((off, off + M * N))
+                return (off, off + M * N)
+        return None
+
+    def _note_overwritten(self, dW, M, N, ldc):
+        r = self._flat_range(dW, M, N, ldc)
+        if r is not None:
+            self.overwritten.add(r)
+            self.written_now.add(r)
+
+    def _is_kept(self, dW, M, N, ldc):
+        """this weight gradient's range was stored (not accumulated) by an earlier backward: the optimizer pass no longer clears it"""
+        return self._flat_range(dW, M, N, ldc) in self.overwritten
 
     PAIR_LAYERS = int(os.environ.get("XL_WGRAD_PAIR", "2"))          # layers per weight-gradient launch (1: every layer its own)
     # Backward scratch generations.  The weight-gradient launches read a layer's scratch (dz, dqkv, dpre ...) from the companion
@@ -952,10 +964,22 @@ class Engine:
             chunk = [pr[:9] for pr in probs[i:i + 8]]
             mask = sum(1 << j for j, pr in enumerate(probs[i:i + 8]) if pr[9])
             if mask and not self.ops.wgrad_group_one_writer(chunk):
-                mask = 0                        # a K-split launch would have to clear C first: leave that to the optimizer pass
+                # A K-split launch would have to clear C first (a memset per problem): leave a range that nobody has promised to
+                # overwrite to the optimizer pass.  A range ALREADY marked "kept" (ParamStore.mark_overwritten: the optimizer pass
+                # does not clear it any more) keeps its bit -- the row count of the packed language side moves K across the
+                # K / 512 split threshold from batch to batch, and accumulating into the uncleared buffer would add the previous
+                # step's gradient; with the bit set xl_gemm_wgrad_group clears C itself in front of the split launch.
+                mask = sum(1 << j for j, pr in enumerate(probs[i:i + 8]) if pr[9] and self._is_kept(pr[2], pr[3], pr[4], pr[8]))
             for j, pr in enumerate(probs[i:i + 8]):
                 if (mask >> j) & 1:
                     self._note_overwritten(pr[2], pr[3], pr[4], pr[8])
+                else:
+                    # accumulating (a later micro-batch of an accumulation window, a tied tensor) into a range the optimizer pass no
+                    # longer clears and no backward since that pass has stored: it still holds the previous step's gradient
+                    r = self._flat_range(pr[2], pr[3], pr[4], pr[8])
+                    if r in self.overwritten and r not in self.written_now:
+                        self.ops.zero(self.store.grad[r[0]:r[1]])
+                        self.written_now.add(r)
             kw = {"overwrite_mask": mask} if mask else {}
             if dw is None:
                 self.ops.gemm_wgrad_group(chunk, **kw)
@@ -1795,6 +1819,7 @@ class Engine:
                 self._flush_if_reporting()
                 self._ready_lang(st.range_of(f"bert.encoder.layer.{i}.")[1])
             self.wgrad_flush(pair=True, force=True)      # an odd layer left over
+            self.wgrad_sync()                             # the scratch / workspace generation written below: its last reader is done
             e = "bert.embeddings"
             dy, MLd = L_(GA), self.MLd
             if self.packed:                       # back to the dense [B*L] rows of the embedding kernels (zero at [PAD] positions)
@@ -1830,6 +1855,7 @@ class Engine:
         # ---- visual feature encoder (HF:468-476) + codebook input
         v = "bert.encoder.visn_fc"
         ops.block = "visn_fc"
+        self.wgrad_sync()                     # (no block's bwd() follows the last _advance_gen: wait for this generation's guard here)
         dxv = self.tmp("dctx", MV, d)
         if self.p_hid > 0:
             ops.dropout(V_(GA), V_(GA), MV, d, d, d, self.p_hid, self.seed(1))

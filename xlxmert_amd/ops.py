@@ -107,7 +107,7 @@ class HipOps:
         self._call("xl_set_gemm_duo", int(mode))
 
     def set_gemm_split_epi(self, on):
-        """K split of few-tile, deep-K launches with an epilogue through the stream's slab workspace: 1 when eligible (default), 0 never."""
+        """K split of few-tile, deep-K launches with an epilogue through the stream's slab workspace: 0 never (default), 1 when eligible."""
         self._call("xl_set_gemm_split_epi", int(on))
 
     def set_gemm_tail_split(self, max_tail_tiles, min_k):

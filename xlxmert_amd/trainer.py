@@ -641,8 +641,15 @@ class PretrainStep:
 
     def optimizer_step(self):
         self.t += 1                      # host mirror of step_dev (seeds, logging): never read by a kernel
-        if self.engine.overwritten:      # ranges the backward stores rather than accumulates: the pass leaves them uncleared
-            self.store.mark_overwritten(sorted(self.engine.overwritten))
+        eng = self.engine
+        if eng.overwritten:              # ranges the backward stores rather than accumulates: the pass leaves them uncleared
+            self.store.mark_overwritten(sorted(eng.overwritten))
+            # "every backward rewrites a kept range" is a claim about the step's composition: a step that skipped a producer (the
+            # answer head when qa_labels is None, ...) left the PREVIOUS step's gradient in a range nobody clears any more.  The
+            # reference's tensor would have .grad None there: zero it, so that the pass sees a zero gradient like before overwrite mode
+            for lo, hi in sorted(eng.overwritten - eng.written_now):
+                self.ops.zero(self.store.grad[lo:hi])
+            eng.written_now = set()
         self._optimizer_launches()
 
     # ---- sharded optimizer (collective="rs+ag"): shard-local norm + one scalar all-reduce, AdamW over this rank's shards,
