@@ -96,7 +96,7 @@ class GemmTimer:
     """Wraps HipOps.gemm / gemm_wgrad_group with HIP events on the launch stream (torch's current stream) for ONE instrumented step."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.orig_group, self.rec = ops, ops.gemm, ops.gemm_wgrad_group, []
+        self.ops, self.orig, self.orig_group, self.orig_pair, self.rec = ops, ops.gemm, ops.gemm_wgrad_group, ops.gemm_pair, []
 
     def __enter__(self):
         def timed(A, B, C, bias, residual, aux, M, N, K, *a, **kw):
@@ -119,13 +119,31 @@ class GemmTimer:
             self.rec.append((s, e, sum(2.0 * pr[3] * pr[4] * pr[5] for pr in problems),
                              ("group", len(problems), problems[0][5], sum(pr[3] * pr[4] for pr in problems) // 65536, 0, 0),
                              nbytes, getattr(self.ops, "block", "")))
+        def timed_pair(c0, c1):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.orig_pair(c0, c1)
+            e.record()
+            fl, nb, Ms = 0.0, 0, []
+            for c in (c0, c1):
+                A, B, C, bias, residual, aux, M, N, K = c.a[:9]
+                eb = 2 if A.dtype == torch.bfloat16 else 4
+                fl += 2.0 * M * N * K
+                nb += eb * (M * K + N * K) + C.element_size() * M * N + (eb * M * N if residual is not None else 0) + \
+                    (eb * M * N if aux is not None else 0)
+                Ms.append(M)
+            kw = c0.kw
+            self.rec.append((s, e, fl, ("pair", Ms[0], Ms[1], c0.a[7], c0.a[8], kw.get("b_kmajor", 1) * 10 + kw.get("epilogue", 0)), nb,
+                             getattr(self.ops, "block", "")))
         self.ops.gemm = timed
         self.ops.gemm_wgrad_group = timed_group
+        self.ops.gemm_pair = timed_pair
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
         self.ops.gemm_wgrad_group = self.orig_group
+        self.ops.gemm_pair = self.orig_pair
         torch.cuda.synchronize()
         self.total_ms = sum(r[0].elapsed_time(r[1]) for r in self.rec)
         self.flops = sum(r[2] for r in self.rec)

@@ -138,6 +138,27 @@ int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             int epilogue, float alpha, int accumulate,
             float p_drop, uint64_t seed, float* colsum_out, float* colsum_ws, void* stream);
 
+/* Two contractions of one shape class, possibly in ONE launch: exactly
+ *     xl_gemm(A0, B0, C0, bias0, residual0, aux0, M0, ..., accumulate 0, p_drop, seed0, colsum_out0, colsum_ws0, stream);
+ *     xl_gemm(A1, B1, C1, bias1, residual1, aux1, M1, ..., accumulate 0, p_drop, seed1, colsum_out1, colsum_ws1, stream);
+ * (same N, K, leading dimensions, layouts, element types, epilogue kind, alpha and dropout probability; own operands, row count,
+ * dropout seed and column-sum outputs).  The visual and the language side of a cross-modality layer's self-attention / FFN
+ * sub-blocks (HF:417-449: visn_self_att | lang_self_att, visn_inter/output | lang_inter/output) and of the two single-modality
+ * stacks (HF:516-529) are such pairs: 16384 visual rows and ~3300 packed language rows against different weights of the same
+ * shape.  When both problems are bf16 with K-major A, M a multiple of 256, N of 256, aligned operands and an epilogue kind with a
+ * paired instance (forward layout: NONE / RESIDUAL / GELU_DG; dX layout: NONE / RESIDUAL / MULAUX), their 256x256 output tiles are
+ * dealt to the CUs by one launch of the ping-pong kernel -- the language side's 39 row tiles ride in the CUs the visual side's
+ * last round leaves idle instead of occupying a quarter of the chip at a tenth of its matrix rate beside it.  Otherwise: the two
+ * xl_gemm calls.  Results are bit-identical either way (the same tile code runs each tile).  xl_set_gemm_pair(0) / env
+ * XL_GEMM_PAIR=0: always two launches. */
+int  xl_gemm_pair(const void* A0, const void* B0, void* C0, const float* bias0, const void* residual0, void* aux0, int M0,
+                  uint64_t seed0, float* colsum_out0, float* colsum_ws0,
+                  const void* A1, const void* B1, void* C1, const float* bias1, const void* residual1, void* aux1, int M1,
+                  uint64_t seed1, float* colsum_out1, float* colsum_ws1,
+                  int N, int K, int lda, int ldb, int ldc, int ldr, int ldx, int a_kmajor, int b_kmajor, int in_dtype,
+                  int out_dtype, int epilogue, float alpha, float p_drop, void* stream);
+int  xl_set_gemm_pair(int on);
+
 /* Grouped weight gradients: for i in [0, count), count <= 8:
  *     C_i[M_i, N_i] (fp32) += sum_k A_i[k, m] * B_i[k, n]        (dW = dY^T X; both operands stored [K_i rows][features])
  * i.e. xl_gemm(..., a_kmajor=0, b_kmajor=0, out fp32, accumulate=1) for several Linear layers in ONE launch: the output

@@ -121,6 +121,11 @@ class FakeOps:
     def wgrad_group_one_writer(self, problems):
         return True
 
+    def gemm_pair(self, c0, c1):
+        """xl_gemm_pair: by contract the two xl_gemm calls"""
+        self.gemm(*c0.a, **c0.kw)
+        self.gemm(*c1.a, **c1.kw)
+
     def gemm_wgrad_group(self, problems, overwrite_mask=0):
         for i, (A, B, C, M, N, K, lda, ldb, ldc) in enumerate(problems):
             self.gemm(A, B, C, None, None, None, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, out_f32=True,

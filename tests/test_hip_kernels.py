@@ -236,6 +236,110 @@ def test_gemm_duo_tiles_equal_whole_cu_tiles(M, N, K, bk, epi, p_drop):
         assert abs(frac - p_drop) < 0.01, frac
 
 
+@pytest.mark.parametrize("M0,M1,N,K,bk,epi,p_drop,colsum", [
+    (16384, 3328, 2304, 768, 1, 0, 0.0, False), (16384, 3328, 768, 768, 1, 2, 0.1, False), (16384, 3584, 3072, 768, 1, 6, 0.0, False),
+    (16384, 3072, 768, 3072, 1, 2, 0.1, False), (16384, 3328, 768, 768, 0, 0, 0.0, False), (16384, 3328, 3072, 768, 0, 7, 0.0, True),
+    (16384, 3328, 768, 3072, 0, 2, 0.0, False), (16384, 3328, 768, 2304, 0, 2, 0.0, False), (256, 256, 768, 768, 1, 2, 0.1, False),
+    (512, 256, 3072, 768, 0, 7, 0.0, True), (256, 1024, 2304, 768, 1, 0, 0.0, False), (2048, 256, 768, 200, 1, 0, 0.0, False)])
+def test_gemm_pair_equals_two_launches(M0, M1, N, K, bk, epi, p_drop, colsum):
+    """xl_gemm_pair (two problems -- a visual and a language side -- dealt to the CUs by ONE launch of the 256x256 ping-pong kernel)
+    against the two xl_gemm launches it stands for, on the step's own shapes: forward and dX layouts, the paired epilogue kinds
+    (plain, dropout + residual, GELU with saved derivative, multiply by the saved derivative with fused column sums).  Every output
+    element is produced by the same tile code from the same operands, the dropout draw is a function of the element's coordinates
+    and the launch's seed: C, the saved aux and the column sums must be BIT-identical; twice, so that a stale ring slot would show."""
+    g = torch.Generator().manual_seed(M0 + M1 + N + K + epi)
+    ops = hip(torch.bfloat16)
+    from xlxmert_amd.ops import GemmCall
+    prob = []
+    for M, sd in ((M0, 1234), (M1, 99)):
+        A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        B = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.05).to(torch.bfloat16).cuda()
+        bias = torch.randn(N, generator=g).cuda() if bk else None
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+        auxin = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        prob.append((A, B, bias, res, auxin, M, sd))
+    ws = [torch.zeros(ops.workspace_floats(N), device="cuda") for _ in range(2)]
+
+    def calls():
+        out, cs = [], []
+        for i, (A, B, bias, res, auxin, M, sd) in enumerate(prob):
+            C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+            aux = auxin.clone()
+            csum = torch.zeros(N, device="cuda") if colsum else None
+            cs.append(GemmCall(A, B, C, bias, res if epi == 2 else None, aux if epi in (6, 7) else None, M, N, K, K, K if bk else N, N,
+                               ldr=N, ldx=N, a_kmajor=1, b_kmajor=bk, epilogue=epi, p_drop=p_drop, seed=sd, colsum=csum, ws=ws[i]))
+            out.append((C, aux, csum))
+        return cs, out
+    ops.set_gemm_pingpong(2)
+    ops.set_gemm_duo(0)
+    try:
+        for rep in range(2):
+            cs, ref = calls()
+            for c in cs:
+                ops.gemm(*c.a, **c.kw)
+            torch.cuda.synchronize()
+            cs, got = calls()
+            ops.gemm_pair(*cs)
+            torch.cuda.synchronize()
+        ops.set_gemm_pair(0)                    # the switch: two launches through the same entry point
+        cs, off = calls()
+        ops.gemm_pair(*cs)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_pair(1)
+        ops.set_gemm_duo(1)
+        ops.set_gemm_pingpong(1)
+    for i in range(2):
+        for other in (got, off):
+            assert torch.equal(ref[i][0], other[i][0]), (i, (ref[i][0].float() - other[i][0].float()).abs().max().item())
+            assert torch.equal(ref[i][1], other[i][1]), i
+            if colsum:
+                assert torch.equal(ref[i][2], other[i][2]), i
+        assert not (ref[i][0] == 7.0).all()
+        if p_drop > 0:
+            frac = (got[i][0] == prob[i][3]).float().mean().item()         # dropped elements keep the residual alone
+            assert abs(frac - p_drop) < 0.01, frac
+    if p_drop > 0 and M0 == M1:
+        assert not torch.equal(got[0][0] == prob[0][3], got[1][0] == prob[1][3])       # own seeds: different masks
+
+
+@pytest.mark.parametrize("bk,epi", [(1, 0), (1, 2), (1, 6), (0, 0), (0, 2), (0, 7)])
+@pytest.mark.parametrize("M0,M1,N,K", [(256, 512, 256, 64), (768, 256, 768, 128), (512, 512, 512, 200), (256, 256, 2304, 1000)])
+def test_gemm_pair_exact(M0, M1, N, K, epi, bk):
+    """the paired launch on integer-valued operands against the host restatement: the fp32 accumulation is exact, so the plain
+    result must equal the host product bit for bit (1 / 2 / 4 ragged / 16 ragged K tiles, both layouts, every paired epilogue)."""
+    from xlxmert_amd.ops import GemmCall
+    ops, fk = hip(torch.bfloat16), FakeOps(torch.bfloat16)
+    g = torch.Generator().manual_seed(M0 + M1 + N + K + epi * 3 + bk)
+    alpha = 2.0 ** -6 if epi in (6, 7) else 1.0
+    dev, host = [], []
+    for M in (M0, M1):
+        A = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+        B = torch.randint(-3, 4, ((N, K) if bk else (K, N)), generator=g).to(torch.bfloat16)
+        bias = torch.randint(-4, 5, (N,), generator=g).float()
+        res = torch.randint(-8, 9, (M, N), generator=g).to(torch.bfloat16)
+        aux = (torch.randint(-8, 9, (M, N), generator=g).float() * 0.25).to(torch.bfloat16)
+        for where, lst in (("cuda", dev), ("cpu", host)):
+            t = [x.to(where) for x in (A, B, bias, res, aux)]
+            C = torch.zeros(M, N, dtype=torch.bfloat16, device=where)
+            lst.append((GemmCall(t[0], t[1], C, t[2], t[3] if epi == 2 else None, t[4] if epi in (6, 7) else None, M, N, K, K,
+                                 K if bk else N, N, ldr=N, ldx=N, a_kmajor=1, b_kmajor=bk, epilogue=epi, alpha=alpha), C, t[4]))
+    ops.set_gemm_pingpong(2)
+    try:
+        ops.gemm_pair(dev[0][0], dev[1][0])
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_pingpong(1)
+    for i in range(2):
+        fk.gemm(*host[i][0].a, **host[i][0].kw)
+        tol = 0.0 if epi in (0, 2) else 2e-2
+        d = (dev[i][1].cpu().float() - host[i][1].float()).abs().max().item()
+        assert d <= tol * max(1.0, host[i][1].float().abs().max().item()), (i, d)
+        if epi == 6:
+            d = (dev[i][2].cpu().float() - host[i][2].float()).abs().max().item()
+            assert d <= 2e-2, (i, d)
+
+
 @pytest.mark.parametrize("bk", [1, 0])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(128, 192, 64), (384, 768, 128), (640, 384, 200), (128, 2304, 1000), (896, 768, 1536)])

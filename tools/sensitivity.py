@@ -51,6 +51,11 @@ V = {
     "no_lang_deepK_gemm": lambda op, tag, a: op == "gemm" and lang(tag) and a[8] >= 2304 and a[7] == 768,
     "no_lang_gemm": lambda op, tag, a: op == "gemm" and lang(tag),
     "no_lang_anything": lambda op, tag, a: lang(tag) and op in ("gemm", "sdpa_fwd", "sdpa_bwd", "layernorm_fwd", "layernorm_bwd", "gemm_wgrad_group"),
+    "no_lang_small": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("sdpa_fwd", "sdpa_bwd", "layernorm_fwd", "layernorm_bwd"),
+    "no_lang_small_paired": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("sdpa_fwd", "sdpa_bwd", "layernorm_fwd", "layernorm_bwd")
+    and not (tag.startswith("l") and int(tag[1:]) < 4),
+    "no_lang_sdpa_paired": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("sdpa_fwd", "sdpa_bwd") and not (tag.startswith("l") and int(tag[1:]) < 4),
+    "no_lang_ln_paired": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("layernorm_fwd", "layernorm_bwd") and not (tag.startswith("l") and int(tag[1:]) < 4),
     "no_lang_wgrad": lambda op, tag, a: op == "gemm_wgrad_group" and lang(tag),
     "no_vis_wgrad": lambda op, tag, a: op == "gemm_wgrad_group" and not lang(tag),
     "no_ln_fwd": lambda op, tag, a: op == "layernorm_fwd",

@@ -549,6 +549,72 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     return XL_OK;
 }
 
+// Two contractions of the same shape class in one launch (gemm_pp_kernel.h PairParams); see include/xlxmert_hip.h.  Whatever the
+// launch strategy, the results are those of xl_gemm(problem 0) followed by xl_gemm(problem 1): the same tile kernel runs both.
+extern "C" int xl_gemm_pair(const void* A0, const void* B0, void* C0, const float* bias0, const void* residual0, void* aux0, int M0,
+                            uint64_t seed0, float* colsum_out0, float* colsum_ws0,
+                            const void* A1, const void* B1, void* C1, const float* bias1, const void* residual1, void* aux1, int M1,
+                            uint64_t seed1, float* colsum_out1, float* colsum_ws1,
+                            int N, int K, int lda, int ldb, int ldc, int ldr, int ldx, int a_kmajor, int b_kmajor, int in_dtype,
+                            int out_dtype, int epilogue, float alpha, float p_drop, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Ctx& cx = ctx();
+    const void* A[2] = {A0, A1}; const void* B[2] = {B0, B1}; void* C[2] = {C0, C1};
+    const float* bias[2] = {bias0, bias1}; const void* res[2] = {residual0, residual1}; void* aux[2] = {aux0, aux1};
+    const int M[2] = {M0, M1}; const uint64_t seed[2] = {seed0, seed1};
+    float* cs_out[2] = {colsum_out0, colsum_out1}; float* cs_ws[2] = {colsum_ws0, colsum_ws1};
+    if (cx.gemm_pp < 0) cx.gemm_pp = env_int("XL_GEMM_PP", 1);
+    if (cx.gemm_pair < 0) cx.gemm_pair = env_int("XL_GEMM_PAIR", 1);
+    static const int pp_min_tiles = env_int("XL_GEMM_PP_MIN_TILES", 48);
+    bool one = cx.gemm_pair != 0 && cx.gemm_pp != 0 && cx.use_tr_read && in_dtype == XL_BF16 && out_dtype == XL_BF16 && a_kmajor &&
+               M0 > 0 && M1 > 0 && N > 0 && K > 0 && N % 256 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+               lda >= K && ldb >= (b_kmajor ? K : N) && ldc >= N && p_drop >= 0.f && p_drop < 1.f &&
+               epilogue != XL_EPI_TANH && epilogue != XL_EPI_ROWMAX && pp_pair_has_instance(b_kmajor, epilogue) &&
+               (double)(b_kmajor ? N : K) * ldb < 1e9;
+    long tiles[2] = {0, 0};
+    for (int i = 0; i < 2 && one; ++i) {
+        one = A[i] && B[i] && C[i] && M[i] % 256 == 0 && aligned16(A[i]) && aligned16(B[i]) && aligned16(C[i]) && (double)M[i] * lda < 1e9 &&
+              (bias[i] == nullptr || aligned16(bias[i]));
+        if (epilogue == XL_EPI_RESIDUAL) one = one && res[i] && aligned16(res[i]) && ldr % 8 == 0 && ldr >= N;
+        if (epilogue == XL_EPI_GELU_DG || epilogue == XL_EPI_MULAUX) one = one && aux[i] && aligned16(aux[i]) && ldx % 8 == 0 && ldx >= N;
+        if (cs_out[i] != nullptr) one = one && cs_ws[i] != nullptr && (long)((M[i] + 63) / 64) * N <= xl_workspace_floats(N);
+        tiles[i] = (long)(M[i] / 256) * (N / 256);
+    }
+    one = one && (cx.gemm_pp == 2 || tiles[0] + tiles[1] >= pp_min_tiles) && tiles[0] < (1 << 20) && tiles[1] < (1 << 20);
+    if (!one) {          // fp32 parity path, small or ragged problems, kinds without a paired instance: one launch each
+        for (int i = 0; i < 2; ++i) {
+            const int rc = xl_gemm(A[i], B[i], C[i], bias[i], res[i], aux[i], M[i], N, K, lda, ldb, ldc, ldr, ldx, a_kmajor, b_kmajor,
+                                   in_dtype, out_dtype, epilogue, alpha, 0, p_drop, seed[i], cs_out[i], cs_ws[i], stream);
+            if (rc != XL_OK) return rc;
+        }
+        return XL_OK;
+    }
+    static const int ablate = env_int("XL_GEMM_ABLATE", 0);
+    PairParams pp;
+    for (int i = 0; i < 2; ++i) {
+        GemmParams& p = pp.p[i];
+        p.A = A[i]; p.B = B[i]; p.C = C[i]; p.bias = bias[i]; p.residual = res[i]; p.aux = aux[i];
+        p.M = M[i]; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldx = ldx;
+        p.epilogue = epilogue; p.out_f32 = 0; p.atomic_out = 0; p.splitk = 1; p.kper = (K + 63) / 64 * 64; p.vec_epi = 1;
+        p.alpha = alpha; p.p_drop = p_drop; p.inv_keep = 1.0f / (1.0f - p_drop); p.seed = seed[i]; p.step_seed = cx.step_seed;
+        p.tiles_m = M[i] / 256; p.tiles_n = N / 256; p.ablate = ablate; p.trace = cx.gemm_trace;
+        p.colsum_ws = cs_out[i] != nullptr ? cs_ws[i] : nullptr;
+        p.slab = nullptr; p.tickets = nullptr; p.tail_tiles = 0; p.tail_kper = 0; p.overwrite = 0; p.slab_det = 0;
+    }
+    pp.tiles0 = (int)tiles[0];
+    hipError_t e = launch_pp_pair(pp, b_kmajor, epilogue, (int)(tiles[0] + tiles[1]), st);
+    XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm_pair: launch failed: %s", hipGetErrorString(e));
+    XL_CHECK_LAUNCH();
+    for (int i = 0; i < 2; ++i)
+        if (cs_out[i] != nullptr) { launch_colsum_reduce(cs_ws[i], M[i] / 128, N, cs_out[i], st); XL_CHECK_LAUNCH(); }
+    return XL_OK;
+}
+
+extern "C" int xl_set_gemm_pair(int on) {
+    ctx().gemm_pair = on ? 1 : 0;
+    return XL_OK;
+}
+
 extern "C" int xl_gemm_wgrad_group_splitk(const int* M, const int* N, const int* K, int count) {
     if (M == nullptr || N == nullptr || K == nullptr || count < 1 || count > 8) return 0;
     static const int group_max_wgs = env_int("XL_GEMM_GROUP_MAX_WGS", 256);

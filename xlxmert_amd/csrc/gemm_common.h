@@ -737,6 +737,12 @@ hipError_t launch_pp_group(const GroupParams& g, int nblk, hipStream_t st);
 // the host for launches whose C / residual / aux rows are 16-byte aligned (interior tiles take it, edge tiles fall back)
 // bn: 256 (256x256 tile) or 192 (256x192 tile: N a multiple of 192, every tile interior, fast epilogue, no fused column sums)
 hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int bn, int nblk, hipStream_t st, int bm = 256);
+// gemm_pp_pair.hip: two problems per launch (gemm_pp_kernel.h gemm_bf16_pp_pair_kernel), 256x256 tiles, A K-major, fast epilogue;
+// hipErrorInvalidValue: no instance for this (layout, epilogue kind) -- forward layout: NONE / RESIDUAL / GELU_DG, dX layout:
+// NONE / RESIDUAL / MULAUX.  tiles0: problem 0's tile count (linear tiles [0, tiles0) are its, the rest problem 1's)
+struct PairParams { GemmParams p[2]; int tiles0; };
+hipError_t launch_pp_pair(const PairParams& pp, int b_kmajor, int epik, int nblk, hipStream_t st);
+bool pp_pair_has_instance(int b_kmajor, int epik);
 // persistent variant (gemm_pp_persist.hip): A K-major, bf16 in / out, every tile interior, fast epilogue, several rounds of tiles;
 // hipErrorInvalidValue when the (layout, epilogue kind) has no instance
 hipError_t launch_pp_persist(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);

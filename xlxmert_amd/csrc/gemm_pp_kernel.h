@@ -417,6 +417,34 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmParams p) {
                                p.slab != nullptr ? tn * p.tiles_m + tm : -1, z, p.splitk);
 }
 
+// Two problems in ONE launch ("pair"): C_i = epilogue(A_i B_i^T) for i = 0, 1 with the same N, K, layouts, leading dimensions and
+// epilogue kind but their own operands, bias / residual / aux, row count and dropout seed -- the visual (B x 64 rows) and the
+// language (packed B x ~13 rows) side of a cross-modality layer's self-attention / FFN sub-blocks, or a visual and a language
+// layer of the two stacks (HF:417-449, 516-529: same shapes, different weights).  The language side alone is 39 row tiles of 256:
+// as its own launch it occupies 39-156 of the 256 CUs at 0.1 of the MFMA peak next to the other streams' launches; as the tail of
+// the visual side's tile list it fills CUs that launch leaves idle anyway (N = 768: 192 tiles + 39 on 256 CUs).  Linear tile
+// order: problem 0's tiles, then problem 1's, each in its own XCD-aware (8 row tiles x all columns) order.
+template <bool AK, bool BKM, int EPIK>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp_pair_kernel(PairParams pp) {
+    const int L = linear_block();
+    const int which = L >= pp.tiles0 ? 1 : 0;
+    const GemmParams& p = pp.p[which];
+    int tm, tn;
+    tile_of(p, L - which * pp.tiles0, tm, tn);
+    pp_tile<AK, BKM, EPIK, 256>(p, tm, tn, 0, p.K, true);
+}
+
+template <bool AK, bool BKM, int EPIK>
+static hipError_t launch_pp_pair_one(const PairParams& pp, int nblk, hipStream_t st) {
+    constexpr int lds = 131072;
+    hipError_t e = hipSuccess;
+    static bool attr = false;
+    auto k = gemm_bf16_pp_pair_kernel<AK, BKM, EPIK>;
+    if (!attr) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(512), lds, st, pp);
+    return e;
+}
+
 template <bool AK, bool BKM, int EPIK, int BN = 256, int BM = 256>
 static hipError_t launch_pp_one(const GemmParams& p, int nblk, hipStream_t st) {
     hipError_t e = hipSuccess;

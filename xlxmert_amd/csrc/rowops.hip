@@ -153,25 +153,48 @@ __device__ __forceinline__ void flush_colsums3(float (&a0)[NIT][VEC], float (&a1
     }
 }
 
-// out[v][n*stride] += sum_g ws[(g*nvec + v)*N + n].  grid = (column blocks, G-slices): each block sums one slice of the
-// partial slabs and adds it with one atomic per column (<= 16 atomics per output element).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int G, int nvec, int N, ReduceOuts outs) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nvec * N) return;
-    const int v = idx / N, n = idx - v * N;
-    if (outs.p[v] == nullptr) return;
-    const int per = (G + gridDim.y - 1) / gridDim.y;
-    const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+// out[v][n*stride] += sum_g ws[(g*nvec + v)*N + n], DETERMINISTIC: a block owns 32 consecutive (vector, column) pairs and sums
+// the G partial slabs in 8 fixed slices (lane -> column: a wave reads two 128-byte row segments per step), the slices meet in LDS
+// and are added in slice order by the thread that then makes ONE plain read-modify-write of the output element -- no atomics, the
+// same bits every run.  (Rounds 1-4: grid.y slices met through up to 16 fp32 atomics per element, whose order varied from run to
+// run -- the last non-reproducible reduction of the step together with the feature encoder's)  The caller
+// guarantees that nothing else writes the outputs concurrently: launches on one stream are ordered, and entries of one batched
+// launch never alias (xl_flush_reductions_on cuts the batch there).
+__device__ __forceinline__ void reduce_partials_entry(const float* __restrict__ ws, int G, int nvec, int N, const ReduceOuts& outs,
+                                                      int group, float (*red)[33]) {
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = group * 32 + c;
+    const bool in = idx < nvec * N;
+    const int v = in ? idx / N : 0, n = in ? idx - v * N : 0;
+    const bool live = in && outs.p[v] != nullptr;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = g0;
-    for (; g + 4 <= g1; g += 4) {
-        s0 += ws[((size_t)(g + 0) * nvec + v) * N + n];
-        s1 += ws[((size_t)(g + 1) * nvec + v) * N + n];
-        s2 += ws[((size_t)(g + 2) * nvec + v) * N + n];
-        s3 += ws[((size_t)(g + 3) * nvec + v) * N + n];
+    if (live) {
+        const int per = (G + 7) >> 3;
+        const int g0 = sl * per, g1 = min(G, g0 + per);
+        const float* col = ws + (size_t)v * N + n;
+        const size_t pitch = (size_t)nvec * N;
+        int g = g0;
+        for (; g + 4 <= g1; g += 4) {
+            s0 += col[(size_t)(g + 0) * pitch];
+            s1 += col[(size_t)(g + 1) * pitch];
+            s2 += col[(size_t)(g + 2) * pitch];
+            s3 += col[(size_t)(g + 3) * pitch];
+        }
+        for (; g < g1; ++g) s0 += col[(size_t)g * pitch];
     }
-    for (; g < g1; ++g) s0 += ws[((size_t)g * nvec + v) * N + n];
-    if (g1 > g0) atomicAdd(outs.p[v] + (size_t)n * outs.stride[v], (s0 + s1) + (s2 + s3));
+    red[sl][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && live) {
+        float t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][c];
+        float* o = outs.p[v] + (size_t)n * outs.stride[v];
+        *o += t;
+    }
+}
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int G, int nvec, int N, ReduceOuts outs) {
+    __shared__ float red[8][33];
+    reduce_partials_entry(ws, G, nvec, N, outs, blockIdx.x, red);
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -1406,36 +1429,37 @@ constexpr int kBatch = 6;
 struct BatchArgs { int n; PendingReduce e[kBatch]; };
 
 __global__ __launch_bounds__(256) void reduce_partials_batched_kernel(BatchArgs a) {
+    __shared__ float red[8][33];
     const PendingReduce& e = a.e[blockIdx.z];
-    if ((int)blockIdx.y >= e.gy) return;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= e.nvec * e.N) return;
-    const int v = idx / e.N, n = idx - v * e.N;
-    if (e.outs.p[v] == nullptr) return;
-    const int per = (e.G + e.gy - 1) / e.gy;
-    const int g0 = blockIdx.y * per, g1 = min(e.G, g0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = g0;
-    for (; g + 4 <= g1; g += 4) {
-        s0 += e.ws[((size_t)(g + 0) * e.nvec + v) * e.N + n];
-        s1 += e.ws[((size_t)(g + 1) * e.nvec + v) * e.N + n];
-        s2 += e.ws[((size_t)(g + 2) * e.nvec + v) * e.N + n];
-        s3 += e.ws[((size_t)(g + 3) * e.nvec + v) * e.N + n];
+    if ((int)blockIdx.x * 32 >= e.nvec * e.N) return;          // (block-uniform: the grid is sized for the widest entry)
+    reduce_partials_entry(e.ws, e.G, e.nvec, e.N, e.outs, blockIdx.x, red);
+}
+
+// do two pending reductions write any common output element?  (they must not share a batched launch: plain read-modify-write)
+static bool reduce_outputs_alias(const PendingReduce& a, const PendingReduce& b) {
+    for (int v = 0; v < a.nvec && v < 16; ++v) {
+        if (a.outs.p[v] == nullptr) continue;
+        const float* a0 = a.outs.p[v];
+        const float* a1 = a0 + (size_t)(a.N - 1) * a.outs.stride[v] + 1;
+        for (int w = 0; w < b.nvec && w < 16; ++w) {
+            if (b.outs.p[w] == nullptr) continue;
+            const float* b0 = b.outs.p[w];
+            const float* b1 = b0 + (size_t)(b.N - 1) * b.outs.stride[w] + 1;
+            if (a0 < b1 && b0 < a1) return true;
+        }
     }
-    for (; g < g1; ++g) s0 += e.ws[((size_t)g * e.nvec + v) * e.N + n];
-    if (g1 > g0) atomicAdd(e.outs.p[v] + (size_t)n * e.outs.stride[v], (s0 + s1) + (s2 + s3));
+    return false;
 }
 
 static void launch_reduce(const float* ws, int G, int nvec, int N, ReduceOuts outs, hipStream_t st) {
     for (int v = 0; v < 16; ++v) if (outs.stride[v] == 0) outs.stride[v] = 1;
-    const int gy = G >= 256 ? 16 : (G >= 64 ? 8 : (G >= 16 ? 4 : 1));
     Ctx& c = ctx();
     if (c.defer_reduce) {
         std::lock_guard<std::mutex> lk(c.mu);
-        c.pending[st].push_back(PendingReduce{ws, G, nvec, N, gy, outs});
+        c.pending[st].push_back(PendingReduce{ws, G, nvec, N, 1, outs});
         return;
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nvec * N + 255) / 256, gy), dim3(256), 0, st, ws, G, nvec, N, outs);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nvec * N + 31) / 32), dim3(256), 0, st, ws, G, nvec, N, outs);
 }
 
 extern "C" int xl_set_deferred_reduce(int on) {
@@ -1455,16 +1479,22 @@ extern "C" int xl_flush_reductions_on(void* producer_stream, void* launch_stream
         if (it == c.pending.end() || it->second.empty()) return XL_OK;
         todo.swap(it->second);
     }
-    for (size_t i = 0; i < todo.size(); i += kBatch) {
+    for (size_t i = 0; i < todo.size();) {
         BatchArgs a;
-        a.n = (int)std::min<size_t>(kBatch, todo.size() - i);
-        int gx = 1, gy = 1;
-        for (int j = 0; j < a.n; ++j) {
-            a.e[j] = todo[i + j];
-            gx = std::max(gx, (a.e[j].nvec * a.e[j].N + 255) / 256);
-            gy = std::max(gy, a.e[j].gy);
+        a.n = 0;
+        int gx = 1;
+        // up to kBatch entries per launch, in the order they were registered; an entry that adds into an output some entry of this
+        // batch already adds into (the q/k/v bias gradient of a shared cross-attention: two attention backwards, one tensor) opens
+        // the next launch -- launches on a stream are ordered, so the sums are added in registration order, every run
+        while (i < todo.size() && a.n < kBatch) {
+            bool alias = false;
+            for (int j = 0; j < a.n && !alias; ++j) alias = reduce_outputs_alias(a.e[j], todo[i]);
+            if (alias) break;
+            a.e[a.n++] = todo[i];
+            gx = std::max(gx, (todo[i].nvec * todo[i].N + 31) / 32);
+            ++i;
         }
-        hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3(gx, gy, a.n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3(gx, 1, a.n), dim3(256), 0, st, a);
     }
     XL_CHECK_LAUNCH();
     return XL_OK;

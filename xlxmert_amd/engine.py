@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from .ops import EPI_DGELU, EPI_GELU, EPI_GELU_DG, EPI_MULAUX, EPI_NONE, EPI_RESIDUAL, EPI_ROWMAX, EPI_TANH
+from .ops import EPI_DGELU, EPI_GELU, EPI_GELU_DG, EPI_MULAUX, EPI_NONE, EPI_RESIDUAL, EPI_ROWMAX, EPI_TANH, GemmCall
 
 
 class _Att:
@@ -105,16 +105,23 @@ class SelfAttBlock:
         return e.kmask, {}
 
     def fwd(self, x, y):
+        self.e.run_steps(self.fwd_steps(x, y))
+
+    def fwd_steps(self, x, y):
+        """the forward as a generator: every dense contraction is YIELDED (ops.GemmCall) instead of launched, everything else is
+        issued as the generator advances -- Engine.run_steps launches each yielded call, Engine.run_pair advances a visual and a
+        language block of this class in lock step and launches their contractions two at a time (xl_gemm_pair)."""
         e, p, d, M = self.e, self.p, self.e.d, self.M
-        ops = e.ops
-        ops.block = self.tag
+        ops, tag = e.ops, self.tag
         qkv, ctx, z = self.qkv[:M], self.ctx[:M], self.z[:M]
-        ops.gemm(x, p.wqkv, qkv, p.bqkv, None, None, M, 3 * d, d, d, d, 3 * d)
+        yield GemmCall(x, p.wqkv, qkv, p.bqkv, None, None, M, 3 * d, d, d, d, 3 * d, tag=tag)
         km, vl = self._att_args()
+        ops.block = tag
         ops.sdpa_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], km, ctx, self.lse, e.B, e.H, self.n, self.n,
                      e.dh, 3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), **vl)
-        ops.gemm(ctx, p.wo, z, p.bo, x, None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
-                 p_drop=e.p_hid, seed=e.seed(self.site + 1))
+        yield GemmCall(ctx, p.wo, z, p.bo, x, None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
+                       p_drop=e.p_hid, seed=e.seed(self.site + 1), tag=tag)
+        ops.block = tag
         ops.layernorm_fwd(z, p.g, p.b, y, self.mean, self.rstd, M, d, e.eps)
         self.x = x
 
@@ -130,25 +137,29 @@ class SelfAttBlock:
         return out
 
     def bwd(self, dy, dx):
+        self.e.run_steps(self.bwd_steps(dy, dx))
+
+    def bwd_steps(self, dy, dx):
         e, p, d, M = self.e, self.p, self.e.d, self.M
-        ops = e.ops
-        ops.block = self.tag
+        ops, tag = e.ops, self.tag
+        ops.block = tag
         e.wgrad_sync()                  # the previous block's weight-gradient GEMMs still read the shared scratch
         qkv, ctx, z = self.qkv[:M], self.ctx[:M], self.z[:M]
         dz = e.tmp("dz", M, d)
         dzm = e.ln_bwd_dense(dy, z, p.g, self.mean, self.rstd, dz, p.gg, p.gb, p.gbo, M, d, self.site + 1)
         e.wgrad_defer(dzm, ctx, p.gwo, d, d, M, d, d, d)
         dctx = e.tmp("dctx", M, d)
-        ops.gemm(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
+        yield GemmCall(dzm, p.wo, dctx, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0, tag=tag)
         dqkv = e.tmp("dqkv", M, 3 * d)
         km, vl = self._att_args()
+        ops.block = tag
         ops.sdpa_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                      e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws, **vl)      # + d(b_q | b_k | b_v)
         e.wgrad_defer(dqkv, self.x, p.gwqkv, 3 * d, d, M, 3 * d, d, d)
         e.wgrad_flush(pair=True)        # this layer's four weight gradients: launched together with the next layer's
-        ops.gemm(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
-                 epilogue=EPI_RESIDUAL)
+        yield GemmCall(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+                       epilogue=EPI_RESIDUAL, tag=tag)
 
 
 class FFNBlock:
@@ -177,22 +188,29 @@ class FFNBlock:
         return self.e.ML if self.lang else self.e.MV
 
     def fwd(self, x, y):
+        self.e.run_steps(self.fwd_steps(x, y))
+
+    def fwd_steps(self, x, y):
+        """(a generator of the block's dense contractions: see SelfAttBlock.fwd_steps)"""
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
-        ops = e.ops
-        ops.block = self.tag
+        ops, tag = e.ops, self.tag
         pre, h, z = self.pre[:M], self.h[:M], self.z[:M]
         # self.pre holds gelu'(pre-activation): erf and exp(-x^2/2) are in registers in the forward epilogue anyway, and the
         # backward epilogue becomes a multiply (no second erf + exp per element of the [M, dff] gradient)
-        ops.gemm(x, self.w1, h, self.b1, None, pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU_DG)
-        ops.gemm(h, self.w2, z, self.b2, x, None, M, d, dff, dff, dff, d, ldr=d, epilogue=EPI_RESIDUAL,
-                 p_drop=e.p_hid, seed=e.seed(self.site))
+        yield GemmCall(x, self.w1, h, self.b1, None, pre, M, dff, d, d, d, dff, ldx=dff, epilogue=EPI_GELU_DG, tag=tag)
+        yield GemmCall(h, self.w2, z, self.b2, x, None, M, d, dff, dff, dff, d, ldr=d, epilogue=EPI_RESIDUAL,
+                       p_drop=e.p_hid, seed=e.seed(self.site), tag=tag)
+        ops.block = tag
         ops.layernorm_fwd(z, self.g, self.b, y, self.mean, self.rstd, M, d, e.eps)
         self.x = x
 
     def bwd(self, dy, dx):
+        self.e.run_steps(self.bwd_steps(dy, dx))
+
+    def bwd_steps(self, dy, dx):
         e, d, dff, M = self.e, self.e.d, self.e.dff, self.M
-        ops = e.ops
-        ops.block = self.tag
+        ops, tag = e.ops, self.tag
+        ops.block = tag
         e.wgrad_sync()
         pre, h, z = self.pre[:M], self.h[:M], self.z[:M]
         # own scratch names: the two weight gradients registered here are launched together with the attention block's
@@ -202,11 +220,11 @@ class FFNBlock:
                              tmp_name="f_dzm")
         e.wgrad_defer(dzm, h, self.gw2, d, dff, M, d, dff, dff)
         dpre = e.tmp("dpre", M, dff)
-        ops.gemm(dzm, self.w2, dpre, None, None, pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
-                 epilogue=EPI_MULAUX, colsum=self.gb1, ws=e.ws)      # d(b1) = column sums of dpre, in the same epilogue
+        yield GemmCall(dzm, self.w2, dpre, None, None, pre, M, dff, d, d, dff, dff, ldx=dff, a_kmajor=1, b_kmajor=0,
+                       epilogue=EPI_MULAUX, colsum=self.gb1, ws=e.ws_gemm, tag=tag)      # d(b1) = column sums of dpre, in the same epilogue
         e.wgrad_defer(dpre, self.x, self.gw1, dff, d, M, dff, d, d)
-        ops.gemm(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
-                 epilogue=EPI_RESIDUAL)
+        yield GemmCall(dpre, self.w1, dx, None, dz, None, M, d, dff, dff, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
+                       epilogue=EPI_RESIDUAL, tag=tag)
 
 
 class CrossAttBlock:
@@ -619,6 +637,10 @@ class Engine:
         self.H, self.dh = cfg.num_attention_heads, cfg.head_dim
         self.P = cfg.visual_pos_dim
         self.pack_lang = (os.environ.get("XL_PACK_LANG", "1") != "0") if pack_lang is None else bool(pack_lang)
+        # visual / language sub-blocks of one shape class in lock step on one stream, contractions two per launch (run_pair);
+        # XL_PAIR_BLOCKS=0: every language-side block on the language stream, as in rounds 1-4
+        self.pair_blocks = os.environ.get("XL_PAIR_BLOCKS", "1") != "0"
+        self.pair_side = os.environ.get("XL_PAIR_SIDE", "1") != "0"       # ... the language block's own kernels on the language stream
         self.packed = False                 # this batch runs packed (set_inputs: pack_lang and a usable attention mask)
         self.MLd, self.MV = B * L, B * V    # dense language rows / visual rows
         # language row CAPACITY of every buffer (a packed row count is rounded up to the row tile) and the ACTIVE count
@@ -745,7 +767,7 @@ class Engine:
         self._ws_len = {"v": ops.workspace_floats(max(3 * d, self.dff, self.F)), "l": ops.workspace_floats(max(3 * d, self.dff))}
         self._ws, self._ws_wide = {}, None
         self._ws_i = {"v": 0, "l": 0}
-        self._red_gens = {"v": set(), "l": set()}      # generations with column-sum partials not yet combined
+        self._red_gens = {"v": set(), "l": set()}      # (generation, producing stream) with column-sum partials not yet combined
         self._gen_guard = {"v": {}, "l": {}}           # generation -> event after the companion-stream launch that read / combined it
         self._guard_ring, self._guard_next = {"v": [], "l": []}, {"v": 0, "l": 0}
         self._deferred = False
@@ -807,8 +829,40 @@ class Engine:
         i = self._ws_i[t]
         assert i < self._WS_REGIONS, "too many column reductions in one scratch generation"
         self._ws_i[t] = i + 1
-        self._red_gens[t].add(self._gen[t])
+        self._note_partials(t)
         return self._ws_region(t, self._gen[t], i)
+
+    def _cur_handle(self):
+        return torch.cuda.current_stream().cuda_stream if self.dev.type == "cuda" else 0
+
+    # a contraction with fused column sums that run_pair holds back is LAUNCHED on the pair's stream, whatever stream its block's
+    # generator was advanced on: the library files its pending second stage under the launching stream
+    _gemm_handle = None
+
+    @property
+    def ws_gemm(self):
+        """ws for the fused column sums of a contraction yielded to run_steps / run_pair"""
+        h, self._note_handle = self._note_handle, self._gemm_handle
+        try:
+            return self.ws
+        finally:
+            self._note_handle = h
+
+    _note_handle = None
+
+    def _note_partials(self, t):
+        """lane t has column-sum partials of its current scratch generation waiting for their combine, filed by the library under
+        the stream that launched the producer (a lane's kernels may run on either compute stream: run_pair)"""
+        h = self._note_handle if self._note_handle is not None else self._cur_handle()
+        self._red_gens[t].add((self._gen[t], h))
+
+    def _combined(self, handle, ev=None):
+        """everything pending from the stream `handle` has been combined (ev: by a launch on a companion stream, done when ev is)"""
+        for t in ("v", "l"):
+            for g, h in [x for x in self._red_gens[t] if x[1] == handle]:
+                if ev is not None:
+                    self._gen_guard[t].setdefault(g, []).append(ev)
+                self._red_gens[t].discard((g, h))
 
     def ws_wide(self, name, N):
         """workspace of a column sum wider than dff (the 10k-codebook head's, the MLM decoder's, the answer head's): one per user,
@@ -818,7 +872,7 @@ class Engine:
         if name not in self._ws_wide:
             self._ws_wide[name] = self.f32(self.ops.workspace_floats(N))
         if self._deferred:
-            self._red_gens[self._tag].add(self._gen[self._tag])
+            self._note_partials(self._tag)
         return self._ws_wide[name]
 
     def defer_reductions(self, on):
@@ -836,7 +890,7 @@ class Engine:
         """combine everything pending from the current stream, on the current stream (in order behind the producers)"""
         if self._deferred:
             self.ops.flush_reductions()
-            self._red_gens[self._tag].clear()
+            self._combined(self._cur_handle())      # (the library combines everything pending from this stream, whichever lane's)
 
     def _flush_if_reporting(self):
         """per-layer combine on the CURRENT stream -- only when somebody is told that the layer's gradients are final (gradient
@@ -862,6 +916,75 @@ class Engine:
 
     def lang_stream(self):
         return Engine._LangStream(self)
+
+    class _Lane:
+        """bookkeeping lane ("v" visual / "l" language: backward scratch sets, column-sum workspace regions, pending weight
+        gradients and their companion stream) WITHOUT a change of stream: a language-side block of a pair runs on the stream
+        of its visual partner but keeps the language lane's buffers and weight-gradient grouping."""
+
+        def __init__(self, eng, tag):
+            self.e, self.tag = eng, tag
+
+        def __enter__(self):
+            self.prev, self.e._tag = self.e._tag, self.tag
+
+        def __exit__(self, *a):
+            self.e._tag = self.prev
+
+    def lane(self, tag):
+        return Engine._Lane(self, tag)
+
+    def run_steps(self, steps):
+        """a block's generator (SelfAttBlock / FFNBlock fwd_steps, bwd_steps) on its own: every yielded contraction is one launch"""
+        ops = self.ops
+        for c in steps:
+            ops.block = c.tag
+            ops.gemm(*c.a, **c.kw)
+
+    def run_pair(self, steps_v, steps_l):
+        """a VISUAL-side and a LANGUAGE-side block of one class (the self-attention / FFN sub-blocks of a cross-modality layer,
+        HF:417-449, or a layer of each single-modality stack, HF:516-529) in lock step on the current stream: the two generators
+        are advanced alternately -- each issues its own LayerNorm / attention-core / bookkeeping calls, the language one inside
+        the language lane -- and every pair of contractions they yield goes out as ONE xl_gemm_pair launch: the language side's
+        39 row tiles ride in the CUs that the visual side's 64 x (3 | 9 | 12) tiles leave idle in their last round, instead of
+        holding 39-156 CUs at a tenth of the matrix rate on a stream of their own."""
+        ops = self.ops
+        side = self.side if self.pair_side else None
+        self._gemm_handle = self._cur_handle()          # (fused column sums of a yielded contraction: filed under THIS stream)
+        try:
+            while True:
+                # The language block's own kernels (LayerNorm, attention core: ~3300 rows, 5-25 us each) go to the language stream,
+                # beside the visual block's on this one -- queued one behind the other they added ~100 us per layer to the chain
+                # (measured: +0.85 ms per step, more than the paired contractions save).  The language stream continues behind the
+                # pair launch just queued; this stream waits for it only if the block issued anything before its next contraction.
+                issued = False
+                if side is not None:
+                    self.fork()
+                    with self.lang_stream():
+                        n0 = ops.ncalls
+                        cl = next(steps_l, None)
+                        issued = ops.ncalls != n0
+                else:
+                    with self.lane("l"):
+                        cl = next(steps_l, None)
+                cv = next(steps_v, None)
+                if issued:
+                    self.join()
+                if cv is None and cl is None:
+                    return
+                if cv is not None and cl is not None:
+                    ops.block = f"{cv.tag}+{cl.tag}"
+                    ops.gemm_pair(cv, cl)
+                else:
+                    c = cv if cv is not None else cl
+                    ops.block = c.tag
+                    ops.gemm(*c.a, **c.kw)
+        finally:
+            self._gemm_handle = None
+
+    def _lang_side(self):
+        """context of the language lane's own work in a paired section: the language stream (pair_side) or this stream"""
+        return self.lang_stream() if (self.pair_side and self.side is not None) else self.lane("l")
 
     # Set by a trainer whose optimizer pass runs behind the step on its own stream (trainer.PretrainStep overlap_optimizer): called
     # with the key of a parameter group right before the forward first reads it, on the stream that reads it.
@@ -921,7 +1044,9 @@ class Engine:
 
     def _advance_gen(self, tag):
         g = (self._gen[tag] + 1) % self.NGEN
-        if g in self._red_gens[tag]:            # its column-sum partials were never combined (no launch since): do it now, in order
+        stale = [h for gg, h in self._red_gens[tag] if gg == g]
+        if stale:                               # its column-sum partials were never combined (no launch since): do it now, in order
+            assert stale == [self._cur_handle()], "pending column sums of this lane's next scratch set belong to another stream"
             self.flush_reductions()
         self._gen[tag] = g
         self._ws_i[tag] = 0
@@ -995,12 +1120,10 @@ class Engine:
         if dw is not None:
             ev = self._guard_event(tag)
             self.ops.event_record(ev, dw)
-            gens = {pr[10] for pr in probs}
-            if ride:
-                gens |= self._red_gens[tag]
-                self._red_gens[tag].clear()
-            for g in gens:
-                self._gen_guard[tag][g] = ev
+            for g in {pr[10] for pr in probs}:
+                self._gen_guard[tag].setdefault(g, []).append(ev)
+            if ride:            # everything pending from the producing stream was combined behind this launch, whichever lane's
+                self._combined(self._cur_handle(), ev)
         if not force:
             self._advance_gen(tag)
 
@@ -1008,8 +1131,7 @@ class Engine:
         """the current stream is about to write the current scratch generation: wait for the companion-stream launch that read it
         (weight gradients) or combined its column-sum partials, if there was one since the generation was last waited for."""
         tag = self._tag
-        ev = self._gen_guard[tag].pop(self._gen[tag], None)
-        if ev is not None:
+        for ev in self._gen_guard[tag].pop(self._gen[tag], ()):
             self.ops.stream_wait(ev, torch.cuda.current_stream())
 
     def wgrad_sync_all(self):
@@ -1247,11 +1369,33 @@ class Engine:
         with Engine._Seeded(self):
             return self._encoder_forward(want_pooled)
 
-    def _language_stack_forward(self):
-        """embeddings + l_layers self-attention layers (HF:516-521); leaves the language rows of the first cross layer's input
-        in the language rows of X[0]."""
+    def _stack_pairs(self):
+        """layers of the two single-modality stacks that run as pairs (run_pair): the LAST min(l_layers, r_layers) of each --
+        visual layer r - n + k with language layer l - n + k -- so that the longer stack's first layers (9 language against 5
+        visual: layers 0-3) run ahead on the other stream, beside the feature encoder / the embeddings and the previous step's
+        optimizer pass, and in the backward pass behind the pairs, beside the feature encoder's backward."""
+        if not self.pair_blocks:
+            return []
+        n = min(self.cfg.l_layers, self.cfg.r_layers)
+        return [(self.cfg.r_layers - n + k, self.cfg.l_layers - n + k) for k in range(n)]
+
+    def _lang_layer_io(self, i):
+        """(input, attention-block output, output) of language layer i (layer 0 reads the embeddings: _language_stack_forward)"""
+        ML = self.ML
+        x = (self.emb_p[:ML] if self.packed else self.emb_y) if i == 0 else self.lang_out[i - 1][:ML]
+        y = self.lr(self.X[0]) if i == self.cfg.l_layers - 1 else self.lang_out[i][:ML]
+        return x, self.lang_mid[i][:ML], y
+
+    def _vis_layer_io(self, i):
+        x = self.vis0 if i == 0 else self.vis_out[i - 1]
+        y = self.vr(self.X[0]) if i == self.cfg.r_layers - 1 else self.vis_out[i]
+        return x, self.vis_mid[i], y
+
+    def _language_stack_forward(self, n_layers=None):
+        """embeddings + the first n_layers (default: all l_layers) self-attention layers (HF:516-521); the last layer leaves the
+        language rows of the first cross layer's input in the language rows of X[0]."""
         cfg, st, ops, d, ML = self.cfg, self.store, self.ops, self.d, self.ML
-        X0 = self.X[0]
+        n_layers = cfg.l_layers if n_layers is None else n_layers
         e = "bert.embeddings"
         self._pr("emb")
         emb = getattr(self, "embeds_mode", False)
@@ -1266,13 +1410,11 @@ class Engine:
         if self.packed:                 # the real tokens' rows, packed (zero rows in the tail that pads to the row tile)
             x = self.emb_p[:ML]
             ops.gather_rows(self.emb_y, self.lrows, x, ML, d, d, d)
-        for i, (sa, ffn) in enumerate(self.lang_layers):
+        for i, (sa, ffn) in enumerate(self.lang_layers[:n_layers]):
             self._pr(("lang", i))
-            mid = self.lang_mid[i][:ML]
+            x, mid, y = self._lang_layer_io(i)
             sa.fwd(x, mid)
-            y = self.lr(X0) if i == cfg.l_layers - 1 else self.lang_out[i][:ML]
             ffn.fwd(mid, y)
-            x = y
 
     def _encoder_forward(self, want_pooled=True):
         cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
@@ -1283,9 +1425,12 @@ class Engine:
         # language stack (embeddings + l_layers self-attention layers: it never sees the visual tokens) -- it still sits in
         # the language rows of X[0] from the loop's first pass (no later layer writes there), so the later passes skip it.  Exact.
         skip_lang = getattr(self, "_reuse_lang_stack", False) and self.p_hid == 0 and self.p_attn == 0
+        pairs = [] if skip_lang else self._stack_pairs()
+        n_lang_alone = cfg.l_layers - len(pairs)
+        n_vis_alone = cfg.r_layers - len(pairs)
         if not skip_lang:
-            with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream
-                self._language_stack_forward()
+            with self.lang_stream():            # ---- language stack (HF:516-521) on the side stream: all of it, or the layers
+                self._language_stack_forward(n_lang_alone)      # that have no visual partner (_stack_pairs)
         # ---- visual feature encoder + relational stack (HF:513, 524-529) on the main stream
         self._pr("visn")
         if self.use_codebook:
@@ -1301,18 +1446,28 @@ class Engine:
                         self.vis0, *self.vn_stats, MV, d, self.P, self.eps)
         if self.p_hid > 0:              # HF:475
             ops.dropout(self.vis0, self.vis0, MV, d, d, d, self.p_hid, self.seed(1))
-        x = self.vis0
-        for i, (sa, ffn) in enumerate(self.vis_layers):
+        for i, (sa, ffn) in enumerate(self.vis_layers[:n_vis_alone]):
             self._pr(("vis", i))
-            sa.fwd(x, self.vis_mid[i])
-            y = self.vr(X0) if i == cfg.r_layers - 1 else self.vis_out[i]
-            ffn.fwd(self.vis_mid[i], y)
-            x = y
+            x, mid, y = self._vis_layer_io(i)
+            sa.fwd(x, mid)
+            ffn.fwd(mid, y)
         self.join()
+        for iv, il in pairs:                # ---- a visual and a language layer per step, their contractions two per launch
+            self._pr(("vis", iv))
+            self._pr(("lang", il))
+            (sa_v, ffn_v), (sa_l, ffn_l) = self.vis_layers[iv], self.lang_layers[il]
+            xv, mv, yv = self._vis_layer_io(iv)
+            xl, ml, yl = self._lang_layer_io(il)
+            self.run_pair(sa_v.fwd_steps(xv, mv), sa_l.fwd_steps(xl, ml))
+            self.run_pair(ffn_v.fwd_steps(mv, yv), ffn_l.fwd_steps(ml, yl))
         for i, blk in enumerate(self.x_layers):
             Xi, Y, S, Xo = self.X[i], self.XY[i], self.XS[i], self.X[i + 1]
             self._pr(("x", i))              # (the language stream forks from this stream after the wait and inherits it)
             blk["cross"].fwd(Xi, Y)
+            if self.pair_blocks and blk["lang_on"] and blk["vis_on"]:
+                self.run_pair(blk["sa_v"].fwd_steps(self.vr(Y), self.vr(S)), blk["sa_l"].fwd_steps(self.lr(Y), self.lr(S)))
+                self.run_pair(blk["ffn_v"].fwd_steps(self.vr(S), self.vr(Xo)), blk["ffn_l"].fwd_steps(self.lr(S), self.lr(Xo)))
+                continue
             if blk["lang_on"]:
                 self.fork()
                 with self.lang_stream():
@@ -1790,29 +1945,61 @@ class Engine:
         for i in reversed(range(cfg.x_layers)):
             blk = self.x_layers[i]
             lang_on = blk["lang_on"] and (have_lang_grad or i < cfg.x_layers - 1)
-            if blk["lang_on"]:
-                if not lang_on:
-                    raise RuntimeError("engine built with need_lang=True needs d(language_output)")
-                self.fork()
-                with self.lang_stream():
-                    blk["ffn_l"].bwd(L_(GA), L_(GB))
-                    blk["sa_l"].bwd(L_(GB), L_(GA))
-                    if i == 0:                  # the language side of the cross layers is reported by the main stream (below):
-                        self.wgrad_flush(pair=True, force=True)      # nothing of it may stay held into the language stack
-                    if self.grad_ready is not None:     # (the main stream reports this layer, language side included)
-                        self._flush_if_reporting()
-                        self.wgrad_sync_all()
-            if blk["vis_on"]:
-                blk["ffn_v"].bwd(V_(GA), V_(GB))
-                blk["sa_v"].bwd(V_(GB), V_(GA))
-            if blk["lang_on"]:
-                self.join()
+            if blk["lang_on"] and not lang_on:
+                raise RuntimeError("engine built with need_lang=True needs d(language_output)")
+            if self.pair_blocks and blk["lang_on"] and blk["vis_on"]:
+                # both sides on this stream, their dX contractions two per launch; the language side keeps its own lane (scratch
+                # sets, column-sum regions, weight-gradient grouping on its companion stream)
+                self.run_pair(blk["ffn_v"].bwd_steps(V_(GA), V_(GB)), blk["ffn_l"].bwd_steps(L_(GA), L_(GB)))
+                self.run_pair(blk["sa_v"].bwd_steps(V_(GB), V_(GA)), blk["sa_l"].bwd_steps(L_(GB), L_(GA)))
+                if i == 0 or self.grad_ready is not None:
+                    self.fork()
+                    with self._lang_side():
+                        if i == 0:              # the language side of the cross layers is reported by the main range (below):
+                            self.wgrad_flush(pair=True, force=True)      # nothing of it may stay held into the language stack
+                        if self.grad_ready is not None:
+                            self._flush_if_reporting()
+                            self.wgrad_sync_all()
+                    if self.grad_ready is not None:
+                        self.join()
+            else:
+                if blk["lang_on"]:
+                    self.fork()
+                    with self.lang_stream():
+                        blk["ffn_l"].bwd(L_(GA), L_(GB))
+                        blk["sa_l"].bwd(L_(GB), L_(GA))
+                        if i == 0:                  # the language side of the cross layers is reported by the main stream (below):
+                            self.wgrad_flush(pair=True, force=True)      # nothing of it may stay held into the language stack
+                        if self.grad_ready is not None:     # (the main stream reports this layer, language side included)
+                            self._flush_if_reporting()
+                            self.wgrad_sync_all()
+                if blk["vis_on"]:
+                    blk["ffn_v"].bwd(V_(GA), V_(GB))
+                    blk["sa_v"].bwd(V_(GB), V_(GA))
+                if blk["lang_on"]:
+                    self.join()
             blk["cross"].bwd(GA, GB)
             self._ready(f"bert.encoder.x_layers.{i}.")
             GA, GB = GB, GA
+        # ---- the two single-modality stacks: the paired layers first (a visual and a language layer per step on this stream) ...
+        pairs = self._stack_pairs()
+        for iv, il in reversed(pairs):
+            (sa_v, ffn_v), (sa_l, ffn_l) = self.vis_layers[iv], self.lang_layers[il]
+            self.run_pair(ffn_v.bwd_steps(V_(GA), V_(GB)), ffn_l.bwd_steps(L_(GA), L_(GB)))
+            self.run_pair(sa_v.bwd_steps(V_(GB), V_(GA)), sa_l.bwd_steps(L_(GB), L_(GA)))
+            if iv == 0 and self.grad_ready is not None:
+                self.wgrad_flush(pair=True, force=True)         # (see the unpaired visual stack below)
+            self._ready(f"bert.encoder.r_layers.{iv}.")
+            if self.grad_ready is not None:
+                self.fork()                 # (the language lane's fused column sums were combined on this stream: _ready)
+                with self._lang_side():
+                    self._flush_if_reporting()
+                    self._ready_lang(st.range_of(f"bert.encoder.layer.{il}.")[1])
+        n_lang_alone, n_vis_alone = cfg.l_layers - len(pairs), cfg.r_layers - len(pairs)
+        # ---- ... then what is left of the longer stack beside the feature encoder's / the embeddings' backward
         self.fork()
         with self.lang_stream():            # ---- language stack + embeddings (HF:191-214) on the side stream
-            for i in reversed(range(cfg.l_layers)):
+            for i in reversed(range(n_lang_alone)):
                 sa, ffn = self.lang_layers[i]
                 ffn.bwd(L_(GA), L_(GB))
                 sa.bwd(L_(GB), L_(GA))
@@ -1842,7 +2029,7 @@ class Engine:
             self._ready_lang(st.language_range()[1], flush=True)
             self.wgrad_sync_all()
         # ---- relational (visual) stack
-        for i in reversed(range(cfg.r_layers)):
+        for i in reversed(range(n_vis_alone)):
             sa, ffn = self.vis_layers[i]
             ffn.bwd(V_(GA), V_(GB))
             sa.bwd(V_(GB), V_(GA))

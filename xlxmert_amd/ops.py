@@ -26,6 +26,14 @@ def xl_dtype(torch_dtype):
     raise XlError(f"unsupported dtype {torch_dtype}: the HIP path computes in float32 or bfloat16")
 
 
+class GemmCall:
+    """arguments of one HipOps.gemm call, held back so that a caller can hand two of them to gemm_pair (engine: paired blocks)"""
+    __slots__ = ("a", "kw", "tag")
+
+    def __init__(self, *a, tag=None, **kw):
+        self.a, self.kw, self.tag = a, kw, tag          # tag: label of the issuing model block (HipOps.block, bench.py's per-block table)
+
+
 class HipOps:
     """One instance per compute dtype."""
 
@@ -33,6 +41,7 @@ class HipOps:
         self.lib = get_lib()
         self.dtype = dtype
         self.dt = xl_dtype(dtype)
+        self.ncalls = 0              # C-ABI calls issued through this object (engine.run_pair: did a block's step launch anything?)
         self.block = ""              # label of the model block issuing the current calls (set by the engine; bench.py's per-block table)
         # this object's library context (include/xlxmert_hip.h xl_ctx_*): step-seed pointer, deferred reductions, slab
         # workspaces and kernel switches set through it are invisible to every other HipOps of the process
@@ -60,6 +69,7 @@ class HipOps:
         if HipOps.bound() != self.ctx:
             self.lib.call("xl_ctx_bind", self.ctx)
             HipOps._tls.ctx = self.ctx
+        self.ncalls += 1
         return self.lib.call(name, *args)
 
     def rebind(self):
@@ -177,6 +187,35 @@ class HipOps:
                       M, N, K, lda, ldb, ldc, ldr, ldx, int(a_kmajor), int(b_kmajor), self.dt,
                       XL_F32 if out_f32 else self.dt, epilogue, float(alpha), int(accumulate), float(p_drop),
                       int(seed), self._p(colsum), self._p(ws if colsum is not None else None), self._stream())
+
+    @staticmethod
+    def _gemm_args(A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, ldr=0, ldx=0, a_kmajor=1, b_kmajor=1,
+                   out_f32=False, epilogue=EPI_NONE, alpha=1.0, accumulate=0, p_drop=0.0, seed=0, colsum=None, ws=None):
+        return dict(A=A, B=B, C=C, bias=bias, residual=residual, aux=aux, M=M, seed=int(seed), colsum=colsum, ws=ws,
+                    shared=(N, K, lda, ldb, ldc, ldr, ldx, int(a_kmajor), int(b_kmajor), bool(out_f32), epilogue, float(alpha),
+                            int(accumulate), float(p_drop)))
+
+    def gemm_pair(self, c0, c1):
+        """two gemm() calls, c = GemmCall(*args, **kwargs) each, of one shape class (same N, K, leading dimensions, layouts,
+        epilogue, alpha, dropout probability; bf16 output, no accumulation): ONE launch when the library can pair them
+        (xl_gemm_pair), the two launches otherwise.  Same results either way."""
+        g0, g1 = self._gemm_args(*c0.a, **c0.kw), self._gemm_args(*c1.a, **c1.kw)
+        sh = g0["shared"]
+        if sh != g1["shared"] or sh[9] or sh[12]:
+            self.gemm(*c0.a, **c0.kw)
+            self.gemm(*c1.a, **c1.kw)
+            return
+        N, K, lda, ldb, ldc, ldr, ldx, ak, bk, _, epi, alpha, _, p_drop = sh
+        per = []
+        for g in (g0, g1):
+            cs = g["colsum"]
+            per += [self._p(g["A"]), self._p(g["B"]), self._p(g["C"]), self._p(g["bias"]), self._p(g["residual"]), self._p(g["aux"]),
+                    g["M"], g["seed"], self._p(cs), self._p(g["ws"] if cs is not None else None)]
+        self._call("xl_gemm_pair", *per, N, K, lda, ldb, ldc, ldr, ldx, ak, bk, self.dt, self.dt, epi, alpha, p_drop, self._stream())
+
+    def set_gemm_pair(self, on):
+        """two-problem launches (xl_gemm_pair): 1 when eligible (default), 0 always two launches."""
+        self._call("xl_set_gemm_pair", int(on))
 
     def gemm_wgrad_group(self, problems, overwrite_mask=0):
         """problems: list of (dY [K, M], X [K, N], dW [M, N] fp32, M, N, K, lda, ldb, ldc): dW += dY^T X, one launch; bit i of
