@@ -1301,17 +1301,55 @@ def test_two_library_contexts_interleaved_in_one_process():
         assert torch.equal(codes, codes_alone)
     tr.sync()
     for a, b in zip(alone, mixed):
-        assert torch.allclose(a, b, rtol=2e-5, atol=1e-6), (a, b)        # (fp32 atomics: not bit-identical run to run)
-    # (the last step's gradient norm of a bf16 model four updates in: summation-order noise of the fp32 atomics is amplified by bf16
-    #  rounding flips of the updated weights -- 3.3e-4 relative seen once in ~15 runs, 1e-5..1e-4 otherwise; a context leaking
-    #  into the other -- wrong kernel switch, wrong step-seed pointer -- moves it by O(1))
-    # Round 4 (tools/race_probe.py: the same four steps 40 times in one process, with and without random stalls on the side streams):
-    # the outcome is BIMODAL -- deviation ~1e-8, or exactly 3.32e-4 on the norm / 1.92e-5 on the parameters, in ~45 % of the runs whatever
-    # the stalls.  Its source after step 1 is fp32 summation order at the 1e-7 level in two column sums of the feature encoder's backward
-    # (reduce slices added by atomics: two orders), which flips the bf16 rounding of a few updated weights -- not a missing stream
-    # dependency.  The weight gradients themselves are order-free here (slabs summed in slice order).
-    assert abs(tr.grad_norm() - alone_n) < 2e-3 * alone_n
-    assert (tr.store.master - alone_p).abs().max().item() < 1e-4
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-6), (a, b)        # (the loss scalars are summed by one fp32 atomic per block)
+    # Round 4 (tools/race_probe.py) traced a BIMODAL run-to-run deviation of this comparison -- 1e-8, or 3.3e-4 on the norm -- to fp32
+    # summation order in two column sums of the feature encoder's backward: the second stage of every two-stage column reduction
+    # added its G-slices with atomics.  Round 5: that combine sums the slices in a fixed order (csrc/rowops.hip reduce_partials_entry),
+    # the embedding scatter has one writer per table row, and the K-split weight gradients go through slabs here -- every gradient
+    # is reproducible, so the two runs agree to the last bit (test_training_step_is_bit_reproducible is the direct statement).
+    assert abs(tr.grad_norm() - alone_n) <= 2e-5 * alone_n
+    assert torch.equal(tr.store.master, alone_p)
+
+
+@pytest.mark.parametrize("plan", [False, True])
+def test_training_step_is_bit_reproducible(plan):
+    """The same three training steps (bf16, dropout on, four streams, deferred reductions, grouped weight gradients, overwrite
+    mode, AdamW behind the step) twice in one process from the same state: parameters, both Adam moments and the gradient norm must
+    be BIT-identical.  What makes that true: column sums combine their partial slabs in a fixed order, the embedding scatter has
+    one writer per table row, the position table one writer per element, xl_sumsq adds its block partials in index order, and
+    K-split weight gradients meet in slabs summed in slice order (xl_set_gemm_wgrad_slabs(1): opt-in, 1-3 % slower than fp32
+    atomics, which is why the DEFAULT keeps atomics for the few K-split launches).  The two loss scalars are the exception: one fp32
+    atomic per block -- compared to 1e-5."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig(vocab_size=200, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        max_position_embeddings=32, visual_feat_dim=64, num_clusters=96, l_layers=3, x_layers=2, r_layers=2)
+    g = torch.Generator().manual_seed(3)
+    cents = torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu()
+    B = 16
+    batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=70 + i).items()} for i in range(3)]
+
+    def run():
+        tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=5, lr=1e-3, total_steps=100, train_dropout=True,
+                          plan=plan, drop_grads=True, overlap_optimizer=True)
+        tr.set_centroids(cents)
+        tr.ops.set_gemm_wgrad_slabs(1)
+        losses, params = [], []
+        for i in range(6):
+            losses.append(tr.step(batches[i % 3]).clone())
+            tr.sync()
+            params.append(tr.store.master.clone())
+        st = tr.store
+        return losses, st.master.clone(), st.exp_avg.clone(), st.exp_avg_sq.clone(), tr.grad_norm(), params
+
+    a, b = run(), run()
+    for i, (x, y) in enumerate(zip(a[5], b[5])):
+        assert torch.equal(x, y), ("parameters after step", i, (x - y).abs().max().item(), (x != y).float().mean().item())
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7), (i, (x - y).abs().max().item(), x, y)
+    assert a[4] == b[4], (a[4], b[4])
+    for name, x, y in (("master", a[1], b[1]), ("exp_avg", a[2], b[2]), ("exp_avg_sq", a[3], b[3])):
+        assert torch.equal(x, y), (name, (x - y).abs().max().item(), (x != y).float().mean().item())
 
 
 @pytest.mark.parametrize("plan", [False, True])

@@ -865,9 +865,44 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     }
 }
 
-// Scatter of d(pre-LN) into the word and token-type tables: a wave per row, lanes on consecutive columns, so every atomic
-// instruction covers 256 contiguous bytes (two lines).  padding_idx = 0 rows of both tables are frozen (HF:411-413).
-template <typename T>
+// Scatter of d(pre-LN) into the word and token-type tables, DETERMINISTIC (round 5; rounds 1-4: one fp32 atomic per element, whose
+// order -- and with it the last bits of every frequent token's gradient -- varied from run to run).  A wave per row r; the wave of
+// the FIRST row that holds a token id owns that table row: it adds the rows r' > r with the same id in row order (ids scanned 64
+// at a time: one compare + ballot per chunk) and makes one plain read-modify-write of the table row.  Every other wave finds an
+// earlier occurrence and leaves.  Same for the token-type table.  padding_idx = 0 rows of both tables are frozen (HF:411-413).
+template <typename T, int NV>
+__device__ __forceinline__ void embed_owner_sum(const T* __restrict__ dpre, const int64_t* __restrict__ key, int64_t k, int row,
+                                                int M, int N, int lane, float* __restrict__ table_row) {
+    for (int r0 = 0; r0 < row; r0 += 64) {              // an earlier row with this key owns the table row
+        const int r = r0 + lane;
+        if (__ballot(r < row && key[r] == k) != 0ull) return;
+    }
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = lane + i * 64;
+        acc[i] = col < N ? Elem<T>::ld(dpre + (size_t)row * N + col) : 0.f;
+    }
+    for (int r0 = row + 1; r0 < M; r0 += 64) {
+        const int r = r0 + lane;
+        unsigned long long m = __ballot(r < M && key[r] == k);
+        while (m != 0ull) {
+            const int rr = r0 + __builtin_ctzll(m);
+            m &= m - 1ull;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = lane + i * 64;
+                if (col < N) acc[i] += Elem<T>::ld(dpre + (size_t)rr * N + col);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = lane + i * 64;
+        if (col < N) table_row[col] += acc[i];
+    }
+}
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ ids,
                                                         const int64_t* __restrict__ tt, float* dword, float* dtype_tab,
                                                         int M, int N) {
@@ -875,32 +910,36 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dp
     const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (row >= M) return;
     const int64_t id = ids[row], ty = tt ? tt[row] : 0;
-    if (id == 0 && ty == 0) return;
-    for (int col = lane; col < N; col += 64) {
-        const float d = Elem<T>::ld(dpre + (size_t)row * N + col);
-        if (id != 0) atomicAdd(dword + (size_t)id * N + col, d);
-        if (ty != 0) atomicAdd(dtype_tab + (size_t)ty * N + col, d);
-    }
+    if (id != 0) embed_owner_sum<T, NV>(dpre, ids, id, row, M, N, lane, dword + (size_t)id * N);
+    if (ty != 0) embed_owner_sum<T, NV>(dpre, tt, ty, row, M, N, lane, dtype_tab + (size_t)ty * N);
 }
 
-// Position table: position l is shared by all B examples, so its gradient is a strided column sum, not a scatter (the
-// atomics of B rows on one table row serialise).  grid (L, N / 256, slices of the batch); position 0 is frozen (padding_idx).
+// Position table: position l is shared by all B examples, so its gradient is a strided column sum, not a scatter.  A block per
+// (position, 64 columns): its four waves sum a quarter of the batch each, the quarters meet in LDS and are added in order by the
+// wave that makes the one read-modify-write of the table row -- deterministic (rounds 1-4: 8 batch slices, one atomic each).
+// Position 0 is frozen (padding_idx).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict__ dpre, float* dpos, int B, int L, int N) {
-    const int l = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
-    if (l == 0 || col >= N) return;
-    const int per = (B + gridDim.z - 1) / gridDim.z;
-    const int b0 = blockIdx.z * per, b1 = min(B, b0 + per);
+    __shared__ float part[4][64];
+    const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + lane;
+    if (l == 0) return;
+    const int per = (B + 3) / 4;
+    const int b0 = wave * per, b1 = min(B, b0 + per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = b0;
-    for (; b + 4 <= b1; b += 4) {
-        s0 += Elem<T>::ld(dpre + ((size_t)(b + 0) * L + l) * N + col);
-        s1 += Elem<T>::ld(dpre + ((size_t)(b + 1) * L + l) * N + col);
-        s2 += Elem<T>::ld(dpre + ((size_t)(b + 2) * L + l) * N + col);
-        s3 += Elem<T>::ld(dpre + ((size_t)(b + 3) * L + l) * N + col);
+    if (col < N) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            s0 += Elem<T>::ld(dpre + ((size_t)(b + 0) * L + l) * N + col);
+            s1 += Elem<T>::ld(dpre + ((size_t)(b + 1) * L + l) * N + col);
+            s2 += Elem<T>::ld(dpre + ((size_t)(b + 2) * L + l) * N + col);
+            s3 += Elem<T>::ld(dpre + ((size_t)(b + 3) * L + l) * N + col);
+        }
+        for (; b < b1; ++b) s0 += Elem<T>::ld(dpre + ((size_t)b * L + l) * N + col);
     }
-    for (; b < b1; ++b) s0 += Elem<T>::ld(dpre + ((size_t)b * L + l) * N + col);
-    if (b1 > b0) atomicAdd(dpos + (size_t)l * N + col, (s0 + s1) + (s2 + s3));
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && col < N) dpos[(size_t)l * N + col] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // ------------------------------------------------------------------ codebook gather + [MASK] substitution
@@ -1617,11 +1656,15 @@ extern "C" int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t*
     CHECK_ROW(N, dtype);
     hipStream_t st = (hipStream_t)stream;
     const int M = B * L;
-    const int slices = B >= 64 ? 8 : 1;
+    XL_CHECK_ARG(N <= 64 * 16, XL_ERR_BAD_SHAPE, "xl_embed_bwd: hidden size %d > 1024", N);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
-                           (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
-        hipLaunchKernelGGL((embed_bwd_pos_kernel<T>), dim3(L, (N + 255) / 256, slices), dim3(256), 0, st,
+        if (N <= 64 * 4) hipLaunchKernelGGL((embed_bwd_kernel<T, 4>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                                             (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
+        else if (N <= 64 * 12) hipLaunchKernelGGL((embed_bwd_kernel<T, 12>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                                                   (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
+        else hipLaunchKernelGGL((embed_bwd_kernel<T, 16>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
+                                 (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
+        hipLaunchKernelGGL((embed_bwd_pos_kernel<T>), dim3(L, (N + 63) / 64), dim3(256), 0, st,
                            (const T*)dpre, dpos, B, L, N););
     XL_CHECK_LAUNCH();
     return XL_OK;

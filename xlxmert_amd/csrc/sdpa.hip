@@ -932,9 +932,11 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
     XL_CHECK_LAUNCH();
     if (bias_grad != nullptr) {          // no fused partials on this path: column sums of the stored gradients
         const int rq = q_rowoff ? q_rows_padded : B * nq, rk = k_rowoff ? k_rows_padded : B * nk;      // (pad rows are zero)
+        // three column sums in flight at once (deferred combines): a third of the caller's xl_workspace_floats(HD) = 4096 * HD floats each
+        constexpr size_t kWsThird = 4096 / 3;
         int rc2 = xl_colsum(dq, bias_grad, rq, HD, lddq, workspace, dtype, stream);
-        if (rc2 == XL_OK) rc2 = xl_colsum(dk, bias_grad + HD, rk, HD, lddk, workspace ? workspace + 1365 * (size_t)HD : nullptr, dtype, stream);
-        if (rc2 == XL_OK) rc2 = xl_colsum(dv, bias_grad + 2 * HD, rk, HD, lddv, workspace ? workspace + 2730 * (size_t)HD : nullptr, dtype, stream);
+        if (rc2 == XL_OK) rc2 = xl_colsum(dk, bias_grad + HD, rk, HD, lddk, workspace ? workspace + kWsThird * (size_t)HD : nullptr, dtype, stream);
+        if (rc2 == XL_OK) rc2 = xl_colsum(dv, bias_grad + 2 * HD, rk, HD, lddv, workspace ? workspace + 2 * kWsThird * (size_t)HD : nullptr, dtype, stream);
         return rc2;
     }
     return XL_OK;

@@ -637,10 +637,15 @@ class Engine:
         self.H, self.dh = cfg.num_attention_heads, cfg.head_dim
         self.P = cfg.visual_pos_dim
         self.pack_lang = (os.environ.get("XL_PACK_LANG", "1") != "0") if pack_lang is None else bool(pack_lang)
-        # visual / language sub-blocks of one shape class in lock step on one stream, contractions two per launch (run_pair);
-        # XL_PAIR_BLOCKS=0: every language-side block on the language stream, as in rounds 1-4
-        self.pair_blocks = os.environ.get("XL_PAIR_BLOCKS", "1") != "0"
-        self.pair_side = os.environ.get("XL_PAIR_SIDE", "1") != "0"       # ... the language block's own kernels on the language stream
+        # XL_PAIR_BLOCKS=1 (opt-in): visual / language sub-blocks of one shape class in lock step on one stream, their contractions
+        # two per launch (run_pair).  Measured (round 5, bs 256, profiles/r05a): the paired launches take 1.6 ms less GEMM time per
+        # step (14.7 -> 13.1 ms isolated, roofline.frac 0.30 -> 0.34) and the step gets SLOWER -- 16.75 -> 17.6 ms with the language
+        # blocks' own kernels (LayerNorm, attention core) queued behind the visual ones on the chain, 18.2 ms with them on the
+        # language stream (XL_PAIR_SIDE=1: ~170 cross-stream hand-overs per step at 5-9 us each); with those kernels REMOVED
+        # altogether (tools/sensitivity.py no_lang_small_paired: the bound for launches that merge them too) 16.68 ms, i.e. no
+        # better than the language stream of rounds 1-4 beside the visual chain.  Default: off.
+        self.pair_blocks = os.environ.get("XL_PAIR_BLOCKS", "0") != "0"
+        self.pair_side = os.environ.get("XL_PAIR_SIDE", "0") != "0"       # ... the language block's own kernels on the language stream
         self.packed = False                 # this batch runs packed (set_inputs: pack_lang and a usable attention mask)
         self.MLd, self.MV = B * L, B * V    # dense language rows / visual rows
         # language row CAPACITY of every buffer (a packed row count is rounded up to the row tile) and the ACTIVE count
