@@ -243,9 +243,14 @@ int xl_embed_ln_fwd(const int64_t* ids, const int64_t* tt, const void* word, con
                     void* y, void* pre, float* mean, float* rstd,
                     int B, int L, int N, float eps, int dtype, void* stream);
 /* scatter-add of d(pre) into the fp32 table gradients.  Row 0 of every table is frozen
- * (nn.Embedding(padding_idx=0), HF:184-186). */
-int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t* tt,
-                 float* dword, float* dpos, float* dtype_tab, int B, int L, int N, int dtype, void* stream);
+ * (nn.Embedding(padding_idx=0), HF:184-186).  Deterministic: every table row has ONE writer, which adds the rows that map to it
+ * in row order (no floating-point atomics).
+ *   order: int32 [B*L], the row indices b*L+l sorted by (ids[row], row) -- a stable argsort of the flattened ids, computed where the
+ *          ids are made (the data loader, next to attention_mask / masked_rows); NULL: every row scans the batch for its id
+ *          (same result, ~40x slower at B*L = 5120).
+ *   tt / n_types: token-type ids and type_vocab_size (HF: 2); tt NULL = every token has type 0 (no gradient: frozen row). */
+int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t* tt, const int32_t* order,
+                 float* dword, float* dpos, float* dtype_tab, int B, int L, int N, int n_types, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- codebook input (ref lxrt/modeling.py:185-193)
  * feats[b,v,:] = vis_mask[b,v] ? mask_feat : centroids[cluster_ids[b,v]]   (centroids in `dtype`) */

@@ -196,10 +196,16 @@ class FakeOps:
         v2(y, M, N, N).copy_(o)
         mean.copy_(m); rstd.copy_(r)
 
-    def embed_bwd(self, dpre, ids, tt, dword, dpos, dtype_tab, B, L, N):
+    def embed_bwd(self, dpre, ids, tt, dword, dpos, dtype_tab, B, L, N, order=None, n_types=2):
         M = B * L
         d = v2(dpre, M, N, N).float()
-        idf, ttf = ids.view(-1), tt.view(-1)
+        if order is not None:              # the loader's stable argsort of the ids: rows sorted by (id, row)
+            key = ids.view(-1)[order.long()]
+            assert sorted(order.tolist()) == list(range(M)) and bool((key[1:] >= key[:-1]).all())
+            same = key[1:] == key[:-1]
+            assert bool((order[1:][same] > order[:-1][same]).all())
+        idf = ids.view(-1)
+        ttf = tt.view(-1) if tt is not None else torch.zeros_like(idf)
         lf = torch.arange(L).repeat(B)
         dword.index_add_(0, idf[idf != 0], d[idf != 0])
         dpos.index_add_(0, lf[lf != 0], d[lf != 0])

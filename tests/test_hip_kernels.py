@@ -774,10 +774,51 @@ def test_embeddings_fwd_bwd(dtype):
     close(gpu[7], cpu[7], dtype, "embed y")
     dpre = rnd(g, B * L, N, dtype=dtype)
     dw, dp, dt_ = torch.zeros(vocab, N), torch.zeros(32, N), torch.zeros(2, N)
-    cpu, gpu = run_both(dtype, "embed_bwd", [dpre, ids, tt, dw, dp, dt_, B, L, N])
-    for i, nm in ((3, "dword"), (4, "dpos"), (5, "dtype")):
-        close(gpu[i], cpu[i], torch.float32, "embed " + nm, f32_tol=1e-5)
-    assert gpu[3][0].abs().max() == 0 and gpu[4][0].abs().max() == 0 and gpu[5][0].abs().max() == 0   # padding_idx rows
+    from xlxmert_amd.trainer import word_order_of
+    outs = []
+    for order in (None, word_order_of(ids)):        # the scanning kernel / the loader's sorted row list: one writer per table row both
+        cpu, gpu = run_both(dtype, "embed_bwd", [dpre, ids, tt, dw, dp, dt_, B, L, N], dict(order=order, n_types=2))
+        for i, nm in ((3, "dword"), (4, "dpos"), (5, "dtype")):
+            close(gpu[i], cpu[i], torch.float32, "embed " + nm, f32_tol=1e-5)
+        assert gpu[3][0].abs().max() == 0 and gpu[4][0].abs().max() == 0 and gpu[5][0].abs().max() == 0   # padding_idx rows
+        outs.append(gpu)
+    for i in (3, 4, 5):                             # the same addends in the same (row) order: bit-identical
+        assert torch.equal(outs[0][i], outs[1][i]), i
+
+
+def test_embed_bwd_is_deterministic_at_the_step_shape():
+    """B*L = 5120 rows with a Zipf-like id distribution ([CLS] / [SEP] in every sentence, a few very frequent words): two runs
+    bit-identical (one writer per table row, occurrences added in row order), equal to a float64 index_add to fp32 rounding,
+    and a run of 256 occurrences is walked by its owner wave."""
+    from xlxmert_amd.trainer import word_order_of
+    g = torch.Generator().manual_seed(5)
+    B, L, N, vocab = 256, 20, 768, 30522
+    z = torch.rand(B, L, generator=g)
+    ids = (1000 + (z ** 4 * 5000)).long()               # heavy head: many repeats
+    ids[:, 0] = 101
+    ids[:, 9] = 102
+    ids[:, 12:][torch.rand(B, 8, generator=g) < 0.5] = 0
+    tt = torch.zeros(B, L, dtype=torch.long)
+    tt[:, 10:] = 1
+    dpre = rnd(g, B * L, N, dtype=torch.bfloat16).cuda()
+    ops = hip(torch.bfloat16)
+    order = word_order_of(ids).cuda()
+    idc, ttc = ids.cuda(), tt.cuda()
+    res = []
+    for rep in range(2):
+        dw, dp, dt_ = torch.zeros(vocab, N, device="cuda"), torch.zeros(32, N, device="cuda"), torch.zeros(2, N, device="cuda")
+        ops.embed_bwd(dpre, idc, ttc, dw, dp, dt_, B, L, N, order=order, n_types=2)
+        torch.cuda.synchronize()
+        res.append((dw, dp, dt_))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    d64 = dpre.double().cpu()
+    ref = torch.zeros(vocab, N, dtype=torch.float64).index_add_(0, ids.view(-1), d64)
+    ref[0] = 0
+    assert (res[0][0].cpu().double() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+    reft = torch.zeros(2, N, dtype=torch.float64).index_add_(0, tt.view(-1), d64)
+    assert (res[0][2][1].cpu().double() - reft[1]).abs().max().item() < 1e-3 * reft[1].abs().max().item()
+    assert res[0][2][0].abs().max().item() == 0
 
 
 @pytest.mark.parametrize("dtype", DT)

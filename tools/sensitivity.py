@@ -56,6 +56,7 @@ V = {
     and not (tag.startswith("l") and int(tag[1:]) < 4),
     "no_lang_sdpa_paired": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("sdpa_fwd", "sdpa_bwd") and not (tag.startswith("l") and int(tag[1:]) < 4),
     "no_lang_ln_paired": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("layernorm_fwd", "layernorm_bwd") and not (tag.startswith("l") and int(tag[1:]) < 4),
+    "no_embed_bwd": lambda op, tag, a: op == "embed_bwd",
     "no_lang_wgrad": lambda op, tag, a: op == "gemm_wgrad_group" and lang(tag),
     "no_vis_wgrad": lambda op, tag, a: op == "gemm_wgrad_group" and not lang(tag),
     "no_ln_fwd": lambda op, tag, a: op == "layernorm_fwd",
@@ -73,7 +74,7 @@ V = {
 names = [n for n in V if not args.only or n in args.only.split(",") or n == "base"]
 orig = {}
 for op in ("gemm", "sdpa_fwd", "sdpa_bwd", "layernorm_fwd", "layernorm_bwd", "gemm_wgrad_group", "adamw", "sumsq", "ce_fwd_bwd", "colsum",
-           "gelu_bwd", "gather_rows", "scatter_rows", "dropout", "codebook_gather"):
+           "gelu_bwd", "gather_rows", "scatter_rows", "dropout", "codebook_gather", "embed_bwd"):
     orig[op] = getattr(ops, op)
 cur = {"pred": V["base"], "skipped": 0}
 

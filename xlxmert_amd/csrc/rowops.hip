@@ -866,80 +866,201 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
 }
 
 // Scatter of d(pre-LN) into the word and token-type tables, DETERMINISTIC (round 5; rounds 1-4: one fp32 atomic per element, whose
-// order -- and with it the last bits of every frequent token's gradient -- varied from run to run).  A wave per row r; the wave of
-// the FIRST row that holds a token id owns that table row: it adds the rows r' > r with the same id in row order (ids scanned 64
-// at a time: one compare + ballot per chunk) and makes one plain read-modify-write of the table row.  Every other wave finds an
-// earlier occurrence and leaves.  Same for the token-type table.  padding_idx = 0 rows of both tables are frozen (HF:411-413).
-template <typename T, int NV>
-__device__ __forceinline__ void embed_owner_sum(const T* __restrict__ dpre, const int64_t* __restrict__ key, int64_t k, int row,
-                                                int M, int N, int lane, float* __restrict__ table_row) {
-    for (int r0 = 0; r0 < row; r0 += 64) {              // an earlier row with this key owns the table row
-        const int r = r0 + lane;
-        if (__ballot(r < row && key[r] == k) != 0ull) return;
-    }
-    float acc[NV];
+// order -- and with it the last bits of every frequent token's gradient -- varied from run to run).  Every table row has ONE writer,
+// which adds the rows that map to it in row order and makes one plain read-modify-write.  16-byte accesses (a lane owns 8 / 4
+// consecutive columns per 64-lane pass, NIT passes), eight rows in flight per wave.  padding_idx = 0 rows are frozen (HF:411-413).
+template <typename T, int NIT>
+__device__ __forceinline__ void embed_add_rows(const T* __restrict__ dpre, int N, int lane, int rr, int n,
+                                               float (&acc)[NIT][Elem<T>::VEC]) {
+    // acc += dpre[row of lane t], t = 0 .. n-1 (n <= 64, wave-uniform), in that order; eight rows requested at a time
+    constexpr int VEC = Elem<T>::VEC;
+    for (int t0 = 0; t0 < n; t0 += 8) {
+        float tmp[8][NIT][VEC];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int col = lane + i * 64;
-        acc[i] = col < N ? Elem<T>::ld(dpre + (size_t)row * N + col) : 0.f;
-    }
-    for (int r0 = row + 1; r0 < M; r0 += 64) {
-        const int r = r0 + lane;
-        unsigned long long m = __ballot(r < M && key[r] == k);
-        while (m != 0ull) {
-            const int rr = r0 + __builtin_ctzll(m);
-            m &= m - 1ull;
+        for (int u = 0; u < 8; ++u)
+            if (t0 + u < n) load_row<T, NIT>(dpre + (size_t)__shfl(rr, t0 + u, 64) * N, N, lane, tmp[u]);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int col = lane + i * 64;
-                if (col < N) acc[i] += Elem<T>::ld(dpre + (size_t)rr * N + col);
-            }
-        }
-    }
+        for (int u = 0; u < 8; ++u)
+            if (t0 + u < n)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int col = lane + i * 64;
-        if (col < N) table_row[col] += acc[i];
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[it][i] += tmp[u][it][i];
     }
 }
-template <typename T, int NV>
+template <typename T, int NIT>
+__device__ __forceinline__ void embed_commit(float* __restrict__ table_row, int N, int lane, const float (&acc)[NIT][Elem<T>::VEC]) {
+    constexpr int VEC = Elem<T>::VEC;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (it * 64 + lane) * VEC;
+        if (col < N)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) table_row[col + i] += acc[it][i];
+    }
+}
+
+// without a row order from the caller: a wave per row r; the wave of the FIRST row that holds a token id owns the table row and
+// finds the later occurrences by scanning the ids 64 at a time (compare + ballot); every other wave finds an earlier occurrence and
+// leaves.  Correct for any caller, ~50x slower than the sorted form at B*L = 5120.
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ ids,
-                                                        const int64_t* __restrict__ tt, float* dword, float* dtype_tab,
-                                                        int M, int N) {
+                                                        float* dword, int M, int N) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (row >= M) return;
-    const int64_t id = ids[row], ty = tt ? tt[row] : 0;
-    if (id != 0) embed_owner_sum<T, NV>(dpre, ids, id, row, M, N, lane, dword + (size_t)id * N);
-    if (ty != 0) embed_owner_sum<T, NV>(dpre, tt, ty, row, M, N, lane, dtype_tab + (size_t)ty * N);
+    const int64_t id = ids[row];
+    if (id == 0) return;
+    for (int r0 = 0; r0 < row; r0 += 64) {              // an earlier row with this id owns the table row
+        const int r = r0 + lane;
+        if (__ballot(r < row && ids[r] == id) != 0ull) return;
+    }
+    float acc[NIT][Elem<T>::VEC];
+    load_row<T, NIT>(dpre + (size_t)row * N, N, lane, acc);
+    for (int r0 = row + 1; r0 < M; r0 += 64) {
+        const int r = r0 + lane;
+        const bool same = r < M && ids[r] == id;
+        const unsigned long long m = __ballot(same);
+        if (m == 0ull) continue;
+        // the matching rows, in row order, to lanes 0 .. n-1
+        const int n = __builtin_popcountll(m);
+        int rr = 0;
+        unsigned long long mm = m;
+        for (int t = 0; t < n; ++t) {
+            if (lane == t) rr = r0 + __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+        }
+        embed_add_rows<T, NIT>(dpre, N, lane, rr, n, acc);
+    }
+    embed_commit<T, NIT>(dword + (size_t)id * N, N, lane, acc);
+}
+
+// With the rows handed over SORTED by (token id, row) -- `order`, a stable argsort of the ids computed where the ids are made (data
+// loader; the engine sorts on the device otherwise): a BLOCK per sorted position; the block at the first position of an id owns that
+// table row (all others leave after three loads), and its four waves walk the id's run 64 candidates at a time, wave w the chunks
+// w, w + 4, ... (one load of the order, one of the ids, a ballot; sorted: the matches are a prefix); the four partial sums meet in
+// LDS and are added in wave order -- a fixed tree over the run, the same bits every time.  A token in every sentence ([CLS], [SEP]:
+// 256 occurrences) costs each wave 64 rows instead of one wave 256: ~15 us for the launch instead of ~100.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ ids,
+                                                               const int32_t* __restrict__ order, float* dword, int M, int N) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float part[3][NIT][64][VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x;
+    const int r = order[j];
+    const int64_t id = ids[r];
+    if (id == 0) return;
+    if (j > 0 && ids[order[j - 1]] == id) return;
+    float acc[NIT][VEC];
+    if (wave == 0) load_row<T, NIT>(dpre + (size_t)r * N, N, lane, acc);
+    else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[it][i] = 0.f;
+    }
+    for (int j0 = j + 1 + 64 * wave; j0 < M; j0 += 256) {
+        const int jj = j0 + lane;
+        const int rr = jj < M ? order[jj] : 0;
+        const unsigned long long m = __ballot(jj < M && ids[rr] == id);
+        const int n = m == ~0ull ? 64 : __builtin_ctzll(~m);         // length of the run's part in this chunk
+        embed_add_rows<T, NIT>(dpre, N, lane, rr, n, acc);
+        if (n < 64) break;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) part[wave - 1][it][lane][i] = acc[it][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[it][i] = ((acc[it][i] + part[0][it][lane][i]) + part[1][it][lane][i]) + part[2][it][lane][i];
+        embed_commit<T, NIT>(dword + (size_t)id * N, N, lane, acc);
+    }
+}
+
+// Token-type table (type_vocab_size rows, 2 in BERT): type t's gradient is the sum over the rows that carry it.  A block per
+// (type >= 1, quarter of the column passes); its four waves take a quarter of the rows each, 64 type ids per step (a chunk without
+// the type costs one load + ballot), the matching rows in row order; the quarters meet in LDS and are added in order.  Type 0 is
+// frozen (padding_idx).
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void embed_bwd_type_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ tt,
+                                                             float* dtype_tab, int M, int N) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float part[4][NIT][64][VEC];
+    const int t = blockIdx.x + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = ((M + 3) / 4 + 63) / 64 * 64;
+    const int r0 = wave * per, r1 = min(M, r0 + per);
+    float acc[NIT][VEC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[it][i] = 0.f;
+    for (int c0 = r0; c0 < r1; c0 += 64) {
+        const int r = c0 + lane;
+        unsigned long long m = __ballot(r < r1 && tt[r] == t);
+        while (m != 0ull) {                               // up to 8 of the chunk's matching rows at a time, in row order
+            int rr = 0, n = 0;
+            unsigned long long mm = m;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (mm != 0ull) { if (lane == u) rr = c0 + __builtin_ctzll(mm); mm &= mm - 1ull; ++n; }
+            m = mm;
+            embed_add_rows<T, NIT>(dpre, N, lane, rr, n, acc);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) part[wave][it][lane][i] = acc[it][i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (it * 64 + lane) * VEC;
+            if (col < N)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    dtype_tab[(size_t)t * N + col + i] += ((part[0][it][lane][i] + part[1][it][lane][i]) + part[2][it][lane][i]) + part[3][it][lane][i];
+        }
+    }
 }
 
 // Position table: position l is shared by all B examples, so its gradient is a strided column sum, not a scatter.  A block per
-// (position, 64 columns): its four waves sum a quarter of the batch each, the quarters meet in LDS and are added in order by the
-// wave that makes the one read-modify-write of the table row -- deterministic (rounds 1-4: 8 batch slices, one atomic each).
-// Position 0 is frozen (padding_idx).
+// (position, 64 columns): its eight waves sum an eighth of the batch each (16 rows requested at a time), the partial sums meet in
+// LDS and are added in wave order by the wave that makes the one read-modify-write of the table row -- deterministic (rounds 1-4:
+// 8 batch slices, one atomic each).  Position 0 is frozen (padding_idx).
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict__ dpre, float* dpos, int B, int L, int N) {
-    __shared__ float part[4][64];
+__global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const T* __restrict__ dpre, float* dpos, int B, int L, int N) {
+    __shared__ float part[8][64];
     const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.y * 64 + lane;
     if (l == 0) return;
-    const int per = (B + 3) / 4;
+    const int per = (B + 7) / 8;
     const int b0 = wave * per, b1 = min(B, b0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s = 0.f;
     if (col < N) {
-        int b = b0;
-        for (; b + 4 <= b1; b += 4) {
-            s0 += Elem<T>::ld(dpre + ((size_t)(b + 0) * L + l) * N + col);
-            s1 += Elem<T>::ld(dpre + ((size_t)(b + 1) * L + l) * N + col);
-            s2 += Elem<T>::ld(dpre + ((size_t)(b + 2) * L + l) * N + col);
-            s3 += Elem<T>::ld(dpre + ((size_t)(b + 3) * L + l) * N + col);
+        for (int b = b0; b < b1; b += 16) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = b + u < b1 ? Elem<T>::ld(dpre + ((size_t)(b + u) * L + l) * N + col) : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += t[u];
         }
-        for (; b < b1; ++b) s0 += Elem<T>::ld(dpre + ((size_t)b * L + l) * N + col);
     }
-    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    part[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && col < N) dpos[(size_t)l * N + col] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (wave == 0 && col < N) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += part[w][lane];
+        dpos[(size_t)l * N + col] += t;
+    }
 }
 
 // ------------------------------------------------------------------ codebook gather + [MASK] substitution
@@ -1651,21 +1772,27 @@ extern "C" int xl_embed_ln_fwd(const int64_t* ids, const int64_t* tt, const void
     return XL_OK;
 }
 
-extern "C" int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t* tt,
-                            float* dword, float* dpos, float* dtype_tab, int B, int L, int N, int dtype, void* stream) {
+extern "C" int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t* tt, const int32_t* order,
+                            float* dword, float* dpos, float* dtype_tab, int B, int L, int N, int n_types, int dtype, void* stream) {
     CHECK_ROW(N, dtype);
+    XL_CHECK_ARG(dpre && ids && dword && dpos && B > 0 && L > 0 && (tt == nullptr || (dtype_tab != nullptr && n_types >= 1)), XL_ERR_BAD_ARG,
+                 "xl_embed_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
     const int M = B * L;
     XL_CHECK_ARG(N <= 64 * 16, XL_ERR_BAD_SHAPE, "xl_embed_bwd: hidden size %d > 1024", N);
+    const dim3 grid((M + WPB - 1) / WPB);
+#define XL_EMBED_WORD(NIT)                                                                                                           \
+    if (order != nullptr) hipLaunchKernelGGL((embed_bwd_sorted_kernel<T, NIT>), dim3(M), dim3(256), 0, st, (const T*)dpre, ids, order, dword, M, N); \
+    else hipLaunchKernelGGL((embed_bwd_kernel<T, NIT>), grid, dim3(256), 0, st, (const T*)dpre, ids, dword, M, N);                   \
+    if (tt != nullptr && n_types > 1)                                                                                                \
+        hipLaunchKernelGGL((embed_bwd_type_kernel<T, NIT>), dim3(n_types - 1), dim3(256), 0, st, (const T*)dpre, tt, dtype_tab, M, N);
     DISPATCH_T(dtype,
-        if (N <= 64 * 4) hipLaunchKernelGGL((embed_bwd_kernel<T, 4>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
-                                             (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
-        else if (N <= 64 * 12) hipLaunchKernelGGL((embed_bwd_kernel<T, 12>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
-                                                   (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
-        else hipLaunchKernelGGL((embed_bwd_kernel<T, 16>), dim3((M + WPB - 1) / WPB), dim3(256), 0, st,
-                                 (const T*)dpre, ids, tt, dword, dtype_tab, M, N);
-        hipLaunchKernelGGL((embed_bwd_pos_kernel<T>), dim3(L, (N + 63) / 64), dim3(256), 0, st,
-                           (const T*)dpre, dpos, B, L, N););
+        const int passes = (N + 64 * vec_of(dtype) - 1) / (64 * vec_of(dtype));
+        if (passes <= 1) { XL_EMBED_WORD(1) }
+        else if (passes <= 2) { XL_EMBED_WORD(2) }
+        else { XL_EMBED_WORD(4) }
+        hipLaunchKernelGGL((embed_bwd_pos_kernel<T>), dim3(L, (N + 63) / 64), dim3(512), 0, st, (const T*)dpre, dpos, B, L, N););
+#undef XL_EMBED_WORD
     XL_CHECK_LAUNCH();
     return XL_OK;
 }

@@ -152,8 +152,9 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
 
 // ================================================================== long sequences (nq or nk in 65..512)
 // --max_text_length above 64 (ref param.py:140; the position table has 512 rows): not the benchmarked shapes, so these are the
-// plain kernels -- one lane per query (resp. key), fp32 arithmetic, the other side streamed from global memory -- built for
-// correctness at any length up to MAXLONG, with the same conventions as the kernels above (dropout counters, log-sum-exp layout,
+// plain kernels -- one lane per query (resp. key), fp32 arithmetic, the other side streamed from global memory -- a CORRECTNESS
+// FALLBACK at scalar-FMA speed (no MFMA, no LDS staging: nowhere near the chip; the benchmarked configuration, 20 text tokens, never
+// takes it), built for any length up to MAXLONG, with the same conventions as the kernels above (dropout counters, log-sum-exp layout,
 // packed rows, zeroed pad rows).  Forward: online softmax (running max / sum, the accumulator rescaled), dropout applied to the
 // un-normalised terms (linear).  Backward in two launches: per query, delta_i = sum_j p_ij dp_ij and dQ_i (delta also goes to a
 // caller-owned fp32 scratch [B, H, nq]); per key, dK_j and dV_j over all queries with the saved delta -- no atomics.

@@ -722,6 +722,7 @@ class Engine:
         self.vkmask, self._vkmask_buf = None, None        # visual_attention_mask (HF:760-770): None in every reference caller
         self.pos = torch.zeros(self.MV, self.P, dtype=torch.float32, device=self.dev)
         self.ids = torch.zeros(B, L, dtype=torch.int64, device=self.dev)
+        self.word_order = torch.arange(B * L, dtype=torch.int32, device=self.dev)      # token positions sorted by (id, position)
         self.tt = torch.zeros(B, L, dtype=torch.int64, device=self.dev)
         self.cid = torch.zeros(B, V, dtype=torch.int64, device=self.dev)
         self.vmask = torch.zeros(B, V, dtype=torch.uint8, device=self.dev)
@@ -1250,7 +1251,7 @@ class Engine:
     # ------------------------------------------------------------ inputs
     def set_inputs(self, input_ids, attention_mask=None, token_type_ids=None, visual_pos=None, cluster_ids=None,
                    vis_mask=None, obj_labels=None, visual_feats=None, masked_rows=None, feat_labels=None,
-                   visual_attention_mask=None, inputs_embeds=None, lang_rows=None, lang_off=None):
+                   visual_attention_mask=None, inputs_embeds=None, lang_rows=None, lang_off=None, word_order=None):
         """masked_rows (optional): ascending ids b*V+v of the masked positions, i.e. vis_mask.flatten().nonzero(), as the data
         loader can compute them on the CPU next to vis_mask itself; given, the step needs no host <-> device round trip.
         feat_labels (optional, [B,V,F]): regression targets of the feature loss (label_dict['feat_labels'], ref
@@ -1258,7 +1259,10 @@ class Engine:
         feature loss regresses onto the centroid of each position's cluster id.
         lang_rows / lang_off (optional, pack_lang): ascending ids b*L+l of the real tokens, i.e. attention_mask.flatten().nonzero(),
         and the [B+1] prefix sums of the per-example token counts -- computed by the data loader next to the mask (given, the
-        step needs no host <-> device round trip; every example must have at least one real token)."""
+        step needs no host <-> device round trip; every example must have at least one real token).
+        word_order (optional): int32 [B*L], the flat token positions sorted by (input id, position) = a stable argsort of
+        input_ids.flatten() (trainer.word_order_of) -- the embedding backward gives every word-table row ONE writer that adds
+        its occurrences in that order (deterministic scatter, xl_embed_bwd); sorted on the device when the loader sends none."""
         B, L, V = self.B, self.L, self.V
         # inputs_embeds [B, L, d] instead of input_ids (HF:699,731-744,773 -> HF:191-214: they replace the word-embedding
         # lookup; position / token-type embeddings, LayerNorm and dropout still apply): staged as a per-call "word table" of
@@ -1271,10 +1275,14 @@ class Engine:
                 self._emb_tab = torch.zeros(B * L + 1, self.d, dtype=self.cdtype, device=self.dev)
                 self._emb_grad = torch.zeros(B * L + 1, self.d, dtype=torch.float32, device=self.dev)
                 self._emb_ids = torch.arange(1, B * L + 1, dtype=torch.int64, device=self.dev).view(B, L)
+                self._emb_order = torch.arange(B * L, dtype=torch.int32, device=self.dev)       # (all ids distinct: already sorted)
             self._emb_tab[1:].copy_(inputs_embeds.reshape(B * L, self.d), non_blocking=True)
         else:
             assert tuple(input_ids.shape) == (B, L), (input_ids.shape, (B, L))
             self.ids.copy_(input_ids, non_blocking=True)
+            if word_order is None:
+                word_order = torch.sort(input_ids.reshape(-1), stable=True).indices
+            self.word_order.copy_(word_order.reshape(-1), non_blocking=True)
         if attention_mask is None:
             self.kmask.fill_(1)
         else:
@@ -2029,7 +2037,7 @@ class Engine:
             ops.embed_bwd(dpre, self._emb_ids if emb else self.ids, self.tt,
                           self._emb_grad if emb else st.gview(e + ".word_embeddings.weight"),
                           st.gview(e + ".position_embeddings.weight"), st.gview(e + ".token_type_embeddings.weight"),
-                          self.B, self.L, d)
+                          self.B, self.L, d, order=self._emb_order if emb else self.word_order, n_types=cfg.type_vocab_size)
             self.flush_reductions()
             self._ready_lang(st.language_range()[1], flush=True)
             self.wgrad_sync_all()

@@ -289,9 +289,10 @@ class HipOps:
                       self._p(gamma), self._p(beta), self._p(y), self._p(pre), self._p(mean), self._p(rstd), B, L, N,
                       float(eps), self.dt, self._stream())
 
-    def embed_bwd(self, dpre, ids, tt, dword, dpos, dtype_tab, B, L, N):
-        self._call("xl_embed_bwd", self._p(dpre), self._p(ids), self._p(tt), self._p(dword), self._p(dpos),
-                      self._p(dtype_tab), B, L, N, self.dt, self._stream())
+    def embed_bwd(self, dpre, ids, tt, dword, dpos, dtype_tab, B, L, N, order=None, n_types=2):
+        """order: int32 [B*L] rows sorted by (id, row) -- trainer.word_order_of(input_ids); None: the (slow) scanning kernel"""
+        self._call("xl_embed_bwd", self._p(dpre), self._p(ids), self._p(tt), self._p(order), self._p(dword), self._p(dpos),
+                      self._p(dtype_tab), B, L, N, int(n_types), self.dt, self._stream())
 
     def codebook_gather(self, cluster_ids, vis_mask, centroids, mask_feat, feats, M, F):
         self._call("xl_codebook_gather", self._p(cluster_ids), self._p(vis_mask), self._p(centroids),

@@ -523,7 +523,8 @@ class PretrainStep:
             # word_rows_of(word_labels), the masked-row decoder) | matched_labels
             eng.set_step_seed(self._next_seed())
             eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
-                           lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
+                           lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"),
+                           word_order=batch.get("word_order"))
             eng.grad_ready = None
             if exchange:
                 self._begin_exchange()
@@ -549,7 +550,8 @@ class PretrainStep:
                 feats, pos = feats.reshape(-1, *feats.shape[2:]), pos.reshape(-1, *pos.shape[2:])
             eng.set_step_seed(self._next_seed())
             eng.set_inputs(ids, am, batch.get("token_type_ids"), pos, visual_feats=feats,
-                           lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
+                           lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"),
+                           word_order=batch.get("word_order"))
             eng.grad_ready = None
             if exchange:
                 self._begin_exchange()
@@ -569,7 +571,8 @@ class PretrainStep:
         eng.set_inputs(ids, am, batch.get("token_type_ids"), batch["visual_pos"], cluster_ids=batch["cluster_ids"],
                        vis_mask=batch["vis_mask"], obj_labels=labels, masked_rows=batch.get("masked_rows"),
                        feat_labels=batch.get("feat_labels") if self.feat_loss else None,
-                       lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"))
+                       lang_rows=batch.get("lang_rows"), lang_off=batch.get("lang_off"),
+                           word_order=batch.get("word_order"))
         if qa_labels is None:                   # every tensor of the batch went through set_inputs: the staging slot is free
             self._mark_consumed(batch)
         if self.plan_mode and qa_labels is None and not accumulating:
@@ -900,8 +903,17 @@ def synthetic_batch(cfg, B, L=20, grid=8, seed=9595, device="cpu", ragged=True):
              "masked_rows": vm.reshape(-1).nonzero().reshape(-1),      # computed where the mask is drawn: on the host
              # ... and likewise the real tokens' row list + per-example offsets (packed language rows, engine pack_lang)
              "lang_rows": am.reshape(-1).nonzero().reshape(-1),
-             "lang_off": torch.cat([torch.zeros(1, dtype=torch.int64), am.sum(1).cumsum(0)]).to(torch.int32)}
+             "lang_off": torch.cat([torch.zeros(1, dtype=torch.int64), am.sum(1).cumsum(0)]).to(torch.int32),
+             # ... and the token positions sorted by (id, position): the embedding backward's one-writer-per-row scatter
+             "word_order": word_order_of(ids)}
     return {k: v.to(device) for k, v in batch.items()}
+
+
+def word_order_of(input_ids):
+    """flat token positions b*L+l sorted by (input id, position) -- a stable argsort of the ids, int32 [B*L] -- what the data
+    loader hands over next to `input_ids` (batch["word_order"]): xl_embed_bwd gives every word-embedding row one writer that adds
+    the row's occurrences in this order (ref: nn.Embedding's backward, HF:184-186, is an index_add over the same rows)."""
+    return torch.sort(input_ids.reshape(-1), stable=True).indices.to(torch.int32)
 
 
 def word_rows_of(word_labels):
