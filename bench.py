@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="enqueue every step from Python instead of replaying the recorded launch plan")
     ap.add_argument("--collective", default=None, choices=["allreduce", "rs+ag"], help="gradient exchange at N > 1: all-reduce + "
                     "replicated AdamW (default) or reduce-scatter -> shard-local AdamW -> all-gather (trainer.PretrainStep collective)")
+    ap.add_argument("--gather", default=None, choices=["fp32", "bf16"], help="rs+ag: what the all-gather moves -- the fp32 master slices "
+                    "(default) or the bf16 compute copy + a sparse fp32 side car (half the bytes; trainer.PretrainStep gather)")
     ap.add_argument("--resident-inputs", action="store_true", help="minibatches resident in HBM before the timed region (default: "
                     "pinned host memory, uploaded inside the timed step on a copy stream, one step ahead)")
     args = ap.parse_args()
@@ -336,7 +338,7 @@ def main():
                       total_steps=max(1000, args.steps + args.warmup), train_dropout=not args.no_dropout,
                       bucket_mb=float(os.environ.get("XL_BUCKET_MB", "64")),
                       plan=(not args.eager and not args.single_stream), drop_grads=True,
-                      overlap_optimizer=not (args.no_opt_overlap or args.single_stream), collective=args.collective)
+                      overlap_optimizer=not (args.no_opt_overlap or args.single_stream), collective=args.collective, gather=args.gather)
     if args.single_stream:
         tr.engine.side = None
     g = torch.Generator().manual_seed(9595)
@@ -506,6 +508,7 @@ def main():
             out["config"]["gradient_exchange"] = {
                 "backend": args.backend + (" (= RCCL over xGMI)" if args.backend == "nccl" else " (host-staged: test rig)"),
                 "collective": tr.collective,
+                "all_gather_payload": ("bf16 compute copy + sparse fp32 side car" if tr.gather_bf16 else "fp32 master slices") if tr.sharded else None,
                 "collective_note": ("reduce-scatter (sum) per finished slice of the flat gradient buffer -> shard-local norm + one scalar "
                                     "all-reduce -> AdamW over this rank's shards -> all-gather of the fp32 master slices, first-needed "
                                     "first, overlapping the next forward" if tr.sharded else

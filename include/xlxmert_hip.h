@@ -400,6 +400,12 @@ int xl_adamw(float* p, float* g, float* m, float* v, void* p_compute,
 int xl_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
 /* dst (fp32) = src (`dtype`) */
 int xl_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream);
+/* Sparse fp32 side car of the sharded exchange (trainer collective="rs+ag", gather="bf16": SURVEY 5.8 "bf16 on the wire").  idx: int32
+ * [n] positions (relative to src / dst) of the elements that are read in fp32 (biases, LayerNorm affines ...):
+ *   xl_take_f32: dst[j] = src[idx[j]] if own_lo <= idx[j] < own_hi else 0   (the pack a rank contributes to a sum all-reduce)
+ *   xl_put_f32:  dst[idx[j]] = src[j]                                        (the all-reduced pack back into the master buffer) */
+int xl_take_f32(const float* src, const int32_t* idx, int n, int own_lo, int own_hi, float* dst, void* stream);
+int xl_put_f32(float* dst, const int32_t* idx, int n, const float* src, void* stream);
 
 /* ---------------------------------------------------------------- launch plans (csrc/plan.hip)
  * The host language records one training step as the list of C-ABI calls it made (function + argument words) and replays

@@ -121,6 +121,14 @@ class FakeOps:
     def wgrad_group_one_writer(self, problems):
         return True
 
+    def take_f32(self, src, idx, own_lo, own_hi, dst):
+        i = idx.long()
+        own = (i >= own_lo) & (i < own_hi)
+        dst[:i.numel()].copy_(torch.where(own, src[i], torch.zeros((), dtype=src.dtype)))
+
+    def put_f32(self, dst, idx, src):
+        dst[idx.long()] = src[:idx.numel()]
+
     def gemm_pair(self, c0, c1):
         """xl_gemm_pair: by contract the two xl_gemm calls"""
         self.gemm(*c0.a, **c0.kw)

@@ -75,6 +75,73 @@ def _worker(rank, world, port, out_dir, backend, issuer, comm_bf16, collective):
     dist.destroy_process_group()
 
 
+def _worker_gather(rank, world, port, out_dir, backend, issuer):
+    """rs+ag on a bf16 model: fp32 master slices on the wire against the bf16 compute copy + fp32 side car (trainer gather=)"""
+    import torch.distributed as dist
+    from test_trainer_cpu import TINY, oracle_cfg
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import reserve_streams
+    from xlxmert_amd.params import ParamStore
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), XL_COMM=issuer)
+    dev = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
+    reserve_streams(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    cfg = XLxmertConfig(**TINY)
+    sd = O.make_state_dict(oracle_cfg(cfg), 3)
+    out = {}
+    for name in ("fp32", "bf16"):
+        for plan in (False, True):
+            store = ParamStore(cfg, dev, torch.bfloat16, task="vis_mask")
+            store.load_named(sd)
+            tr = PretrainStep(cfg, 2, 8, 16, dtype=torch.bfloat16, device=dev, store=store, total_steps=10, lr=1e-2, bucket_mb=0.05,
+                              visual_losses="obj,feat", plan=plan, drop_grads=False, collective="rs+ag", gather=name)
+            tr.ops.set_gemm_wgrad_slabs(1)                   # (reproducible K-split weight gradients: the two runs are compared bit for bit)
+            assert tr.sharded and tr.gather_bf16 == (name == "bf16")
+            for t in range(3):
+                tr.step({k: v.to(dev) for k, v in synthetic_batch(cfg, 2, 8, 4, seed=500 + 10 * t + rank).items()})
+            tr.sync()
+            st = tr.store
+            idx = st.fp32_read_index(0, st.n_used).long()
+            out[f"{name}:{plan}:compute"] = st.compute[:st.n_used].cpu().clone()
+            out[f"{name}:{plan}:fp32_read"] = st.master[idx].cpu().clone()
+            assert tr.verify_replicas() == []
+            out[f"{name}:{plan}:master"] = st.master[:st.n_used].cpu().clone()
+            tr.close()
+    torch.save(out, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_gather(tmp_path, backend, issuer):
+    import torch.multiprocessing as mp
+    from test_trainer_cpu import _free_port
+    world, port = 2, _free_port()
+    mp.spawn(_worker_gather, args=(world, port, str(tmp_path), backend, issuer), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    for plan in (False, True):
+        for what in ("compute", "fp32_read", "master"):
+            assert torch.equal(r0[f"fp32:{plan}:{what}"], r0[f"bf16:{plan}:{what}"]), (plan, what)
+
+
+def test_bf16_all_gather_two_ranks_sharing_one_gpu_gloo(tmp_path):
+    """gather="bf16" (the compute copy + the sparse fp32 side car on the wire) against the fp32 master gather, real kernels, eager
+    and plan: the same compute copy, fp32-read elements and (gathered) master weights, bit for bit, on both ranks"""
+    _run_gather(tmp_path, "gloo", "torch")
+
+
+@two_gpus
+@pytest.mark.parametrize("issuer", ["rccl", "torch"])
+def test_bf16_all_gather_two_gpus_rccl(tmp_path, issuer):
+    _run_gather(tmp_path, "nccl", issuer)
+
+
 def _run_and_check(tmp_path, backend, issuer, comm_bf16, collective):
     import torch.multiprocessing as mp
     from test_trainer_cpu import TINY, _free_port, oracle_cfg, oracle_grads

@@ -356,6 +356,51 @@ def _dp_worker_sharded(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _dp_worker_bf16_gather(rank, world, port, out_dir):
+    """collective="rs+ag" on a bf16 compute copy: the all-gather of the fp32 master slices against gather="bf16" (the compute copy
+    on the wire + the sparse fp32 side car of the elements that are read in fp32)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = XLxmertConfig(**TINY)
+    B, L, grid = 2, 8, 4
+    res = {}
+    for name, kw in (("g32", dict(gather="fp32")), ("g16", dict(gather="bf16"))):
+        store = ParamStore(cfg, "cpu", torch.bfloat16, task="vis_mask")
+        store.load_named(O.make_state_dict(oracle_cfg(cfg), 3))
+        tr = PretrainStep(cfg, B, L, grid * grid, dtype=torch.bfloat16, device="cpu", store=store, ops=FakeOps(torch.bfloat16),
+                          total_steps=10, lr=1e-2, weight_decay=0.01, bucket_mb=0.05, collective="rs+ag", visual_losses="obj,feat", **kw)
+        assert tr.sharded and tr.gather_bf16 == (name == "g16")
+        for t in range(3):
+            tr.step(synthetic_batch(cfg, B, L, grid, seed=500 + 10 * t + rank))
+        st = tr.store
+        res[name + ":compute"] = st.compute[:st.n_used].clone()
+        # the elements the kernels read in fp32 (biases, LayerNorm affines ...) are whole in the master buffer on every rank
+        idx = st.fp32_read_index(0, st.n_used).long()
+        res[name + ":fp32_read"] = st.master[idx].clone()
+        if name == "g16":                      # ... the matrices' fp32 master is the owner's business until gather_state()
+            n_rs = sum(hi - lo for k, lo, hi in tr._segments if k == "rs")
+            assert 0 < idx.numel() < 0.2 * st.n_used and n_rs > 0.9 * st.n_used
+        assert tr.verify_replicas() == [], (name, tr.verify_replicas()[:4])       # (gathers the state first)
+        res[name + ":master"] = st.master[:st.n_used].clone()
+    torch.save(res, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_all_gather_equals_fp32_gather_world2_gloo(tmp_path):
+    """VERDICT r04 item 8 / SURVEY 5.8 "bf16 on the wire": in rs+ag mode the updated parameters travel back as the bf16 compute copy
+    (half the bytes) + a sparse fp32 side car for the elements read in fp32; compute copy, fp32-read elements and (after
+    gather_state) the whole master buffer equal the fp32-gather path's bit for bit, on both ranks."""
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker_bf16_gather, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k                               # replicas identical
+    for what in ("compute", "fp32_read", "master"):
+        assert torch.equal(r0["g32:" + what], r0["g16:" + what]), what     # and equal to the fp32-gather path
+
+
 def test_sharded_exchange_equals_allreduce_world2_gloo(tmp_path):
     """collective="rs+ag": replicas identical, and after three steps the parameters equal the all-reduce path's -- bit for bit
     without clipping (two ranks: a + b either way), to 1e-6 with it (the norm's summation order differs: shard-local partial

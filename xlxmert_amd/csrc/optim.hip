@@ -276,3 +276,35 @@ extern "C" int xl_cast_to_f32(const void* src, float* dst, int64_t n, int dtype,
     XL_CHECK_LAUNCH();
     return XL_OK;
 }
+
+// ---------------------------------------------------------------- sparse fp32 side car of the sharded exchange (trainer gather="bf16")
+// A reduce-scattered slice of the flat parameter buffer goes back to every rank as its bf16 compute copy (half the bytes of the
+// fp32 master); the few elements that are READ in fp32 -- biases, LayerNorm affines, box_fc, mask_feat: ~0.1 % of a slice, scattered
+// through it -- travel separately: every rank packs the ones it owns (zeros elsewhere), one small sum all-reduce makes the pack
+// whole (x + 0 + ... = x), and every rank puts it back into its master buffer.
+__global__ __launch_bounds__(256) void take_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int n,
+                                                       int own_lo, int own_hi, float* __restrict__ dst) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int i = idx[j];
+    dst[j] = (i >= own_lo && i < own_hi) ? src[i] : 0.f;
+}
+__global__ __launch_bounds__(256) void put_f32_kernel(float* __restrict__ dst, const int32_t* __restrict__ idx, int n,
+                                                      const float* __restrict__ src) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) dst[idx[j]] = src[j];
+}
+
+extern "C" int xl_take_f32(const float* src, const int32_t* idx, int n, int own_lo, int own_hi, float* dst, void* stream) {
+    XL_CHECK_ARG(src && idx && dst && n > 0, XL_ERR_BAD_ARG, "xl_take_f32: bad args");
+    hipLaunchKernelGGL(take_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, n, own_lo, own_hi, dst);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}
+
+extern "C" int xl_put_f32(float* dst, const int32_t* idx, int n, const float* src, void* stream) {
+    XL_CHECK_ARG(src && idx && dst && n > 0, XL_ERR_BAD_ARG, "xl_put_f32: bad args");
+    hipLaunchKernelGGL(put_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst, idx, n, src);
+    XL_CHECK_LAUNCH();
+    return XL_OK;
+}

@@ -58,7 +58,7 @@ static const PlanFn kFns[] = {
     XL_PLAN_FN(xl_bce_logits_fwd_bwd), XL_PLAN_FN(xl_sdpa_fwd), XL_PLAN_FN(xl_sdpa_bwd), XL_PLAN_FN(xl_mask_counts),
     XL_PLAN_FN(xl_ce_fwd_bwd), XL_PLAN_FN(xl_featloss_fwd_bwd), XL_PLAN_FN(xl_gather_rows), XL_PLAN_FN(xl_scatter_rows),
     XL_PLAN_FN(xl_gather_labels), XL_PLAN_FN(xl_sumsq), XL_PLAN_FN(xl_schedule_step), XL_PLAN_FN(xl_adamw),
-    XL_PLAN_FN(xl_cast_from_f32), XL_PLAN_FN(xl_cast_to_f32), XL_PLAN_FN(xl_memset), XL_PLAN_FN(xl_stream_fork),
+    XL_PLAN_FN(xl_cast_from_f32), XL_PLAN_FN(xl_cast_to_f32), XL_PLAN_FN(xl_take_f32), XL_PLAN_FN(xl_put_f32), XL_PLAN_FN(xl_memset), XL_PLAN_FN(xl_stream_fork),
     XL_PLAN_FN(xl_rowmax_combine), XL_PLAN_FN(xl_event_record), XL_PLAN_FN(xl_stream_wait), XL_PLAN_FN(xl_ctx_bind),
     XL_PLAN_FN(xl_flush_reductions_on), XL_PLAN_FN(xl_comm_allreduce), XL_PLAN_FN(xl_comm_reduce_scatter), XL_PLAN_FN(xl_comm_allgather), XL_PLAN_FN(xl_comm_wait),
 };

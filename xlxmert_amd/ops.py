@@ -427,6 +427,13 @@ class HipOps:
         st = stream.cuda_stream if stream is not None else self._stream()
         self._call("xl_comm_wait", int(comm), st)
 
+    def take_f32(self, src, idx, own_lo, own_hi, dst):
+        """dst[j] = src[idx[j]] where own_lo <= idx[j] < own_hi, else 0 (xl_take_f32: the sharded exchange's fp32 side car)"""
+        self._call("xl_take_f32", self._p(src), self._p(idx), int(idx.numel()), int(own_lo), int(own_hi), self._p(dst), self._stream())
+
+    def put_f32(self, dst, idx, src):
+        self._call("xl_put_f32", self._p(dst), self._p(idx), int(idx.numel()), self._p(src), self._stream())
+
     def cast_from_f32(self, src, dst, n):
         self._call("xl_cast_from_f32", self._p(src), self._p(dst), n, self.dt, self._stream())
 

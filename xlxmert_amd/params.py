@@ -241,6 +241,22 @@ class ParamStore:
         for t in self._task_flags.values():
             t |= fl
 
+    def fp32_read_index(self, lo, hi):
+        """int32 positions, relative to `lo`, of the elements of the flat range [lo, hi) that the kernels READ IN FP32 from the master
+        buffer (view(): biases, LayerNorm affines, box_fc, mask_feat, ...) -- everything that is not a matrix read through the
+        compute-dtype copy (cview(): Linear weights and embedding tables; box_fc.weight [d, 4] is read in fp32 by the feature encoder).  The sharded exchange's bf16 all-gather carries the
+        matrices; these elements travel in a small fp32 side car (trainer gather="bf16")."""
+        parts = []
+        for name, m in self.index.items():
+            n = _numel(m.shape)
+            matrix = len(m.shape) == 2 and name.endswith("weight") and "box_fc" not in name      # Linear weights, embedding tables
+            a, b = max(lo, m.offset), min(hi, m.offset + n)
+            if not matrix and a < b:
+                parts.append(torch.arange(a - lo, b - lo, dtype=torch.int32))
+        if not parts:
+            return torch.zeros(0, dtype=torch.int32, device=self.device)
+        return torch.cat(parts).sort().values.to(self.device)
+
     def task_flags(self, task):
         """per-chunk optimizer flags for one step of `task` on a multi-task ("all") store: bit 0 = weight decay, bit 1 = skip
         (tensors that get no gradient in that branch of the reference: .grad stays None and AdamW leaves them alone)."""

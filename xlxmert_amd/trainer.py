@@ -53,7 +53,7 @@ class PretrainStep:
                  lr=1e-4, weight_decay=0.0, warmup_ratio=0.05, total_steps=100000, clip_grad_norm=1.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=9595, feat_loss=None, train_dropout=False, store=None,
                  bucket_mb=64, ops=None, task="vis_mask", num_answers=0, visual_losses="obj", grad_comm_dtype=None,
-                 plan=None, drop_grads=None, overlap_optimizer=None, collective=None, overwrite_grads=None):
+                 plan=None, drop_grads=None, overlap_optimizer=None, collective=None, overwrite_grads=None, gather=None):
         """`ops` is injected only by the CPU test-suite (tests/fake_ops.py); the product always runs HipOps.
         task: "vis_mask" (masked-visual-token pretraining step, ref lxmert_pretrain.py), "word_mask" / "matched" (the
         language pretraining branches) or "vqa" (VQA/GQA fine-tune step on real grid features with `num_answers` answers,
@@ -99,6 +99,12 @@ class PretrainStep:
         up to the summation order of the norm; a rank's Adam moments are current on its shards only (gather_state() makes them
         whole: checkpoints, verify_replicas).
         Env XL_COLLECTIVE=allreduce|rs+ag overrides.
+        gather ("fp32" default | "bf16"; env XL_GATHER; collective="rs+ag" with a bf16 compute copy): what the all-gather moves.
+        "bf16": every slice's COMPUTE copy (written by the owner's AdamW pass) -- half the bytes -- plus a sparse fp32 side car for
+        the ~0.1 % of a slice that is read in fp32 (biases, LayerNorm affines, box_fc, mask_feat: ParamStore.fp32_read_index), made
+        whole by one small sum all-reduce per slice (owner's value + zeros).  Same parameters as the fp32 gather, bit for bit;
+        the fp32 master copy of the MATRICES is then current on the owning rank only (gather_state() makes it whole: checkpoints,
+        verify_replicas).
         overwrite_grads: weight gradients with exactly one contribution per step (every Linear weight but the MLM decoder tied to
         the word embeddings) are STORED by the first backward after an optimizer pass instead of accumulated into a cleared buffer
         (engine.dw_overwrite -> xl_gemm_wgrad_group overwrite_mask): the optimizer pass does not clear them (decay_flags bit 2,
@@ -172,6 +178,10 @@ class PretrainStep:
         assert want_c in ("allreduce", "rs+ag"), want_c
         self.sharded = self.exchange and want_c == "rs+ag"
         self.collective = "rs+ag" if self.sharded else "allreduce"
+        want_g = os.environ.get("XL_GATHER") or gather or "fp32"
+        assert want_g in ("fp32", "bf16"), want_g
+        self.gather_bf16 = self.sharded and want_g == "bf16" and self.store.compute_dtype == torch.bfloat16
+        self._vec_idx = {}                     # slice (lo, hi) -> (int32 positions of its fp32-read elements, pack buffer)
         self._segments, self._seg_key, self._seg_events, self._group_seg = [], None, [], {}
         self.exposed_comm_ms = []              # per step: time the main stream waited for collectives after backward
         self._comm_t = None                    # (xl_comm path: one re-recorded event pair = the last step's wait)
@@ -713,37 +723,60 @@ class PretrainStep:
         # What travels back is the fp32 MASTER slice (biases and LayerNorm affines are read from it in fp32, the matrices through
         # the compute-dtype copy, which every rank re-derives from the gathered slice with one cast on the collectives' stream):
         # the same bytes on the wire as the all-reduce's second half, and every rank's master weights stay whole.
+        bf16_wire = self.gather_bf16
         for i in reversed(range(len(self._segments))):          # last-finished slice first: feature encoder, embeddings, layer 0 ...
             kind, lo, hi = self._segments[i]
             a, b = owned[i]
             c0, c1 = a // 256, b // 256
             ops.adamw(st.master[a:b], st.grad[a:b], st.exp_avg[a:b], st.exp_avg_sq[a:b],
-                      st.compute[a:b] if (kind == "ar" and not fp32) else None,
+                      st.compute[a:b] if ((kind == "ar" or bf16_wire) and not fp32) else None,
                       flags[c0:c1], self.sumsq if self.clip > 0 else None, self.lrs, b - a, b1, b2, self.eps, self.wd, self.clip,
                       grad_scale=1.0 / W, chunk_steps=cs[c0:c1] if cs is not None else None, zero_grad=False)
             if kind != "rs":
                 continue
-            piece = st.master[lo:hi]
+            piece = st.compute[lo:hi] if bf16_wire else st.master[lo:hi]
+            side = None
+            if bf16_wire:                   # the slice's fp32-read elements: this rank's (zeros elsewhere), to be summed over the ranks
+                idx, pack = self._vector_pack(lo, hi)
+                if idx is not None:
+                    ops.take_f32(st.master[lo:hi], idx, a - lo, b - lo, pack)
+                    side = (idx, pack)
             if self.xl_comm is not None:
                 self.ops.comm_allgather(self.xl_comm, piece, hi - lo, r, W)
+                if side is not None:
+                    self.ops.comm_allreduce(self.xl_comm, side[1], side[0].numel())
                 with torch.cuda.stream(self._comm_stream):
-                    if not fp32:
+                    if side is not None:
+                        ops.put_f32(st.master[lo:hi], side[0], side[1])
+                    if not fp32 and not bf16_wire:
                         ops.cast_from_f32(piece, st.compute[lo:hi], hi - lo)
                     if hooked:
                         ops.event_record(self._seg_events[i], self._comm_stream)
             else:
                 per = (hi - lo) // W
                 self._host_op(lambda piece=piece, per=per: dist.all_gather_into_tensor(piece, piece[r * per:(r + 1) * per].clone()))
-                if not fp32:
+                if side is not None:
+                    self._host_op(lambda t=side[1]: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+                    ops.put_f32(st.master[lo:hi], side[0], side[1])
+                if not fp32 and not bf16_wire:
                     ops.cast_from_f32(piece, st.compute[lo:hi], hi - lo)
         if self.xl_comm is not None and not hooked:
             ops.comm_wait(self.xl_comm)
         # the non-owned parts of the gradient buffer hold partial sums: the next backward clears the whole buffer itself
         self.engine.grad_is_zero = False
 
+    def _vector_pack(self, lo, hi):
+        """(int32 positions inside [lo, hi) of the elements read in fp32, fp32 pack buffer) of a scattered slice -- (None, None)
+        when it has none; built once per slice (the segment list repeats from step to step)"""
+        if (lo, hi) not in self._vec_idx:
+            idx = self.store.fp32_read_index(lo, hi)
+            self._vec_idx[(lo, hi)] = (idx, torch.zeros(idx.numel(), dtype=torch.float32, device=self.device)) if idx.numel() else (None, None)
+        return self._vec_idx[(lo, hi)]
+
     def gather_state(self):
         """sharded exchange: make the Adam moments whole on every rank (each rank's are current on its shards only) -- before a
-        checkpoint is written or replicas are compared.  Two all-gathers per slice; off the step."""
+        checkpoint is written or replicas are compared.  Two all-gathers per slice (three with gather="bf16": the fp32 master
+        copy of the matrices is current on the owning rank only); off the step."""
         if not self.sharded or not self._segments:
             return
         self.sync()
@@ -752,7 +785,7 @@ class PretrainStep:
             if kind != "rs":
                 continue
             per = (hi - lo) // W
-            for buf in (st.exp_avg, st.exp_avg_sq):              # (the master weights are gathered by every step)
+            for buf in (st.exp_avg, st.exp_avg_sq) + ((st.master,) if self.gather_bf16 else ()):      # (fp32 gather: the master weights are gathered by every step)
                 piece = buf[lo:hi]
                 dist.all_gather_into_tensor(piece, piece[r * per:(r + 1) * per].clone())
         self.sync()
