@@ -872,20 +872,32 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
 template <typename T, int NIT>
 __device__ __forceinline__ void embed_add_rows(const T* __restrict__ dpre, int N, int lane, int rr, int n,
                                                float (&acc)[NIT][Elem<T>::VEC]) {
-    // acc += dpre[row of lane t], t = 0 .. n-1 (n <= 64, wave-uniform), in that order; eight rows requested at a time
+    // acc += dpre[row of lane t], t = 0 .. n-1 (n <= 64, wave-uniform), in that order; sixteen rows requested at a time, held as
+    // loaded (16 bytes per vector) until they are added
     constexpr int VEC = Elem<T>::VEC;
-    for (int t0 = 0; t0 < n; t0 += 8) {
-        float tmp[8][NIT][VEC];
+    constexpr int R = 16;
+    for (int t0 = 0; t0 < n; t0 += R) {
+        uint4 raw[R][NIT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (t0 + u < n) load_row<T, NIT>(dpre + (size_t)__shfl(rr, t0 + u, 64) * N, N, lane, tmp[u]);
+        for (int u = 0; u < R; ++u)
+            if (t0 + u < n) {
+                const T* row = dpre + (size_t)__shfl(rr, t0 + u, 64) * N;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+                for (int it = 0; it < NIT; ++it) {
+                    const int col = (it * 64 + lane) * VEC;
+                    raw[u][it] = col < N ? *reinterpret_cast<const uint4*>(row + col) : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < R; ++u)
             if (t0 + u < n)
 #pragma unroll
-                for (int it = 0; it < NIT; ++it)
+                for (int it = 0; it < NIT; ++it) {
+                    float v[VEC];
+                    unpack_raw(raw[u][it], v);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[it][i] += tmp[u][it][i];
+                    for (int i = 0; i < VEC; ++i) acc[it][i] += v[i];
+                }
     }
 }
 template <typename T, int NIT>
@@ -937,15 +949,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dp
 
 // With the rows handed over SORTED by (token id, row) -- `order`, a stable argsort of the ids computed where the ids are made (data
 // loader; the engine sorts on the device otherwise): a BLOCK per sorted position; the block at the first position of an id owns that
-// table row (all others leave after three loads), and its four waves walk the id's run 64 candidates at a time, wave w the chunks
-// w, w + 4, ... (one load of the order, one of the ids, a ballot; sorted: the matches are a prefix); the four partial sums meet in
+// table row (all others leave after three loads), and its eight waves walk the id's run 32 candidates at a time, wave w the chunks
+// w, w + 8, ... (one load of the order, one of the ids, a ballot; sorted: the matches are a prefix); the eight partial sums meet in
 // LDS and are added in wave order -- a fixed tree over the run, the same bits every time.  A token in every sentence ([CLS], [SEP]:
-// 256 occurrences) costs each wave 64 rows instead of one wave 256: ~15 us for the launch instead of ~100.
+// 256 occurrences) costs each wave 32 rows (two requests of 16) instead of one wave 256 dependent ones.
 template <typename T, int NIT>
-__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(512) void embed_bwd_sorted_kernel(const T* __restrict__ dpre, const int64_t* __restrict__ ids,
                                                                const int32_t* __restrict__ order, float* dword, int M, int N) {
-    constexpr int VEC = Elem<T>::VEC;
-    __shared__ float part[3][NIT][64][VEC];
+    constexpr int VEC = Elem<T>::VEC, W = 8;
+    __shared__ float part[W - 1][NIT][64][VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x;
     const int r = order[j];
@@ -960,13 +972,15 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const T* __restri
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[it][i] = 0.f;
     }
-    for (int j0 = j + 1 + 64 * wave; j0 < M; j0 += 256) {
+    // wave w: the run's positions j + 1 + 32 w .. + 31, then + 32 W further on ... (32 candidates per step)
+    for (int j0 = j + 1 + 32 * wave; j0 < M; j0 += 32 * W) {
         const int jj = j0 + lane;
-        const int rr = jj < M ? order[jj] : 0;
-        const unsigned long long m = __ballot(jj < M && ids[rr] == id);
-        const int n = m == ~0ull ? 64 : __builtin_ctzll(~m);         // length of the run's part in this chunk
+        const bool cand = lane < 32 && jj < M;
+        const int rr = cand ? order[jj] : 0;
+        const unsigned long long m = __ballot(cand && ids[rr] == id) | 0xFFFFFFFF00000000ull;
+        const int n = m == ~0ull ? 32 : __builtin_ctzll(~m);         // length of the run's part in this chunk
         embed_add_rows<T, NIT>(dpre, N, lane, rr, n, acc);
-        if (n < 64) break;
+        if (n < 32) break;
     }
     if (wave > 0) {
 #pragma unroll
@@ -977,9 +991,11 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const T* __restri
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
+        for (int w = 0; w < W - 1; ++w)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[it][i] = ((acc[it][i] + part[0][it][lane][i]) + part[1][it][lane][i]) + part[2][it][lane][i];
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[it][i] += part[w][it][lane][i];
         embed_commit<T, NIT>(dword + (size_t)id * N, N, lane, acc);
     }
 }
@@ -1782,7 +1798,7 @@ extern "C" int xl_embed_bwd(const void* dpre, const int64_t* ids, const int64_t*
     XL_CHECK_ARG(N <= 64 * 16, XL_ERR_BAD_SHAPE, "xl_embed_bwd: hidden size %d > 1024", N);
     const dim3 grid((M + WPB - 1) / WPB);
 #define XL_EMBED_WORD(NIT)                                                                                                           \
-    if (order != nullptr) hipLaunchKernelGGL((embed_bwd_sorted_kernel<T, NIT>), dim3(M), dim3(256), 0, st, (const T*)dpre, ids, order, dword, M, N); \
+    if (order != nullptr) hipLaunchKernelGGL((embed_bwd_sorted_kernel<T, NIT>), dim3(M), dim3(512), 0, st, (const T*)dpre, ids, order, dword, M, N); \
     else hipLaunchKernelGGL((embed_bwd_kernel<T, NIT>), grid, dim3(256), 0, st, (const T*)dpre, ids, dword, M, N);                   \
     if (tt != nullptr && n_types > 1)                                                                                                \
         hipLaunchKernelGGL((embed_bwd_type_kernel<T, NIT>), dim3(n_types - 1), dim3(256), 0, st, (const T*)dpre, tt, dtype_tab, M, N);
