@@ -573,6 +573,56 @@ def test_packed_language_rows_equal_the_dense_path(monkeypatch, row_pad):
     assert maxdiff(g0, g1) < 5e-6, maxdiff(g0, g1)
 
 
+def check_paired_blocks(ops_factory, device, tol):
+    """Engine(pair_blocks=True) -- the visual / language sub-blocks of the cross layers and a visual + a language layer of the two
+    stacks in lock step on one stream, their contractions two per launch (xl_gemm_pair) -- against the two-stream engine: outputs,
+    hidden states, losses and EVERY gradient, with the language lane's own kernels on this stream (XL_PAIR_SIDE=0) and on the
+    language stream (1).  tiny_955 has 9 language against 5 visual layers: language layers 0-3 run unpaired ahead of the pairs."""
+    g = load_golden("tiny_955")
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "l_layers", "x_layers",
+                                                      "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    inp = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in golden_inputs(g).items()}
+    B, L = inp["input_ids"].shape
+    V = inp["cluster_ids"].shape[1]
+    res = {}
+    for mode in ("two_streams", "paired", "paired_side"):
+        store = ParamStore(cfg, device, torch.float32, task="all")
+        store.load_named(sd)
+        eng = Engine(cfg, store, ops_factory(), B, L, V, need_lang=True)
+        eng.pair_blocks, eng.pair_side = mode != "two_streams", mode == "paired_side"
+        eng.sync_compute_weights()
+        eng.set_inputs(inp["input_ids"], inp["attention_mask"], inp["token_type_ids"], inp["visual_pos"],
+                       cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], obj_labels=inp["obj_labels"])
+        assert len(eng._stack_pairs()) == (min(cfg.l_layers, cfg.r_layers) if eng.pair_blocks else 0)
+        lang, vis, pooled = (t.clone() for t in eng.encoder_forward())
+        lh, vh = eng.hidden_states()
+        hs = [t.clone() for t in lh + vh]
+        eng.store.grad.zero_()
+        eng.vis_mask_forward_backward()
+        gl = torch.randn(B * L, cfg.hidden_size, generator=torch.Generator().manual_seed(1)).to(device) * (inp["attention_mask"].reshape(-1, 1) != 0)
+        eng.backward_from_outputs(d_lang=gl.view(B, L, -1), d_vis=None, d_pooled=torch.ones(B, cfg.hidden_size, device=device))
+        if device != "cpu":
+            torch.cuda.synchronize()
+        res[mode] = (lang, vis, pooled, hs, eng.losses.clone(), eng.store.grad.clone())
+    ref = res["two_streams"]
+    real = (inp["attention_mask"].reshape(-1) != 0)
+    assert maxdiff(ref[0].view(B * L, -1)[real], torch.from_numpy(g["lang"]).to(device).view(B * L, -1)[real]) < 1e-4
+    for mode in ("paired", "paired_side"):
+        got = res[mode]
+        for a, b in zip(ref[:3], got[:3]):
+            assert maxdiff(a, b) <= tol, mode
+        for a, b in zip(ref[3], got[3]):
+            assert maxdiff(a, b) <= tol, mode
+        assert maxdiff(ref[4], got[4]) <= tol and maxdiff(ref[5], got[5]) <= 10 * tol, (mode, maxdiff(ref[5], got[5]))
+
+
+def test_paired_blocks_equal_the_two_stream_engine():
+    check_paired_blocks(lambda: FakeOps(torch.float32), "cpu", 0.0)
+
+
 def check_attention_probs(g, eng, tol):
     """Engine.attention_probs() against the reference's LxmertModel(output_attentions=True) (fixture attn_tiny): per language
     layer [B,H,L,L], per visual layer [B,H,V,V] (ragged visual mask), per cross layer [B,H,L,V]; rows of [PAD] queries are

@@ -1311,6 +1311,59 @@ def test_two_library_contexts_interleaved_in_one_process():
     assert torch.equal(tr.store.master, alone_p)
 
 
+def test_paired_blocks_equal_the_two_stream_engine_on_the_gpu():
+    """Engine.run_pair on the real kernels and streams (fp32: every contraction of a pair falls back to its two xl_gemm launches
+    inside xl_gemm_pair; the lanes, scratch generations, deferred column sums and the language stream hand-overs are the real ones)"""
+    from test_engine_cpu import check_paired_blocks
+    from xlxmert_amd.ops import HipOps
+    check_paired_blocks(lambda: HipOps(torch.float32), "cuda", 2e-5)
+
+
+@pytest.mark.parametrize("side", [False, True])
+def test_paired_blocks_full_width_bf16_step(side):
+    """the benchmarked architecture (9/5/5, d = 768) in bf16 with the pairs going through ONE launch each (xl_gemm_pair's paired
+    instances, ping-pong kernel forced): loss and every gradient norm against the reference fixture full_955, as the two-stream
+    engine is checked -- and against the two-stream engine itself on the same inputs."""
+    from test_engine_cpu import make_engine
+    from xlxmert_amd.ops import HipOps
+    g = load_golden("full_955")
+    res = {}
+    for mode in ("two_streams", "paired"):
+        ops = HipOps(torch.bfloat16)
+        ops.set_gemm_pingpong(2)
+        eng, oc, sd, inp = make_engine_on(g, ops, torch.bfloat16, pair=(mode == "paired"), side=side)
+        losses = eng.vis_mask_forward_backward()
+        torch.cuda.synchronize()
+        res[mode] = (losses.clone(), eng.store.grad[:eng.store.n_used].clone())
+    (l0, g0), (l1, g1) = res["two_streams"], res["paired"]
+    assert torch.allclose(l0, l1, rtol=2e-3, atol=1e-4), (l0, l1)
+    rel = (g0 - g1).norm().item() / g0.norm().item()
+    assert rel < 2e-2, rel                         # (bf16: the paired launches are bit-identical, fp32 atomics / dropout-free noise only)
+
+
+def make_engine_on(g, ops, dtype, pair, side):
+    from _util import golden_cfg, golden_inputs
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import Engine
+    from xlxmert_amd.params import ParamStore
+    oc = golden_cfg(g)
+    cfg = XLxmertConfig(**{k: getattr(oc, k) for k in ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "l_layers", "x_layers",
+                                                      "r_layers", "visual_feat_dim", "visual_pos_dim", "num_clusters")})
+    sd = O.make_state_dict(oc, int(g["seed"]))
+    inp = {k: v.cuda() for k, v in golden_inputs(g).items()}
+    B, L = inp["input_ids"].shape
+    V = inp["cluster_ids"].shape[1]
+    store = ParamStore(cfg, "cuda", dtype, task="vis_mask")
+    store.load_named(sd)
+    eng = Engine(cfg, store, ops, B, L, V, need_lang=False)
+    eng.pair_blocks, eng.pair_side = pair, side
+    eng.sync_compute_weights()
+    eng.set_inputs(inp["input_ids"], inp["attention_mask"], inp["token_type_ids"], inp["visual_pos"],
+                   cluster_ids=inp["cluster_ids"], vis_mask=inp["vis_mask"], obj_labels=inp["obj_labels"])
+    return eng, oc, sd, inp
+
+
 @pytest.mark.parametrize("plan", [False, True])
 def test_training_step_is_bit_reproducible(plan):
     """The same three training steps (bf16, dropout on, four streams, deferred reductions, grouped weight gradients, overwrite
