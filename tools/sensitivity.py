@@ -56,6 +56,9 @@ V = {
     and not (tag.startswith("l") and int(tag[1:]) < 4),
     "no_lang_sdpa_paired": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("sdpa_fwd", "sdpa_bwd") and not (tag.startswith("l") and int(tag[1:]) < 4),
     "no_lang_ln_paired": lambda op, tag, a: lang(tag) and "+" not in tag and op in ("layernorm_fwd", "layernorm_bwd") and not (tag.startswith("l") and int(tag[1:]) < 4),
+    "no_langstack_gemm": lambda op, tag, a: op == "gemm" and tag.startswith("l"),
+    "no_langstack_anything": lambda op, tag, a: tag.startswith("l") and op in ("gemm", "sdpa_fwd", "sdpa_bwd", "layernorm_fwd", "layernorm_bwd", "gemm_wgrad_group"),
+    "no_xlang_gemm": lambda op, tag, a: op == "gemm" and tag.startswith("x") and tag.endswith("l"),
     "no_embed_bwd": lambda op, tag, a: op == "embed_bwd",
     "no_lang_wgrad": lambda op, tag, a: op == "gemm_wgrad_group" and lang(tag),
     "no_vis_wgrad": lambda op, tag, a: op == "gemm_wgrad_group" and not lang(tag),
