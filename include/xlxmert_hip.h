@@ -97,6 +97,13 @@ int  xl_set_gemm_persistent(int on);
  * run on the 128x128 kernel at 0.10 MFMA-busy: -0.15..-0.25 ms per step --, 2 = whenever eligible (measured equal to the whole-CU
  * tiles on the large launches); env XL_GEMM_DUO.  Bit-identical results to the other tile shapes. */
 int  xl_set_gemm_duo(int mode);
+/* 128x192 output tiles by EIGHT waves of 32x96 at 128 registers (csrc/gemm_q.hip): two workgroups per CU, four waves per SIMD -- each
+ * workgroup keeps two waves per SIMD in its K loop, so one's prologue / epilogue / hand-over runs under the other's K loop (the whole-CU
+ * 256x256 tile spends 30-40 % of a K = 768 tile's time there with nothing to overlap it).  0 = never, 1 = contractions of depth <=
+ * XL_GEMM_Q_MAX_K (1024) with at least XL_GEMM_Q_MIN_TILES (256) tiles, 2 = every eligible launch (forward / dX layouts, bf16 in / out,
+ * a fast epilogue kind, no fused column sums, M % 128 == N % 192 == K % 64 == 0); env XL_GEMM_Q sets the initial value.  Bit-identical
+ * results to the other tile shapes. */
+int  xl_set_gemm_q(int mode);
 /* K split of a launch WITH an epilogue (forward / dX layouts, bf16 in and out, fast epilogue): a launch of at most
  * XL_GEMM_SPLIT_EPI_MAX_TILES (80) output tiles of 256x192 / 256x256 whose contraction is at least XL_GEMM_SPLIT_EPI_MIN_K (1536)
  * deep runs every tile as 2..4 K slices of >= 12 K tiles on whole-CU workgroups; the slices meet in the stream's slab workspace

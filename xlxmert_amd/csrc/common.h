@@ -267,6 +267,7 @@ struct Ctx {
     int tail_max = -1, tail_min_k = 4096;     // xl_set_gemm_tail_split; -1 = XL_GEMM_TAIL_MAX (64) / XL_GEMM_TAIL_MIN_K (4096)
     int wgrad_slabs = -1;                     // xl_set_gemm_wgrad_slabs; -1 = XL_GEMM_WGRAD_SLABS (default 0)
     int gemm_duo = -1;                        // xl_set_gemm_duo; -1 = XL_GEMM_DUO (default 1: small launches)
+    int gemm_q = -1;                // 128x192 tiles, eight 128-register waves, two workgroups per CU (xl_set_gemm_q; -1: env XL_GEMM_Q)
     int gemm_pair = -1;             // two-problem launches (xl_gemm_pair / xl_set_gemm_pair; -1: env XL_GEMM_PAIR, default 1 = on)
     int gemm_split_epi = -1;        // K split of few-tile launches with an epilogue (xl_set_gemm_split_epi; -1: env XL_GEMM_SPLIT_EPI, default 0 = off)
     int gemm_persist = -1;                    // xl_set_gemm_persistent; -1 = XL_GEMM_PERSIST (default 0)

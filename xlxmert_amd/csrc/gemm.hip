@@ -471,6 +471,26 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             }
         }
     }
+    // 128x192 tiles by eight waves of 32 x 96 at 128 registers, two workgroups per CU (gemm_q.hip): every workgroup keeps two waves per
+    // SIMD in its K loop, so one's prologue / epilogue / hand-over runs under the other's K loop.  Mode 0 never, 1 contractions of at
+    // most XL_GEMM_Q_MAX_K (the K = 768 launches, a third of whose tile time the whole-CU tile spends outside the K loop), 2 every
+    // eligible launch.  Eligible: forward / dX layouts, bf16 in / out, fast epilogue kind with an instance, no fused column sums,
+    // M % 128 == N % 192 == K % 64 == 0, enough tiles to fill the chip twice over.
+    if (cx.gemm_q < 0) cx.gemm_q = env_int("XL_GEMM_Q", 0);
+    static const int q_max_k = env_int("XL_GEMM_Q_MAX_K", 1024);
+    static const int q_min_tiles = env_int("XL_GEMM_Q_MIN_TILES", 64);
+    static const int q_max_n = env_int("XL_GEMM_Q_MAX_N", 2304);
+    static const int q_max_tiles = env_int("XL_GEMM_Q_MAX_TILES", 1 << 30);
+    if (!epi_split && pp_ok && pp_mode && cx.gemm_q && a_kmajor && M % 128 == 0 && N % 192 == 0 && K % 64 == 0 && out_dtype == in_dtype &&
+        !accumulate && epik >= 0 && colsum_out == nullptr && splitk == 1 && !p.atomic_out && q_has_instance(b_kmajor, epik) &&
+        (double)M * lda < 1e9 && (cx.gemm_q == 2 || (K <= q_max_k && N <= q_max_n && (long)(M / 128) * (N / 192) >= q_min_tiles && (long)(M / 128) * (N / 192) <= q_max_tiles))) {
+        p.tiles_m = M / 128; p.tiles_n = N / 192;
+        p.splitk = 1; p.kper = K; p.tail_tiles = 0;
+        hipError_t e = launch_q(p, b_kmajor, epik, p.tiles_m * p.tiles_n, st);
+        XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        XL_CHECK_LAUNCH();
+        return XL_OK;
+    }
     // 128x192 "duo" tiles, two four-wave workgroups per CU (gemm_pp_kernel.h PPGeo<192, 128>): same eligibility as the 256x192 tile
     // (forward / dX layouts, N a multiple of 192, fast epilogue, plain stores) with M a multiple of 128
     // mode 1: the launches of fewer than XL_GEMM_DUO_MAX_TILES 256x256 tiles (the language stream's: 3328 packed rows = 39 tiles,
@@ -607,6 +627,12 @@ extern "C" int xl_gemm_pair(const void* A0, const void* B0, void* C0, const floa
     XL_CHECK_LAUNCH();
     for (int i = 0; i < 2; ++i)
         if (cs_out[i] != nullptr) { launch_colsum_reduce(cs_ws[i], M[i] / 128, N, cs_out[i], st); XL_CHECK_LAUNCH(); }
+    return XL_OK;
+}
+
+extern "C" int xl_set_gemm_q(int mode) {
+    XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_q: mode %d", mode);
+    ctx().gemm_q = mode;
     return XL_OK;
 }
 

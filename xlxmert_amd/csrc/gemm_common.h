@@ -352,10 +352,10 @@ __device__ __forceinline__ void sub_row_from_lds(const float* wbuf, int row, int
     const float4 hi = *reinterpret_cast<const float4*>(wbuf + row * W + c8 * 8 + 4);
     v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
-template <int EPI, int W>
+template <int EPI, int W, int ROWS = 64>
 __device__ __forceinline__ void sub_operand_load(const GemmParams& p, int lane, int mq, int nq, QuadOperand& op) {
     if constexpr (EPI == XL_EPI_RESIDUAL || EPI == XL_EPI_DGELU || EPI == XL_EPI_MULAUX) {
-        constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = 64 / RPP;
+        constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = ROWS / RPP;
         const bf16_t* src = reinterpret_cast<const bf16_t*>(EPI == XL_EPI_RESIDUAL ? p.residual : p.aux);
         const int ld = EPI == XL_EPI_RESIDUAL ? p.ldr : p.ldx;
         const bf16_t* s0 = src + (size_t)(mq + lane / LPR) * ld + nq + (lane % LPR) * 8;
@@ -384,6 +384,14 @@ __device__ __forceinline__ void quad_operand_load(const GemmParams& p, int lane,
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) op.row[ps] = *reinterpret_cast<const uint4*>(s0 + (size_t)(ps * 8) * ld);
     }
+}
+
+// 32 rows x 32 columns (one accumulator) -> 4 KiB of wave-private LDS, row pitch 32 floats (gemm_q.hip: third accumulator of a 32 x 96 wave tile)
+__device__ __forceinline__ void acc32_to_lds(float* wbuf, int lane, const f32x16_t& a) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wbuf[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[r];
+    __builtin_amdgcn_wave_barrier();
 }
 
 // 32 rows x 64 columns (two accumulators side by side) -> 8 KiB of wave-private LDS, row pitch 64 floats (the quad image's upper half)
@@ -531,10 +539,10 @@ __device__ __forceinline__ void epilogue_rows_fast(const GemmParams& p, const fl
 }
 
 // rows of a 64 x W sub-tile already in LDS (sub_to_lds) -> epilogue math -> 16-byte stores (no fused column sums)
-template <int EPI, int W, bool CS = false>
+template <int EPI, int W, bool CS = false, int ROWS = 64>
 __device__ __forceinline__ void sub_rows_fast(const GemmParams& p, const float* wbuf, int lane, int mq, int nq,
                                               const QuadOperand& op, const float (&bv)[8], uint64_t seed, float (&cs)[8]) {
-    constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = 64 / RPP;
+    constexpr int LPR = W / 8, RPP = 64 / LPR, NPS = ROWS / RPP;
     const int c8 = lane % LPR, rr = lane / LPR;
     const int n = nq + c8 * 8;
     const bool drop = p.p_drop > 0.0f;
@@ -743,6 +751,11 @@ hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, 
 struct PairParams { GemmParams p[2]; int tiles0; };
 hipError_t launch_pp_pair(const PairParams& pp, int b_kmajor, int epik, int nblk, hipStream_t st);
 bool pp_pair_has_instance(int b_kmajor, int epik);
+// gemm_q.hip: 128 x 192 tiles by EIGHT waves of 32 x 96, 128 registers per wave, 80 KiB of LDS -- two workgroups per CU that each keep
+// two waves per SIMD in the K loop; forward / dX layouts, fast epilogue, M % 128 == N % 192 == K % 64 == 0.  hipErrorInvalidValue: no
+// instance for this (layout, epilogue kind)
+hipError_t launch_q(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);
+bool q_has_instance(int b_kmajor, int epik);
 // persistent variant (gemm_pp_persist.hip): A K-major, bf16 in / out, every tile interior, fast epilogue, several rounds of tiles;
 // hipErrorInvalidValue when the (layout, epilogue kind) has no instance
 hipError_t launch_pp_persist(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);

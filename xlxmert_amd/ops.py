@@ -116,6 +116,10 @@ class HipOps:
         """128x192 tiles, two four-wave workgroups per CU: 0 never, 1 small launches (default), 2 every eligible launch."""
         self._call("xl_set_gemm_duo", int(mode))
 
+    def set_gemm_q(self, mode):
+        """128x192 tiles by eight 128-register waves, two workgroups per CU: 0 never, 1 short contractions, 2 every eligible launch."""
+        self._call("xl_set_gemm_q", int(mode))
+
     def set_gemm_split_epi(self, on):
         """K split of few-tile, deep-K launches with an epilogue through the stream's slab workspace: 0 never (default), 1 when eligible."""
         self._call("xl_set_gemm_split_epi", int(on))
