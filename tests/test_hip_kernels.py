@@ -1175,9 +1175,11 @@ def test_sdpa_dropout_fwd_bwd(nq, nk, dh, dtype):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("nq,nk,dh,packed,masked", [(100, 100, 64, True, False), (65, 64, 64, False, True), (64, 130, 16, False, True),
-                                                     (200, 20, 64, True, False), (512, 70, 32, False, False)])
+                                                     (200, 20, 64, True, False), (512, 70, 32, False, False), (512, 512, 64, True, False),
+                                                     (300, 300, 64, False, True), (128, 64, 64, False, False), (20, 200, 64, False, True)])
 def test_sdpa_long_sequences(nq, nk, dh, packed, masked, dtype):
-    """--max_text_length above 64 (ref param.py:140): xl_sdpa_fwd / _bwd / xl_attn_probs take nq, nk up to 512 on the plain
+    """--max_text_length above 64 (ref param.py:140): xl_sdpa_fwd / _bwd / xl_attn_probs take nq, nk up to 512 -- bf16 on the
+    matrix cores (sdpa_fwd_flash / sdpa_bwd_flash_q / _k: 64-key / 64-query blocks, online softmax), fp32 on the plain
     long-sequence kernels (online softmax forward, two-launch backward through a delta scratch in the caller's workspace).  Same
     conventions as the on-chip kernels -- dropout counters, log-sum-exp layout, key masks, packed rows with zeroed pad rows, bias
     gradients -- against the host restatement."""

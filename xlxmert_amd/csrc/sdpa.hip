@@ -152,9 +152,9 @@ __global__ __launch_bounds__(64) void sdpa_bwd_generic(const T* __restrict__ q, 
 
 // ================================================================== long sequences (nq or nk in 65..512)
 // --max_text_length above 64 (ref param.py:140; the position table has 512 rows): not the benchmarked shapes, so these are the
-// plain kernels -- one lane per query (resp. key), fp32 arithmetic, the other side streamed from global memory -- a CORRECTNESS
-// FALLBACK at scalar-FMA speed (no MFMA, no LDS staging: nowhere near the chip; the benchmarked configuration, 20 text tokens, never
-// takes it), built for any length up to MAXLONG, with the same conventions as the kernels above (dropout counters, log-sum-exp layout,
+// plain kernels -- one lane per query (resp. key), fp32 arithmetic, the other side streamed from global memory -- the fp32 path and a
+// CORRECTNESS FALLBACK at scalar-FMA speed (bf16 launches take sdpa_*_flash below, ~100x faster; the benchmarked configuration, 20 text
+// tokens, takes neither), built for any length up to MAXLONG, with the same conventions as the kernels above (dropout counters, log-sum-exp layout,
 // packed rows, zeroed pad rows).  Forward: online softmax (running max / sum, the accumulator rescaled), dropout applied to the
 // un-normalised terms (linear).  Backward in two launches: per query, delta_i = sum_j p_ij dp_ij and dQ_i (delta also goes to a
 // caller-owned fp32 scratch [B, H, nq]); per key, dK_j and dV_j over all queries with the saved delta -- no atomics.
@@ -755,6 +755,298 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
     }
 }
 
+// ================================================================== long sequences on the matrix cores (nq or nk in 65..512, bf16)
+// --max_text_length above 64 (ref param.py:140): the same 32x32x16 MFMA machinery as the on-chip kernels, walked over 64-key (resp.
+// 64-query) blocks.  Forward: a workgroup per (batch, head, 64-query block), two waves of 32 queries; per key block the scores
+// S^T = K Q^T (a lane owns a query), an ONLINE softmax -- running maximum and sum per lane, the output accumulators O^T[d][q] rescaled
+// by the lane's exp(m_old - m_new), dropout applied to the un-normalised terms -- and O^T += V^T P^T with V staged in LDS; the division
+// by the sum and the log-sum-exp at the end.  Backward in two launches like the plain fallback above (sdpa_bwd_long_*): per query
+// block, two passes over the key blocks (delta = sum_j P~ dP, then dQ^T += K^T dS^T; delta also goes to the caller's scratch), and per
+// key block one pass over the query blocks (dV^T += dO^T P~, dK^T += Q^T dS) with the saved log-sum-exp and delta.  No atomics; same
+// dropout counters, packed rows and zeroed pad rows as everywhere else.
+template <int DH, bool TR, bool DROP>
+__global__ __launch_bounds__(128) void sdpa_fwd_flash(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                      const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
+                                                      bf16_t* __restrict__ o, float* __restrict__ lse, int H, int nq, int nk,
+                                                      int ldq, int ldk, int ldv, int ldo, float scale, float p_drop, float inv_keep,
+                                                      uint64_t seed, const uint64_t* __restrict__ step_seed, VarLen vl) {
+    if (DROP) seed = with_step_seed(seed, step_seed);
+    __shared__ __attribute__((aligned(16))) uint8_t vt[64 * Tile<DH>::PITCH];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, qb0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    if (blockIdx.y == 0) zero_pad_rows<bf16_t>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, o, ldo, h * DH, DH, tid, 128);
+    if (qb0 >= nq) return;
+    const bf16_t* qb = q + (size_t)q0 * ldq;
+    const bf16_t* kb = k + (size_t)k0 * ldk;
+    const bf16_t* vb = v + (size_t)k0 * ldv;
+    const int qi = qb0 + j * 32 + l31;
+    constexpr int ND = (DH + 31) / 32;
+    bf16x8_t fq[DH / 16];
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) fq[s] = gfrag(qb, ldq, qi, nq, h * DH + s * 16 + hi * 8);
+    f32x16_t oa[ND];
+#pragma unroll
+    for (int id = 0; id < ND; ++id) oa[id] = zero16();
+    float mx = -INFINITY, sum = 0.f;
+    for (int kb0 = 0; kb0 < nk; kb0 += 64) {
+        const int nkb = nk - kb0;                      // keys left from this block on (rows >= nkb of the block do not exist)
+        TileStage<DH, 64, 128> sv;
+        sv.load(vb + (size_t)kb0 * ldv, ldv, nkb, h * DH, tid);
+        bf16x8_t fk[2][DH / 16];
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fk[i][s] = gfrag(kb + (size_t)kb0 * ldk, ldk, i * 32 + l31, nkb, h * DH + s * 16 + hi * 8);
+        f32x16_t st[2];
+        st[0] = zero16(); st[1] = zero16();
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) st[i] = mfma32(fk[i][s], fq[s], st[i]);
+        if (kb0 > 0) __syncthreads();                  // both waves are done with the previous block's V tile
+        sv.store(vt, tid);
+        const uint64_t kbits = key_bits(key_mask, b * nk_cap + kb0, min(64, nk_cap - kb0), lane);
+        float bm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = i * 32 + acc_row(r, hi);
+                const bool ok = key < nkb && ((kbits >> key) & 1ull) != 0;
+                const float sc = ok ? st[i][r] * scale : -INFINITY;
+                st[i][r] = sc;
+                bm = fmaxf(bm, sc);
+            }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float nm = fmaxf(mx, bm);
+        const float corr = (mx == -INFINITY) ? 0.f : __expf(mx - nm);      // (nm = -inf only while every key so far is masked: sum = 0)
+        float bs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = st[i][r] == -INFINITY ? 0.f : __expf(st[i][r] - nm);
+                bs += e;
+                float pv = e;
+                if (DROP) pv *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)(kb0 + i * 32 + acc_row(r, hi)), p_drop, inv_keep);
+                st[i][r] = pv;
+            }
+        bs += __shfl_xor(bs, 32, 64);
+        sum = sum * corr + bs;
+        mx = nm;
+#pragma unroll
+        for (int id = 0; id < ND; ++id)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oa[id][r] *= corr;
+        __syncthreads();                               // V tile staged by both waves
+#pragma unroll
+        for (int id = 0; id < ND; ++id)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) oa[id] = mfma32(tfrag<DH, TR>(vt, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), oa[id]);
+    }
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    if (hi == 0 && qi < nq) lse[(size_t)bh * nq_cap + qi] = (mx == -INFINITY ? 0.f : mx) + __logf(sum);
+#pragma unroll
+    for (int id = 0; id < ND; ++id) store_rows<DH>(oa[id], o + (size_t)q0 * ldo, ldo, qi, nq, h * DH, id * 32, lane, inv);
+}
+
+// backward, query side: delta and dQ of a 64-query block (two waves of 32 queries), two passes over the key blocks
+template <int DH, bool TR, bool DROP>
+__global__ __launch_bounds__(128) void sdpa_bwd_flash_q(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                        const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
+                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                        bf16_t* __restrict__ dq, float* __restrict__ delta_out, int H, int nq, int nk,
+                                                        int ldq, int ldk, int ldv, int ldo, int lddq, float scale, float p_drop,
+                                                        float inv_keep, uint64_t seed, const uint64_t* __restrict__ step_seed, VarLen vl) {
+    if (DROP) seed = with_step_seed(seed, step_seed);
+    constexpr bool SW = DH == 64;
+    using TL = Tile<DH, SW>;
+    __shared__ __attribute__((aligned(16))) uint8_t tk[64 * TL::PITCH];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, qb0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    if (blockIdx.y == 0) zero_pad_rows<bf16_t>(vl.q_off, vl.q_pad, b, (int)gridDim.x / H, dq, lddq, h * DH, DH, tid, 128);
+    if (qb0 >= nq) return;
+    const bf16_t* qb = q + (size_t)q0 * ldq;
+    const bf16_t* kb = k + (size_t)k0 * ldk;
+    const bf16_t* vb = v + (size_t)k0 * ldv;
+    const bf16_t* dob = dout + (size_t)q0 * ldo;
+    const int qi = qb0 + j * 32 + l31;
+    constexpr int ND = (DH + 31) / 32;
+    bf16x8_t fq[DH / 16], fdo[DH / 16];
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        fq[s] = gfrag(qb, ldq, qi, nq, h * DH + s * 16 + hi * 8);
+        fdo[s] = gfrag(dob, ldo, qi, nq, h * DH + s * 16 + hi * 8);
+    }
+    const float l = qi < nq ? lse[(size_t)bh * nq_cap + qi] : 0.f;
+    float delta = 0.f;
+    f32x16_t qa[ND];
+#pragma unroll
+    for (int id = 0; id < ND; ++id) qa[id] = zero16();
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+        for (int kb0 = 0; kb0 < nk; kb0 += 64) {
+            const int nkb = nk - kb0;
+            TileStage<DH, 64, 128, SW> sk;
+            sk.load(kb + (size_t)kb0 * ldk, ldk, nkb, h * DH, tid);
+            bf16x8_t fv[2][DH / 16];
+#pragma unroll
+            for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fv[i][s] = gfrag(vb + (size_t)kb0 * ldv, ldv, i * 32 + l31, nkb, h * DH + s * 16 + hi * 8);
+            __syncthreads();                           // both waves are done with the previous K tile
+            sk.store(tk, tid);
+            const uint64_t kbits = key_bits(key_mask, b * nk_cap + kb0, min(64, nk_cap - kb0), lane);
+            __syncthreads();
+            f32x16_t st[2], dpt[2];
+            st[0] = zero16(); st[1] = zero16(); dpt[0] = zero16(); dpt[1] = zero16();
+#pragma unroll
+            for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    st[i] = mfma32(lfrag<DH, SW>(tk, i * 32 + l31, s, lane), fq[s], st[i]);
+                    dpt[i] = mfma32(fv[i][s], fdo[s], dpt[i]);
+                }
+            float dacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = i * 32 + acc_row(r, hi);
+                    const bool ok = key < nkb && ((kbits >> key) & 1ull) != 0 && qi < nq;
+                    const float pv = ok ? __expf(st[i][r] * scale - l) : 0.f;
+                    float dp = dpt[i][r];
+                    if (DROP) dp *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)(kb0 + key), p_drop, inv_keep);
+                    dacc += pv * dp;
+                    st[i][r] = pv * (dp - delta) * scale;          // dS^T (second pass: delta is final)
+                }
+            if (pass == 0) delta += dacc;
+            else {
+#pragma unroll
+                for (int id = 0; id < ND; ++id)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            qa[id] = mfma32(tfrag<DH, TR, SW>(tk, id * 32, i * 32 + u * 16, lane), acc_to_frag(st[i], u), qa[id]);
+            }
+        }
+        if (pass == 0) delta += __shfl_xor(delta, 32, 64);
+    }
+    if (hi == 0 && qi < nq) delta_out[(size_t)bh * nq_cap + qi] = delta;
+#pragma unroll
+    for (int id = 0; id < ND; ++id) store_rows<DH>(qa[id], dq + (size_t)q0 * lddq, lddq, qi, nq, h * DH, id * 32, lane, 1.0f);
+}
+
+// backward, key side: dK and dV of a 64-key block (two waves of 32 keys), one pass over the query blocks
+template <int DH, bool TR, bool DROP>
+__global__ __launch_bounds__(128) void sdpa_bwd_flash_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                        const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
+                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                        const float* __restrict__ delta_in, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+                                                        int H, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int lddk, int lddv,
+                                                        float scale, float p_drop, float inv_keep, uint64_t seed,
+                                                        const uint64_t* __restrict__ step_seed, VarLen vl) {
+    if (DROP) seed = with_step_seed(seed, step_seed);
+    constexpr bool SW = DH == 64;
+    using TL = Tile<DH, SW>;
+    __shared__ __attribute__((aligned(16))) uint8_t tq[64 * TL::PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t tdo[64 * TL::PITCH];
+    __shared__ float s_lse[64], s_delta[64];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, kb0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, i = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int nq_cap = nq, nk_cap = nk;
+    const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
+    nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
+    if (blockIdx.y == 0) {
+        zero_pad_rows<bf16_t>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dk, lddk, h * DH, DH, tid, 128);
+        zero_pad_rows<bf16_t>(vl.k_off, vl.k_pad, b, (int)gridDim.x / H, dv, lddv, h * DH, DH, tid, 128);
+    }
+    if (kb0 >= nk) return;
+    const bf16_t* qb = q + (size_t)q0 * ldq;
+    const bf16_t* kb = k + (size_t)k0 * ldk;
+    const bf16_t* vb = v + (size_t)k0 * ldv;
+    const bf16_t* dob = dout + (size_t)q0 * ldo;
+    const int key = kb0 + i * 32 + l31;
+    constexpr int ND = (DH + 31) / 32;
+    bf16x8_t fk[DH / 16], fv[DH / 16];
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        fk[s] = gfrag(kb, ldk, key, nk, h * DH + s * 16 + hi * 8);
+        fv[s] = gfrag(vb, ldv, key, nk, h * DH + s * 16 + hi * 8);
+    }
+    const uint64_t kbits = key_bits(key_mask, b * nk_cap + kb0, min(64, nk_cap - kb0), lane);
+    const bool kok = key < nk && ((kbits >> (i * 32 + l31)) & 1ull) != 0;
+    f32x16_t va[ND], ka[ND];
+#pragma unroll
+    for (int id = 0; id < ND; ++id) { va[id] = zero16(); ka[id] = zero16(); }
+#pragma unroll 1
+    for (int qb0 = 0; qb0 < nq; qb0 += 64) {
+        const int nqb = nq - qb0;
+        TileStage<DH, 64, 128, SW> sq, sd;
+        sq.load(qb + (size_t)qb0 * ldq, ldq, nqb, h * DH, tid);
+        sd.load(dob + (size_t)qb0 * ldo, ldo, nqb, h * DH, tid);
+        const float lq = (tid < 64 && tid < nqb) ? lse[(size_t)bh * nq_cap + qb0 + tid] : 0.f;
+        const float dq_ = (tid < 64 && tid < nqb) ? delta_in[(size_t)bh * nq_cap + qb0 + tid] : 0.f;
+        __syncthreads();                               // both waves are done with the previous block's tiles
+        sq.store(tq, tid);
+        sd.store(tdo, tid);
+        if (tid < 64) { s_lse[tid] = lq; s_delta[tid] = dq_; }
+        __syncthreads();
+        f32x16_t s2[2], dp2[2];
+        s2[0] = zero16(); s2[1] = zero16(); dp2[0] = zero16(); dp2[1] = zero16();
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) {
+                s2[jq] = mfma32(lfrag<DH, SW>(tq, jq * 32 + l31, s, lane), fk[s], s2[jq]);
+                dp2[jq] = mfma32(lfrag<DH, SW>(tdo, jq * 32 + l31, s, lane), fv[s], dp2[jq]);
+            }
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = jq * 32 + acc_row(r, hi);            // query inside the block
+                const float e = __expf(s2[jq][r] * scale - s_lse[ql]);
+                const float pv = (kok && ql < nqb) ? e : 0.f;
+                float msk = 1.f;
+                if (DROP) msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qb0 + ql), (uint32_t)key, p_drop, inv_keep);
+                const float dp = dp2[jq][r] * msk;
+                dp2[jq][r] = pv * (dp - s_delta[ql]) * scale;      // dS[q][key]
+                s2[jq][r] = pv * msk;                              // P~[q][key]
+            }
+#pragma unroll
+        for (int id = 0; id < ND; ++id)
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    va[id] = mfma32(tfrag<DH, TR, SW>(tdo, id * 32, jq * 32 + u * 16, lane), acc_to_frag(s2[jq], u), va[id]);
+                    ka[id] = mfma32(tfrag<DH, TR, SW>(tq, id * 32, jq * 32 + u * 16, lane), acc_to_frag(dp2[jq], u), ka[id]);
+                }
+    }
+#pragma unroll
+    for (int id = 0; id < ND; ++id) {
+        store_rows<DH>(va[id], dv + (size_t)k0 * lddv, lddv, key, nk, h * DH, id * 32, lane, 1.0f);
+        store_rows<DH>(ka[id], dk + (size_t)k0 * lddk, lddk, key, nk, h * DH, id * 32, lane, 1.0f);
+    }
+}
+
+// XL_SDPA_LONG_MFMA=0: the plain long-sequence kernels (any dtype) for every launch
+static bool long_mfma_enabled() {
+    static const bool on = [] { const char* e = getenv("XL_SDPA_LONG_MFMA"); return e == nullptr || atoi(e) != 0; }();
+    return on;
+}
+
 struct SdpaArgs {
     const void *q, *k, *v; const uint8_t* key_mask; const void* dout; void* o; float* lse;
     void *dq, *dk, *dv;
@@ -841,6 +1133,21 @@ extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const ui
     if (rc) return rc;
     XL_CHECK_ARG(q && k && v && o && lse, XL_ERR_BAD_ARG, "xl_sdpa_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if ((nq > MAXN || nk > MAXN) && dtype == XL_BF16 && mfma_eligible(a, false) && ctx().use_tr_read && long_mfma_enabled()) {
+        const dim3 grid(B * H, (nq + 63) / 64);     // long sequences on the matrix cores
+        const bool drop = p_drop > 0.f;
+#define XL_FLASH_FWD(DH_)                                                                                                        \
+        if (drop) hipLaunchKernelGGL((sdpa_fwd_flash<DH_, true, true>), grid, dim3(128), 0, st, (const bf16_t*)q, (const bf16_t*)k,  \
+                                     (const bf16_t*)v, key_mask, (bf16_t*)o, lse, H, nq, nk, ldq, ldk, ldv, ldo, scale, p_drop,  \
+                                     a.inv_keep, seed, ctx().step_seed, a.vl);                                                   \
+        else hipLaunchKernelGGL((sdpa_fwd_flash<DH_, true, false>), grid, dim3(128), 0, st, (const bf16_t*)q, (const bf16_t*)k,     \
+                                (const bf16_t*)v, key_mask, (bf16_t*)o, lse, H, nq, nk, ldq, ldk, ldv, ldo, scale, p_drop,       \
+                                a.inv_keep, seed, ctx().step_seed, a.vl);
+        if (dh == 64) { XL_FLASH_FWD(64) } else if (dh == 32) { XL_FLASH_FWD(32) } else { XL_FLASH_FWD(16) }
+#undef XL_FLASH_FWD
+        XL_CHECK_LAUNCH();
+        return XL_OK;
+    }
     if (nq > MAXN || nk > MAXN) {                 // long sequences: the plain kernels (any dtype)
         const dim3 grid(B * H, (nq + 63) / 64);
         if (dtype == XL_BF16)
@@ -895,7 +1202,20 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
         XL_CHECK_ARG(workspace != nullptr && (int64_t)B * H * nq <= xl_workspace_floats(HD), XL_ERR_BAD_ARG,
                      "xl_sdpa_bwd: sequences longer than %d need the workspace (xl_workspace_floats(H * dh) floats)", MAXN);
         const dim3 gq(B * H, (nq + 63) / 64), gk(B * H, (nk + 63) / 64);
-        if (dtype == XL_BF16) {
+        if (dtype == XL_BF16 && mfma_eligible(a, true) && ctx().use_tr_read && long_mfma_enabled()) {
+            const bool drop = p_drop > 0.f;
+#define XL_FLASH_BWD(DH_, DR_)                                                                                                   \
+            hipLaunchKernelGGL((sdpa_bwd_flash_q<DH_, true, DR_>), gq, dim3(128), 0, st, (const bf16_t*)q, (const bf16_t*)k,        \
+                               (const bf16_t*)v, key_mask, (const bf16_t*)dout, lse, (bf16_t*)dq, workspace, H, nq, nk, ldq, ldk,  \
+                               ldv, ldo, lddq, scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);                            \
+            hipLaunchKernelGGL((sdpa_bwd_flash_k<DH_, true, DR_>), gk, dim3(128), 0, st, (const bf16_t*)q, (const bf16_t*)k,        \
+                               (const bf16_t*)v, key_mask, (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, H, nq, nk, \
+                               ldq, ldk, ldv, ldo, lddk, lddv, scale, p_drop, a.inv_keep, seed, ctx().step_seed, a.vl);
+            if (dh == 64) { if (drop) { XL_FLASH_BWD(64, true) } else { XL_FLASH_BWD(64, false) } }
+            else if (dh == 32) { if (drop) { XL_FLASH_BWD(32, true) } else { XL_FLASH_BWD(32, false) } }
+            else { if (drop) { XL_FLASH_BWD(16, true) } else { XL_FLASH_BWD(16, false) } }
+#undef XL_FLASH_BWD
+        } else if (dtype == XL_BF16) {
             hipLaunchKernelGGL((sdpa_bwd_long_q<bf16_t>), gq, dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask,
                                (const bf16_t*)dout, lse, (bf16_t*)dq, workspace, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, scale, p_drop,
                                a.inv_keep, seed, ctx().step_seed, a.vl);
