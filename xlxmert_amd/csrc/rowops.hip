@@ -154,12 +154,13 @@ __device__ __forceinline__ void flush_colsums3(float (&a0)[NIT][VEC], float (&a1
 }
 
 // out[v][n*stride] += sum_g ws[(g*nvec + v)*N + n], DETERMINISTIC: a block owns 32 consecutive (vector, column) pairs and sums
-// the G partial slabs in 8 fixed slices (lane -> column: a wave reads two 128-byte row segments per step), the slices meet in LDS
+// the G partial slabs in 32 fixed slices (lane -> column: a wave reads two 128-byte row segments per step), the slices meet in LDS
 // and are added in slice order by the thread that then makes ONE plain read-modify-write of the output element -- no atomics, the
 // same bits every run.  (Rounds 1-4: grid.y slices met through up to 16 fp32 atomics per element, whose order varied from run to
 // run -- the last non-reproducible reduction of the step together with the feature encoder's)  The caller
 // guarantees that nothing else writes the outputs concurrently: launches on one stream are ordered, and entries of one batched
 // launch never alias (xl_flush_reductions_on cuts the batch there).
+constexpr int kRedSlices = 32;          // slices of the G partial slabs per output element (block = 32 columns x 32 slices)
 __device__ __forceinline__ void reduce_partials_entry(const float* __restrict__ ws, int G, int nvec, int N, const ReduceOuts& outs,
                                                       int group, float (*red)[33]) {
     const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -169,7 +170,7 @@ __device__ __forceinline__ void reduce_partials_entry(const float* __restrict__ 
     const bool live = in && outs.p[v] != nullptr;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (live) {
-        const int per = (G + 7) >> 3;
+        const int per = (G + kRedSlices - 1) / kRedSlices;
         const int g0 = sl * per, g1 = min(G, g0 + per);
         const float* col = ws + (size_t)v * N + n;
         const size_t pitch = (size_t)nvec * N;
@@ -187,13 +188,13 @@ __device__ __forceinline__ void reduce_partials_entry(const float* __restrict__ 
     if (sl == 0 && live) {
         float t = red[0][c];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][c];
+        for (int k = 1; k < kRedSlices; ++k) t += red[k][c];
         float* o = outs.p[v] + (size_t)n * outs.stride[v];
         *o += t;
     }
 }
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int G, int nvec, int N, ReduceOuts outs) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ ws, int G, int nvec, int N, ReduceOuts outs) {
+    __shared__ float red[kRedSlices][33];
     reduce_partials_entry(ws, G, nvec, N, outs, blockIdx.x, red);
 }
 
@@ -1604,8 +1605,8 @@ extern "C" int xl_layernorm_fwd(const void* x, const float* gamma, const float* 
 constexpr int kBatch = 6;
 struct BatchArgs { int n; PendingReduce e[kBatch]; };
 
-__global__ __launch_bounds__(256) void reduce_partials_batched_kernel(BatchArgs a) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void reduce_partials_batched_kernel(BatchArgs a) {
+    __shared__ float red[kRedSlices][33];
     const PendingReduce& e = a.e[blockIdx.z];
     if ((int)blockIdx.x * 32 >= e.nvec * e.N) return;          // (block-uniform: the grid is sized for the widest entry)
     reduce_partials_entry(e.ws, e.G, e.nvec, e.N, e.outs, blockIdx.x, red);
@@ -1635,7 +1636,7 @@ static void launch_reduce(const float* ws, int G, int nvec, int N, ReduceOuts ou
         c.pending[st].push_back(PendingReduce{ws, G, nvec, N, 1, outs});
         return;
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nvec * N + 31) / 32), dim3(256), 0, st, ws, G, nvec, N, outs);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nvec * N + 31) / 32), dim3(32 * kRedSlices), 0, st, ws, G, nvec, N, outs);
 }
 
 extern "C" int xl_set_deferred_reduce(int on) {
@@ -1670,7 +1671,7 @@ extern "C" int xl_flush_reductions_on(void* producer_stream, void* launch_stream
             gx = std::max(gx, (todo[i].nvec * todo[i].N + 31) / 32);
             ++i;
         }
-        hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3(gx, 1, a.n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3(gx, 1, a.n), dim3(32 * kRedSlices), 0, st, a);
     }
     XL_CHECK_LAUNCH();
     return XL_OK;
