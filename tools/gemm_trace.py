@@ -16,7 +16,7 @@ B = torch.randn((N, K) if bk else (K, N), device=dev).to(torch.bfloat16)
 C = torch.zeros(M, N, device=dev, dtype=torch.float32 if of32 else torch.bfloat16)
 bias = torch.randn(N, device=dev) if ak else None
 res = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi == 2 else None
-aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi in (1, 3) else None
+aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi in (1, 3, 6, 7) else None
 lda, ldb = (K if ak else M), (K if bk else N)
 trace = torch.zeros(4 * 8192 + 12 * 8192, dtype=torch.int64, device=dev)
 def run():
