@@ -46,6 +46,19 @@ def main(path, ngaps=15, which=-2):
         level += d; last = t
     for k in sorted(hist):
         print(f"  {k} kernels in flight: {hist[k] / 1e6:8.3f} ms")
+    # how long is at least one dense contraction in flight (the chip near its power limit), how long only row kernels, how long nothing
+    gev = []
+    for n, s, e, q in step:
+        g = 1 if "gemm" in n else 0
+        gev.append((s, 1, g)); gev.append((e, -1, -g))
+    gev.sort()
+    lv = gl = 0
+    last, t_gemm, t_rows = t0, 0, 0
+    for t, d, g in gev:
+        if gl > 0: t_gemm += t - last
+        elif lv > 0: t_rows += t - last
+        lv += d; gl += g; last = t
+    print(f"  >= 1 contraction in flight {t_gemm / 1e6:.3f} ms, only other kernels {t_rows / 1e6:.3f} ms, nothing {(t1 - t0 - t_gemm - t_rows) / 1e6:.3f} ms")
     agg = {}
     for n, s, e, q in step:
         a = agg.setdefault(short(n), [0, 0]); a[0] += 1; a[1] += e - s
