@@ -565,7 +565,11 @@ def test_vqa_full_size_step_properties_bf16(B):
         torch.cuda.synchronize()
         d = (logit_big - logit_small).abs().max().item()
         print("vqa bs512 vs bs64 logits max abs diff:", d, "logit scale", logit_small.abs().max().item())
-        assert d < 1e-3 * max(1.0, logit_small.abs().max().item())          # measured 2.4e-7
+        # every default kernel sums a contraction in the same K order whatever the row count, so the two engines agree to the last
+        # bits (measured 2.4e-7).  XL_GEMM_SPLIT_EPI=1 (opt-in) runs the small engine's deep contractions as K slices: another
+        # bf16 re-association of the same sums -- both are 0.051 from the fp32 path, 0.043 from each other (tools/split_epi_engine.py)
+        bound = 5e-2 if os.environ.get("XL_GEMM_SPLIT_EPI", "0") != "0" else 1e-3
+        assert d < bound * max(1.0, logit_small.abs().max().item())
 
 
 # ---------------------------------------------------------------- on-device iterative sampler
@@ -1341,6 +1345,39 @@ def test_paired_blocks_full_width_bf16_step(side):
     assert rel < 2e-2, rel                         # (bf16: the paired launches are bit-identical, fp32 atomics / dropout-free noise only)
 
 
+@pytest.mark.parametrize("side", [False, True])
+def test_vqa_step_paired_blocks_full_depth(side):
+    """A fine-tune step (language-side answer head: its backward leaves column-sum partials filed under the LANGUAGE stream) with
+    the blocks paired onto the visual chain, at the full 9 / 5 / 5 depth: the language lane's scratch generations wrap around (8
+    sets) while those partials are still pending, so the lane must combine them on their own stream before it reuses the set
+    (round 5: an assertion fired here).  Same gradients as the two-stream schedule."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        max_position_embeddings=32, visual_feat_dim=64, num_clusters=96, l_layers=9, x_layers=5, r_layers=5)
+    B, A = 16, 40
+    g = torch.Generator().manual_seed(11)
+    b = synthetic_batch(cfg, B, 20, 8, seed=21)
+    tgt = torch.zeros(B, A)
+    tgt[torch.arange(B), torch.randint(0, A, (B,), generator=g)] = 1.0
+    batch = {"input_ids": b["input_ids"].cuda(), "visual_pos": b["visual_pos"].cuda(),
+             "visual_feats": torch.randn(B, 64, cfg.visual_feat_dim, generator=g).relu().cuda(), "targets": tgt.cuda()}
+    res = {}
+    for mode in ("two_streams", "paired"):
+        tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=5, task="vqa", num_answers=A, train_dropout=False,
+                          total_steps=100, plan=False, drop_grads=False)
+        tr.engine.pair_blocks, tr.engine.pair_side = mode == "paired", side
+        losses = [tr.step(batch).clone() for _ in range(2)]
+        tr.sync()
+        res[mode] = (losses, tr.store.master[:tr.store.n_used].clone())
+    (l0, p0), (l1, p1) = res["two_streams"], res["paired"]
+    for a, c in zip(l0, l1):
+        assert torch.allclose(a, c, rtol=2e-3, atol=1e-4), (a, c)
+    assert torch.isfinite(p1).all()
+    rel = (p0 - p1).norm().item() / p0.norm().item()
+    assert rel < 1e-4, rel                      # parameters after two steps (paired launches are bit-identical; fp32 atomics noise only)
+
+
 def make_engine_on(g, ops, dtype, pair, side):
     from _util import golden_cfg, golden_inputs
     from xlxmert_amd.config import XLxmertConfig
@@ -1602,6 +1639,9 @@ def test_sampler_first_step_at_bench_geometry_matches_oracle_where_decisive():
     print(f"sampler step 1 at bs 64: logits std {obj.std().item():.3f}, best logit mean {top2[..., 0].mean().item():.2f}, same code overall "
           f"{same.float().mean().item():.4f}, confidence rel err among agreeing positions: max {rel.max().item():.4f} median {rel.median().item():.4f}")
     assert decisive.float().mean().item() > 0.5
-    assert same[decisive].all()                       # measured: 100 % down to 1/64, 99.1 % at 1/128
+    if os.environ.get("XL_GEMM_SPLIT_EPI", "0") != "0":           # (opt-in K slices: another bf16 re-association -- one or two of the
+        assert same[decisive].float().mean().item() > 0.999       #  ~2800 decisive positions flip; both are one realisation of bf16 rounding)
+    else:
+        assert same[decisive].all()                   # measured: 100 % down to 1/64, 99.1 % at 1/128
     assert same.float().mean().item() >= 0.92         # measured 0.945
     assert rel.median().item() < 4e-2                 # measured 0.023 (max 0.37: a probability is exp of a logit difference)

@@ -1051,9 +1051,20 @@ class Engine:
     def _advance_gen(self, tag):
         g = (self._gen[tag] + 1) % self.NGEN
         stale = [h for gg, h in self._red_gens[tag] if gg == g]
-        if stale:                               # its column-sum partials were never combined (no launch since): do it now, in order
-            assert stale == [self._cur_handle()], "pending column sums of this lane's next scratch set belong to another stream"
-            self.flush_reductions()
+        for h in stale:                         # its column-sum partials were never combined (no launch since): do it now, in order
+            if h == self._cur_handle():
+                self.flush_reductions()
+            else:
+                # produced on the OTHER compute stream (a language-side head's backward on the language stream, then this lane's
+                # blocks paired onto the visual chain, or the reverse): combined on the producing stream, behind its producers, and
+                # this stream -- about to reuse the set's workspace regions -- waits for that combine
+                st = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
+                ev = self._guard_event(tag)
+                with torch.cuda.stream(st):
+                    self.ops.flush_reductions()
+                self.ops.event_record(ev, st)
+                self.ops.stream_wait(ev, torch.cuda.current_stream())
+                self._combined(h)
         self._gen[tag] = g
         self._ws_i[tag] = 0
 
