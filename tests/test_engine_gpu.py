@@ -1378,6 +1378,35 @@ def test_vqa_step_paired_blocks_full_depth(side):
     assert rel < 1e-4, rel                      # parameters after two steps (paired launches are bit-identical; fp32 atomics noise only)
 
 
+def test_two_scratch_generations_give_the_same_gradients(monkeypatch):
+    """XL_SCRATCH_GENS=2 (the minimum): every backward scratch set is reused two closes later.  A cross-modality layer closes two
+    sets per layer (self-attention + cross-attention) while its FFN / self-attention weight gradients are HELD for a grouped launch
+    with the next layer, so the set they read comes up for reuse before they are launched: the engine has to launch them first
+    (Engine._advance_gen).  Round 5: with two sets the next layer overwrote dpre / dqkv under them -- 36 fixture tests off by
+    1e-2 -- which the default eight sets hid.  Same step, 2 against 8 sets: identical parameters after two steps."""
+    from xlxmert_amd.config import XLxmertConfig
+    from xlxmert_amd.engine import Engine
+    from xlxmert_amd.trainer import PretrainStep, synthetic_batch
+    cfg = XLxmertConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        max_position_embeddings=32, visual_feat_dim=64, num_clusters=96, l_layers=3, x_layers=3, r_layers=3)
+    g = torch.Generator().manual_seed(3)
+    cents = torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu()
+    B = 16
+    batches = [{k: v.cuda() for k, v in synthetic_batch(cfg, B, 20, 8, seed=50 + i).items()} for i in range(2)]
+    res = {}
+    for ngen in (8, 2):
+        monkeypatch.setattr(Engine, "NGEN", ngen)
+        tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device="cuda", seed=5, lr=1e-3, total_steps=100, train_dropout=True,
+                          plan=False, drop_grads=True, overlap_optimizer=True)
+        tr.set_centroids(cents)
+        tr.ops.set_gemm_wgrad_slabs(1)
+        for b in batches:
+            tr.step(b)
+        tr.sync()
+        res[ngen] = tr.store.master[:tr.store.n_used].clone()
+    assert torch.equal(res[8], res[2]), ((res[8] - res[2]).abs().max().item(), (res[8] != res[2]).float().mean().item())
+
+
 def make_engine_on(g, ops, dtype, pair, side):
     from _util import golden_cfg, golden_inputs
     from xlxmert_amd.config import XLxmertConfig

@@ -1050,6 +1050,11 @@ class Engine:
 
     def _advance_gen(self, tag):
         g = (self._gen[tag] + 1) % self.NGEN
+        if any(pr[10] == g for pr in self._held[tag]):
+            # weight gradients HELD for a grouped launch with the next layer still read the scratch set that comes up for reuse
+            # (few sets -- XL_SCRATCH_GENS below ~5 -- and a cross-modality layer, whose cross-attention block closes a second
+            # set per layer): launch them now, so that the set has a guard event for the next writer to wait on
+            self.wgrad_flush(pair=True, force=True)
         stale = [h for gg, h in self._red_gens[tag] if gg == g]
         for h in stale:                         # its column-sum partials were never combined (no launch since): do it now, in order
             if h == self._cur_handle():
