@@ -487,6 +487,11 @@ def main():
                          # contract figure 50.782 GFLOP/example credits head rows the step does not compute (masked-row head), so
                          # value x 50.782 GFLOP / peak would overstate it -- this one takes no such credit
                          "frac_contract_uncredited": round(gt.flops / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
+                         # informational, NOT the contract's peak: what a register-only bf16 MFMA loop sustains on all 256 CUs with
+                         # non-trivial operand bits (the 2.5 PFLOP/s figure is reached on zero operands only: the chip clocks to its
+                         # power limit) -- tools/probes/clock_probe.hip, profiles/r05c/clock_probe.txt
+                         "peak_real_data_measured": {"value": 1850.0, "unit": "TFLOP/s", "frac": round(gemm_tflops / 1850.0, 4),
+                                                     "source": "profiles/r05c/clock_probe.txt"},
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(gt.bytes / gt.launches),
                          "algorithmic_bytes_per_step": int(gt.bytes),
