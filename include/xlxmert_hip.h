@@ -104,6 +104,16 @@ int  xl_set_gemm_duo(int mode);
  * a fast epilogue kind, no fused column sums, M % 128 == N % 192 == K % 64 == 0); env XL_GEMM_Q sets the initial value.  Bit-identical
  * results to the other tile shapes. */
 int  xl_set_gemm_q(int mode);
+/* "relay" kernel (csrc/gemm_relay.hip): one persistent 8-wave workgroup per CU whose two groups of four waves trade roles every
+ * 256x128 output tile -- one group runs the tile's K loop as a self-pipelined MFMA stream, the other issues its LDS-DMA and runs the
+ * PREVIOUS tile's epilogue under it (two accumulator sets per SIMD, one per wave).  0 = never, 1 = launches of more than
+ * XL_GEMM_RELAY_MIN_TILES (257) tiles of 256x256 with K <= XL_GEMM_RELAY_MAX_K (1024), 2 = every eligible launch (forward / dX layouts,
+ * bf16 in / out, fast epilogue kind NONE / RESIDUAL / GELU_DG / MULAUX, no fused column sums, M % 256 == N % 256 == K % 64 == 0,
+ * K >= 768); env XL_GEMM_RELAY sets the initial value.  Bit-identical results to the other tile shapes. */
+int  xl_set_gemm_relay(int mode);
+/* number of persistent workgroups a relay launch may put up (default 256 = one per CU; at most half the launch's 256x128 tiles);
+ * tuning / test switch, env XL_GEMM_RELAY_WGS */
+int  xl_set_gemm_relay_wgs(int wgs);
 /* K split of a launch WITH an epilogue (forward / dX layouts, bf16 in and out, fast epilogue): a launch of at most
  * XL_GEMM_SPLIT_EPI_MAX_TILES (80) output tiles of 256x192 / 256x256 whose contraction is at least XL_GEMM_SPLIT_EPI_MIN_K (1536)
  * deep runs every tile as 2..4 K slices of >= 12 K tiles on whole-CU workgroups; the slices meet in the stream's slab workspace

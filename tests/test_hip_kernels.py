@@ -400,7 +400,58 @@ def test_gemm_q_tiles_equal_whole_cu_tiles(M, N, K, bk, epi, p_drop):
     assert not (out[2][0] == 7.0).all()
 
 
-def _tiles_exact(M, N, K, epi, bk, duo, q=0):
+@pytest.mark.parametrize("bk,epi", [(1, 0), (1, 2), (1, 6), (0, 0), (0, 2), (0, 7)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 768), (512, 768, 832), (768, 256, 1024), (1280, 512, 3072), (256, 2304, 896)])
+def test_gemm_relay_tiles_exact(M, N, K, epi, bk):
+    """the role-trading persistent kernel (csrc/gemm_relay.hip) forced for every eligible launch: 1 / 3 / 5 / 9 tiles per workgroup
+    (odd counts: a group's last tile has no partner K loop to hide under), 12 / 13 / 14 / 16 / 48 K tiles, forward and dX layouts, its six
+    (layout, epilogue) instances, against the host restatement on integer-valued operands."""
+    ops = hip(torch.bfloat16)
+    for wgs in (256, 2, 1):          # two tiles per workgroup / 1-9 tiles, odd and even / every tile on one workgroup
+        ops.set_gemm_relay_wgs(wgs)
+        try:
+            _tiles_exact(M, N, K, epi, bk, duo=0, relay=2)
+        finally:
+            ops.set_gemm_relay_wgs(256)
+
+
+@pytest.mark.parametrize("M,N,K,bk,epi,p_drop", [(16384, 768, 768, 1, 2, 0.1), (16384, 2304, 768, 1, 0, 0.0), (16384, 3072, 768, 1, 6, 0.0),
+                                                 (16384, 3072, 768, 0, 7, 0.0), (19712, 2304, 768, 1, 0, 0.0), (16384, 768, 2304, 0, 2, 0.0),
+                                                 (16384, 768, 768, 0, 0, 0.0), (16384, 768, 3072, 1, 2, 0.1), (3328, 768, 3072, 0, 2, 0.0),
+                                                 (16384, 2048, 768, 1, 0, 0.0), (19712, 768, 768, 1, 2, 0.1)])
+def test_gemm_relay_tiles_equal_whole_cu_tiles(M, N, K, bk, epi, p_drop):
+    """the relay kernel against the 256x256 ping-pong tiles on the step's own shapes: the same MFMA chain per output element, the same
+    epilogue arithmetic and dropout draws -- C and the saved aux BIT-identical; three times (stale ring slots, tile hand-overs)."""
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    B = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda() if bk else None
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    auxin = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    ops = hip(torch.bfloat16)
+    ops.set_gemm_pingpong(2)
+    ops.set_gemm_duo(0)
+    out = {}
+    try:
+        for mode in (0, 2):
+            ops.set_gemm_relay(mode)
+            for rep in range(3):
+                C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+                aux = auxin.clone()
+                ops.gemm(A, B, C, bias, res if epi == 2 else None, aux if epi in (6, 7) else None, M, N, K, K, K if bk else N, N,
+                         ldr=N, ldx=N, a_kmajor=1, b_kmajor=bk, epilogue=epi, p_drop=p_drop, seed=77)
+                torch.cuda.synchronize()
+            out[mode] = (C, aux)
+    finally:
+        ops.set_gemm_relay(0)
+        ops.set_gemm_duo(1)
+        ops.set_gemm_pingpong(1)
+    assert torch.equal(out[0][0], out[2][0]), (out[0][0].float() - out[2][0].float()).abs().max().item()
+    assert torch.equal(out[0][1], out[2][1])
+    assert not (out[2][0] == 7.0).all()
+
+
+def _tiles_exact(M, N, K, epi, bk, duo, q=0, relay=0):
     """the 256x192 variant of the ping-pong kernel (waves 4 x 2, wave tile 64 x 96, B staged in three 8 KiB parts) forced for
     every eligible launch: 1 / 2 / 4 (ragged) / 16 (ragged) / 24 K tiles, forward and dX operand layouts, all four fast
     epilogues.  Integer-valued operands: the fp32 accumulation is exact, so the plain result must equal the host product bit
@@ -417,6 +468,7 @@ def _tiles_exact(M, N, K, epi, bk, duo, q=0):
     ops.set_gemm_tile192(2)
     ops.set_gemm_duo(duo)
     ops.set_gemm_q(q)
+    ops.set_gemm_relay(relay)
     try:
         for rep in range(2):
             C = torch.full((M, N), 7.0, dtype=torch.bfloat16)
@@ -438,6 +490,7 @@ def _tiles_exact(M, N, K, epi, bk, duo, q=0):
         ops.set_gemm_tile192(1)
         ops.set_gemm_duo(1)
         ops.set_gemm_q(0)
+        ops.set_gemm_relay(0)
 
 
 @pytest.mark.parametrize("bk", [1, 0])

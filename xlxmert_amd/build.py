@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxlxmert_hip.so")
-SOURCES = ["gemm_pp.hip", "gemm_pp_nn.hip", "gemm_pp_192.hip", "gemm_pp_persist.hip", "gemm_pp_duo.hip", "gemm_pp_pair.hip", "gemm_q.hip", "gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip", "comm.hip"]
+SOURCES = ["gemm_pp.hip", "gemm_pp_nn.hip", "gemm_pp_192.hip", "gemm_pp_persist.hip", "gemm_pp_duo.hip", "gemm_pp_pair.hip", "gemm_q.hip", "gemm_relay.hip", "gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip", "comm.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

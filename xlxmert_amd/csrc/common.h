@@ -268,6 +268,8 @@ struct Ctx {
     int wgrad_slabs = -1;                     // xl_set_gemm_wgrad_slabs; -1 = XL_GEMM_WGRAD_SLABS (default 0)
     int gemm_duo = -1;                        // xl_set_gemm_duo; -1 = XL_GEMM_DUO (default 1: small launches)
     int gemm_q = -1;                // 128x192 tiles, eight 128-register waves, two workgroups per CU (xl_set_gemm_q; -1: env XL_GEMM_Q)
+    int gemm_relay_wgs = -1;        // persistent workgroups of a relay launch (xl_set_gemm_relay_wgs; -1: env XL_GEMM_RELAY_WGS, default 256)
+    int gemm_relay = -1;            // role-trading persistent kernel, epilogue under the next tile's K loop (xl_set_gemm_relay; -1: env XL_GEMM_RELAY)
     int gemm_pair = -1;             // two-problem launches (xl_gemm_pair / xl_set_gemm_pair; -1: env XL_GEMM_PAIR, default 1 = on)
     int gemm_split_epi = -1;        // K split of few-tile launches with an epilogue (xl_set_gemm_split_epi; -1: env XL_GEMM_SPLIT_EPI, default 0 = off)
     int gemm_persist = -1;                    // xl_set_gemm_persistent; -1 = XL_GEMM_PERSIST (default 0)

@@ -471,6 +471,27 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             }
         }
     }
+    // "relay" kernel (gemm_relay.hip): one persistent workgroup per CU whose two wave groups trade roles every 256 x 128 tile -- one runs
+    // the K loop as a self-pipelined MFMA stream, the other issues its LDS-DMA and runs the previous tile's epilogue under it.  Mode 0
+    // never, 1 launches of more than XL_GEMM_RELAY_MIN_TILES 256x256 tiles with K <= XL_GEMM_RELAY_MAX_K, 2 every eligible launch.
+    if (cx.gemm_relay < 0) cx.gemm_relay = env_int("XL_GEMM_RELAY", 0);
+    static const int relay_min_tiles = env_int("XL_GEMM_RELAY_MIN_TILES", 257);
+    static const int relay_max_k = env_int("XL_GEMM_RELAY_MAX_K", 1024);
+    if (cx.gemm_relay_wgs < 0) cx.gemm_relay_wgs = env_int("XL_GEMM_RELAY_WGS", 256);
+    const int relay_wgs = cx.gemm_relay_wgs;
+    if (!epi_split && pp_ok && pp_mode && cx.gemm_relay && a_kmajor && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K >= 768 &&
+        out_dtype == in_dtype && !accumulate && epik >= 0 && colsum_out == nullptr && splitk == 1 && !p.atomic_out &&
+        relay_has_instance(b_kmajor, epik) &&
+        (cx.gemm_relay == 2 || (t256n >= relay_min_tiles && K <= relay_max_k))) {
+        p.tiles_m = M / 256; p.tiles_n = N / 256;
+        p.splitk = 1; p.kper = K; p.tail_tiles = 0;
+        const int nt = p.tiles_m * p.tiles_n * 2;
+        const int wgs = std::max(1, std::min(relay_wgs, nt / 2));
+        hipError_t e = launch_relay(p, b_kmajor, epik, wgs, st);
+        XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        XL_CHECK_LAUNCH();
+        return XL_OK;
+    }
     // 128x192 tiles by eight waves of 32 x 96 at 128 registers, two workgroups per CU (gemm_q.hip): every workgroup keeps two waves per
     // SIMD in its K loop, so one's prologue / epilogue / hand-over runs under the other's K loop.  Mode 0 never, 1 contractions of at
     // most XL_GEMM_Q_MAX_K (the K = 768 launches, a third of whose tile time the whole-CU tile spends outside the K loop), 2 every
@@ -627,6 +648,18 @@ extern "C" int xl_gemm_pair(const void* A0, const void* B0, void* C0, const floa
     XL_CHECK_LAUNCH();
     for (int i = 0; i < 2; ++i)
         if (cs_out[i] != nullptr) { launch_colsum_reduce(cs_ws[i], M[i] / 128, N, cs_out[i], st); XL_CHECK_LAUNCH(); }
+    return XL_OK;
+}
+
+extern "C" int xl_set_gemm_relay(int mode) {
+    XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_relay: mode %d", mode);
+    ctx().gemm_relay = mode;
+    return XL_OK;
+}
+
+extern "C" int xl_set_gemm_relay_wgs(int wgs) {
+    XL_CHECK_ARG(wgs >= 1 && wgs <= 4096, XL_ERR_BAD_ARG, "xl_set_gemm_relay_wgs: %d", wgs);
+    ctx().gemm_relay_wgs = wgs;
     return XL_OK;
 }
 

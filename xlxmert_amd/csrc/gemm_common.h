@@ -756,6 +756,10 @@ bool pp_pair_has_instance(int b_kmajor, int epik);
 // instance for this (layout, epilogue kind)
 hipError_t launch_q(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);
 bool q_has_instance(int b_kmajor, int epik);
+// gemm_relay.hip: persistent workgroups whose two wave groups trade roles every 256 x 128 tile (K loop | LDS-DMA + previous tile's
+// epilogue); forward / dX layouts, fast epilogue, M % 256 == N % 256 == K % 64 == 0, K >= 768; nblk persistent workgroups
+hipError_t launch_relay(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);
+bool relay_has_instance(int b_kmajor, int epik);
 // persistent variant (gemm_pp_persist.hip): A K-major, bf16 in / out, every tile interior, fast epilogue, several rounds of tiles;
 // hipErrorInvalidValue when the (layout, epilogue kind) has no instance
 hipError_t launch_pp_persist(const GemmParams& p, int b_kmajor, int epik, int nblk, hipStream_t st);

@@ -120,6 +120,13 @@ class HipOps:
         """128x192 tiles by eight 128-register waves, two workgroups per CU: 0 never, 1 short contractions, 2 every eligible launch."""
         self._call("xl_set_gemm_q", int(mode))
 
+    def set_gemm_relay(self, mode):
+        """0 never / 1 multi-round K <= 1024 launches / 2 every eligible launch on the role-trading persistent kernel (gemm_relay.hip)"""
+        self._call("xl_set_gemm_relay", int(mode))
+
+    def set_gemm_relay_wgs(self, wgs):
+        self._call("xl_set_gemm_relay_wgs", int(wgs))
+
     def set_gemm_split_epi(self, on):
         """K split of few-tile, deep-K launches with an epilogue through the stream's slab workspace: 0 never (default), 1 when eligible."""
         self._call("xl_set_gemm_split_epi", int(on))
