@@ -16,7 +16,9 @@
  *     config, fp32 FMA / fp32 accumulate); XL_BF16 = bf16 operands, fp32 accumulate on MFMA.
  *     LayerNorm statistics, softmax, losses, gradients of parameters, optimizer state: always fp32.
  *   - "ld*" are leading dimensions in ELEMENTS.
- *   - threading / state: the library keeps NO process-global mutable state.  Everything a caller can
+ *   - threading / state: the library keeps no process-global SETTINGS.  (Two process-wide tables exist and are not
+ *     settings: the RCCL function table resolved by the first xl_comm_* call, immutable afterwards, and the table that maps xl_comm_*
+ *     handles to communicators -- csrc/comm.hip g_rccl / g_comms, both mutex-guarded.)  Everything a caller can
  *     set -- the dropout step-seed pointer, the deferred-reduction switch and its pending lists, the per-stream slab
  *     workspaces, the kernel-choice / debug switches -- belongs to a CONTEXT (xl_ctx_create); a thread binds the context it
  *     works for with xl_ctx_bind and every xl_* call it makes afterwards reads that context.  Calls are re-entrant across
@@ -79,17 +81,6 @@ int  xl_set_step_seed_ptr(const uint64_t* step_seed);
 /* GEMM kernel choice for bf16 operands: 0 = 128x128 kernel only, 1 = by shape (default), 2 = the 256x256 ping-pong
  * kernel whenever the operands allow it (tuning / test switch; env XL_GEMM_PP sets the initial value) */
 int  xl_set_gemm_pingpong(int mode);
-/* 256x192 output tiles of the ping-pong kernel (forward / dX layouts, N a multiple of 192, M of 256, bf16 output): 0 = never
- * (default since round 4: in the four-stream step a main-chain launch that leaves a quarter of the CUs to the other streams is worth
- * more than the full round it forgoes, -0.27 .. -0.37 ms per step), 1 = when they shorten the launch taken alone (N = 768 gives 192
- * tiles of 256x256 on 256 CUs but 256 of 256x192), 2 = whenever eligible (test switch); env XL_GEMM_BN192 sets the initial value */
-int  xl_set_gemm_tile192(int mode);
-/* persistent variant of the ping-pong kernel for launches of several rounds of 256x256 tiles with a short contraction (the FFN's
- * first Linear and the gradient through its GELU: N = 3072, K = 768): one workgroup per CU walks its tiles and requests the next
- * tile's first K tile under the epilogue of the current one.  0 = never (default; env XL_GEMM_PERSIST), 1 = when eligible.
- * Bit-identical results either way.  Measured: -5 % on the FFN1 + GELU launch in isolation, +0.1 ms on the whole step -- a
- * workgroup that holds its CU across tiles keeps the other streams' workgroups out at the tile boundaries. */
-int  xl_set_gemm_persistent(int on);
 /* 128x192 "duo" tiles of the ping-pong kernel: four waves and 80 KiB of LDS per workgroup, TWO workgroups per CU, so that one's
  * prologue / epilogue / hand-over runs under the other's K loop and workgroups of different streams can share a CU.  Eligible:
  * forward / dX layouts, M % 128 == 0, N % 192 == 0, bf16 output through a fast epilogue.  0 = never, 1 (default) = eligible
@@ -97,32 +88,6 @@ int  xl_set_gemm_persistent(int on);
  * run on the 128x128 kernel at 0.10 MFMA-busy: -0.15..-0.25 ms per step --, 2 = whenever eligible (measured equal to the whole-CU
  * tiles on the large launches); env XL_GEMM_DUO.  Bit-identical results to the other tile shapes. */
 int  xl_set_gemm_duo(int mode);
-/* 128x192 output tiles by EIGHT waves of 32x96 at 128 registers (csrc/gemm_q.hip): two workgroups per CU, four waves per SIMD -- each
- * workgroup keeps two waves per SIMD in its K loop, so one's prologue / epilogue / hand-over runs under the other's K loop (the whole-CU
- * 256x256 tile spends 30-40 % of a K = 768 tile's time there with nothing to overlap it).  0 = never, 1 = contractions of depth <=
- * XL_GEMM_Q_MAX_K (1024) with at least XL_GEMM_Q_MIN_TILES (256) tiles, 2 = every eligible launch (forward / dX layouts, bf16 in / out,
- * a fast epilogue kind, no fused column sums, M % 128 == N % 192 == K % 64 == 0); env XL_GEMM_Q sets the initial value.  Bit-identical
- * results to the other tile shapes. */
-int  xl_set_gemm_q(int mode);
-/* "relay" kernel (csrc/gemm_relay.hip): one persistent 8-wave workgroup per CU whose two groups of four waves trade roles every
- * 256x128 output tile -- one group runs the tile's K loop as a self-pipelined MFMA stream, the other issues its LDS-DMA and runs the
- * PREVIOUS tile's epilogue under it (two accumulator sets per SIMD, one per wave).  0 = never, 1 = launches of more than
- * XL_GEMM_RELAY_MIN_TILES (257) tiles of 256x256 with K <= XL_GEMM_RELAY_MAX_K (1024), 2 = every eligible launch (forward / dX layouts,
- * bf16 in / out, fast epilogue kind NONE / RESIDUAL / GELU_DG / MULAUX, no fused column sums, M % 256 == N % 256 == K % 64 == 0,
- * K >= 768); env XL_GEMM_RELAY sets the initial value.  Bit-identical results to the other tile shapes. */
-int  xl_set_gemm_relay(int mode);
-/* number of persistent workgroups a relay launch may put up (default 256 = one per CU; at most half the launch's 256x128 tiles);
- * tuning / test switch, env XL_GEMM_RELAY_WGS */
-int  xl_set_gemm_relay_wgs(int wgs);
-/* K split of a launch WITH an epilogue (forward / dX layouts, bf16 in and out, fast epilogue): a launch of at most
- * XL_GEMM_SPLIT_EPI_MAX_TILES (80) output tiles of 256x192 / 256x256 whose contraction is at least XL_GEMM_SPLIT_EPI_MIN_K (1536)
- * deep runs every tile as 2..4 K slices of >= 12 K tiles on whole-CU workgroups; the slices meet in the stream's slab workspace
- * (xl_gemm_set_workspace: needed), are summed in slice order by the last arriver (deterministic), which runs the epilogue.  The
- * language stream's 3328 packed rows against the d x dff and d x 3d weights are the case: 56 tiles, K = 3072 / 2304 -- measured 47 ->
- * 50 us at every split factor (the slab hand-over costs what the shorter K loop saves, DESIGN.md section 6), hence OFF by default.
- * 0 = never (default; env XL_GEMM_SPLIT_EPI), 1 = when eligible (needs the stream's slab workspace, xl_gemm_set_workspace; without
- * one the launch runs unsplit).  Same values as the unsplit launch up to the fp32 summation order. */
-int  xl_set_gemm_split_epi(int on);
 /* debug: when `buffer` is non-null (device memory, 4 x uint64 per workgroup of the largest launch), the ping-pong GEMM
  * kernel records wall-clock stamps (100 MHz) at start / after prologue / after the K loop / after its stores */
 int  xl_gemm_trace(void* buffer);
@@ -155,26 +120,6 @@ int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             int epilogue, float alpha, int accumulate,
             float p_drop, uint64_t seed, float* colsum_out, float* colsum_ws, void* stream);
 
-/* Two contractions of one shape class, possibly in ONE launch: exactly
- *     xl_gemm(A0, B0, C0, bias0, residual0, aux0, M0, ..., accumulate 0, p_drop, seed0, colsum_out0, colsum_ws0, stream);
- *     xl_gemm(A1, B1, C1, bias1, residual1, aux1, M1, ..., accumulate 0, p_drop, seed1, colsum_out1, colsum_ws1, stream);
- * (same N, K, leading dimensions, layouts, element types, epilogue kind, alpha and dropout probability; own operands, row count,
- * dropout seed and column-sum outputs).  The visual and the language side of a cross-modality layer's self-attention / FFN
- * sub-blocks (HF:417-449: visn_self_att | lang_self_att, visn_inter/output | lang_inter/output) and of the two single-modality
- * stacks (HF:516-529) are such pairs: 16384 visual rows and ~3300 packed language rows against different weights of the same
- * shape.  When both problems are bf16 with K-major A, M a multiple of 256, N of 256, aligned operands and an epilogue kind with a
- * paired instance (forward layout: NONE / RESIDUAL / GELU_DG; dX layout: NONE / RESIDUAL / MULAUX), their 256x256 output tiles are
- * dealt to the CUs by one launch of the ping-pong kernel -- the language side's 39 row tiles ride in the CUs the visual side's
- * last round leaves idle instead of occupying a quarter of the chip at a tenth of its matrix rate beside it.  Otherwise: the two
- * xl_gemm calls.  Results are bit-identical either way (the same tile code runs each tile).  xl_set_gemm_pair(0) / env
- * XL_GEMM_PAIR=0: always two launches. */
-int  xl_gemm_pair(const void* A0, const void* B0, void* C0, const float* bias0, const void* residual0, void* aux0, int M0,
-                  uint64_t seed0, float* colsum_out0, float* colsum_ws0,
-                  const void* A1, const void* B1, void* C1, const float* bias1, const void* residual1, void* aux1, int M1,
-                  uint64_t seed1, float* colsum_out1, float* colsum_ws1,
-                  int N, int K, int lda, int ldb, int ldc, int ldr, int ldx, int a_kmajor, int b_kmajor, int in_dtype,
-                  int out_dtype, int epilogue, float alpha, float p_drop, void* stream);
-int  xl_set_gemm_pair(int on);
 
 /* Grouped weight gradients: for i in [0, count), count <= 8:
  *     C_i[M_i, N_i] (fp32) += sum_k A_i[k, m] * B_i[k, n]        (dW = dY^T X; both operands stored [K_i rows][features])
@@ -477,6 +422,74 @@ int  xl_comm_allgather(int64_t comm, const void* send, void* recv, int64_t send_
 int  xl_comm_bcast(int64_t comm, void* buf, int64_t bytes, int root, void* after_stream);
 int  xl_comm_reduce(int64_t comm, void* buf, int64_t count, int dtype, int root, void* after_stream);
 int  xl_comm_wait(int64_t comm, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * EXPERIMENTAL entry points: kernel / schedule variants that were built, proven bit-exact and MEASURED SLOWER than the defaults
+ * inside the four-stream training step (DESIGN.md section 6 has each one's numbers).  They are compiled and exported only by the
+ * experimental build (XL_EXPERIMENTAL=1 python -m xlxmert_amd.build -> libxlxmert_hip_exp.so, -DXL_EXPERIMENTAL; tests that
+ * exercise them are collected only with XL_EXPERIMENTAL=1); the default library neither contains their kernels nor exports these
+ * symbols.
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+#ifdef XL_EXPERIMENTAL
+/* 256x192 output tiles of the ping-pong kernel (forward / dX layouts, N a multiple of 192, M of 256, bf16 output): 0 = never
+ * (default since round 4: in the four-stream step a main-chain launch that leaves a quarter of the CUs to the other streams is worth
+ * more than the full round it forgoes, -0.27 .. -0.37 ms per step), 1 = when they shorten the launch taken alone (N = 768 gives 192
+ * tiles of 256x256 on 256 CUs but 256 of 256x192), 2 = whenever eligible (test switch); env XL_GEMM_BN192 sets the initial value */
+int  xl_set_gemm_tile192(int mode);
+/* persistent variant of the ping-pong kernel for launches of several rounds of 256x256 tiles with a short contraction (the FFN's
+ * first Linear and the gradient through its GELU: N = 3072, K = 768): one workgroup per CU walks its tiles and requests the next
+ * tile's first K tile under the epilogue of the current one.  0 = never (default; env XL_GEMM_PERSIST), 1 = when eligible.
+ * Bit-identical results either way.  Measured: -5 % on the FFN1 + GELU launch in isolation, +0.1 ms on the whole step -- a
+ * workgroup that holds its CU across tiles keeps the other streams' workgroups out at the tile boundaries. */
+int  xl_set_gemm_persistent(int on);
+/* 128x192 output tiles by EIGHT waves of 32x96 at 128 registers (csrc/gemm_q.hip): two workgroups per CU, four waves per SIMD -- each
+ * workgroup keeps two waves per SIMD in its K loop, so one's prologue / epilogue / hand-over runs under the other's K loop (the whole-CU
+ * 256x256 tile spends 30-40 % of a K = 768 tile's time there with nothing to overlap it).  0 = never, 1 = contractions of depth <=
+ * XL_GEMM_Q_MAX_K (1024) and width N <= XL_GEMM_Q_MAX_N (2304) with between XL_GEMM_Q_MIN_TILES (64) and XL_GEMM_Q_MAX_TILES (unbounded) tiles of 128x192, 2 = every eligible launch (forward / dX layouts, bf16 in / out,
+ * a fast epilogue kind, no fused column sums, M % 128 == N % 192 == K % 64 == 0); env XL_GEMM_Q sets the initial value.  Bit-identical
+ * results to the other tile shapes. */
+int  xl_set_gemm_q(int mode);
+/* "relay" kernel (csrc/gemm_relay.hip): one persistent 8-wave workgroup per CU whose two groups of four waves trade roles every
+ * 256x128 output tile -- one group runs the tile's K loop as a self-pipelined MFMA stream, the other issues its LDS-DMA and runs the
+ * PREVIOUS tile's epilogue under it (two accumulator sets per SIMD, one per wave).  0 = never, 1 = launches of more than
+ * XL_GEMM_RELAY_MIN_TILES (257) tiles of 256x256 with K <= XL_GEMM_RELAY_MAX_K (1024), 2 = every eligible launch (forward / dX layouts,
+ * bf16 in / out, fast epilogue kind NONE / RESIDUAL / GELU_DG / MULAUX, no fused column sums, M % 256 == N % 256 == K % 64 == 0,
+ * K >= 768); env XL_GEMM_RELAY sets the initial value.  Bit-identical results to the other tile shapes. */
+int  xl_set_gemm_relay(int mode);
+/* number of persistent workgroups a relay launch may put up (default 256 = one per CU; at most half the launch's 256x128 tiles);
+ * tuning / test switch, env XL_GEMM_RELAY_WGS */
+int  xl_set_gemm_relay_wgs(int wgs);
+/* K split of a launch WITH an epilogue (forward / dX layouts, bf16 in and out, fast epilogue): a launch of at most
+ * XL_GEMM_SPLIT_EPI_MAX_TILES (80) output tiles of 256x192 / 256x256 whose contraction is at least XL_GEMM_SPLIT_EPI_MIN_K (1536)
+ * deep runs every tile as 2..4 K slices of >= 12 K tiles on whole-CU workgroups; the slices meet in the stream's slab workspace
+ * (xl_gemm_set_workspace: needed), are summed in slice order by the last arriver (deterministic), which runs the epilogue.  The
+ * language stream's 3328 packed rows against the d x dff and d x 3d weights are the case: 56 tiles, K = 3072 / 2304 -- measured 47 ->
+ * 50 us at every split factor (the slab hand-over costs what the shorter K loop saves, DESIGN.md section 6), hence OFF by default.
+ * 0 = never (default; env XL_GEMM_SPLIT_EPI), 1 = when eligible (needs the stream's slab workspace, xl_gemm_set_workspace; without
+ * one the launch runs unsplit).  Same values as the unsplit launch up to the fp32 summation order. */
+int  xl_set_gemm_split_epi(int on);
+/* Two contractions of one shape class, possibly in ONE launch: exactly
+ *     xl_gemm(A0, B0, C0, bias0, residual0, aux0, M0, ..., accumulate 0, p_drop, seed0, colsum_out0, colsum_ws0, stream);
+ *     xl_gemm(A1, B1, C1, bias1, residual1, aux1, M1, ..., accumulate 0, p_drop, seed1, colsum_out1, colsum_ws1, stream);
+ * (same N, K, leading dimensions, layouts, element types, epilogue kind, alpha and dropout probability; own operands, row count,
+ * dropout seed and column-sum outputs).  The visual and the language side of a cross-modality layer's self-attention / FFN
+ * sub-blocks (HF:417-449: visn_self_att | lang_self_att, visn_inter/output | lang_inter/output) and of the two single-modality
+ * stacks (HF:516-529) are such pairs: 16384 visual rows and ~3300 packed language rows against different weights of the same
+ * shape.  When both problems are bf16 with K-major A, M a multiple of 256, N of 256, aligned operands and an epilogue kind with a
+ * paired instance (forward layout: NONE / RESIDUAL / GELU_DG; dX layout: NONE / RESIDUAL / MULAUX), their 256x256 output tiles are
+ * dealt to the CUs by one launch of the ping-pong kernel -- the language side's 39 row tiles ride in the CUs the visual side's
+ * last round leaves idle instead of occupying a quarter of the chip at a tenth of its matrix rate beside it.  Otherwise: the two
+ * xl_gemm calls.  Results are bit-identical either way (the same tile code runs each tile).  xl_set_gemm_pair(0) / env
+ * XL_GEMM_PAIR=0: always two launches. */
+int  xl_gemm_pair(const void* A0, const void* B0, void* C0, const float* bias0, const void* residual0, void* aux0, int M0,
+                  uint64_t seed0, float* colsum_out0, float* colsum_ws0,
+                  const void* A1, const void* B1, void* C1, const float* bias1, const void* residual1, void* aux1, int M1,
+                  uint64_t seed1, float* colsum_out1, float* colsum_ws1,
+                  int N, int K, int lda, int ldb, int ldc, int ldr, int ldx, int a_kmajor, int b_kmajor, int in_dtype,
+                  int out_dtype, int epilogue, float alpha, float p_drop, void* stream);
+int  xl_set_gemm_pair(int on);
+#endif /* XL_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+EXPERIMENTAL = os.environ.get("XL_EXPERIMENTAL", "0") not in ("", "0")
+# tests of kernel / schedule variants that only the experimental build contains (XL_EXPERIMENTAL=1 python -m xlxmert_amd.build):
+# collected only when that build is the one under test
+EXPERIMENTAL_TESTS = ("test_gemm_relay_", "test_gemm_q_tiles", "test_gemm_persistent_kernel", "test_gemm_256x192_tiles", "test_gemm_pair_",
+                      "test_gemm_split_k_with_epilogue", "paired_blocks", "test_vqa_step_paired", "_pair_")
+
+
+def _meaningless(item):
+    """parameter combinations that select nothing: the kernel-choice switches only affect the bf16 MFMA kernels (the tests used to
+    skip them at run time: 100+ "skipped" lines that said nothing about the library)"""
+    cs = getattr(item, "callspec", None)
+    if cs is None:
+        return False
+    p = cs.params
+    fp32 = str(p.get("dtype", "")) == "torch.float32"
+    if fp32 and (p.get("tr") == 0 or p.get("pingpong") == 2):
+        return True
+    return p.get("tr") == 0 and p.get("pingpong") == 2
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests skip themselves when no device is present (so a plain `pytest tests` is green here)."""
+    drop = [it for it in items if _meaningless(it) or (not EXPERIMENTAL and any(k in it.name for k in EXPERIMENTAL_TESTS))]
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = [it for it in items if it not in drop]
     try:
         import torch
         has_gpu = torch.cuda.is_available()

@@ -10,10 +10,19 @@ def test_library_builds_and_exports_every_declared_symbol():
     from xlxmert_amd.build import build_library
     from xlxmert_amd._lib import Lib, parse_header
     lib = Lib(build_library())
-    protos = parse_header()
-    assert len(protos) >= 20
+    exp = parse_header(experimental=True)
+    protos = parse_header(experimental=None if lib.experimental else False)
+    assert len(protos) >= 20 and len(exp) >= 7 and "xl_set_gemm_relay" in exp and "xl_gemm_pair" in exp
     for name in protos:
         assert hasattr(lib._dll, name), name
+    if not lib.experimental:
+        # the default library contains neither the experimental kernels nor their entry points (include/xlxmert_hip.h, EXPERIMENTAL)
+        for name in exp:
+            assert not hasattr(lib._dll, name), name
+        import subprocess
+        syms = subprocess.run(["nm", "-D", "--defined-only", lib.path], capture_output=True, text=True).stdout
+        for frag in ("relay_kernel", "gemm_bf16_q_kernel", "pp_persist_kernel", "pp_pair_kernel"):
+            assert frag not in syms, frag
     assert lib.raw("xl_version")() == 1
     must = {"xl_gemm", "xl_layernorm_fwd", "xl_layernorm_bwd", "xl_sdpa_fwd", "xl_sdpa_bwd", "xl_embed_ln_fwd",
             "xl_codebook_gather", "xl_ce_fwd_bwd", "xl_featloss_fwd_bwd", "xl_adamw", "xl_sumsq", "xl_last_error"}

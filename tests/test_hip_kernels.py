@@ -465,7 +465,8 @@ def _tiles_exact(M, N, K, epi, bk, duo, q=0, relay=0):
     alpha = 2.0 ** -6 if epi in (1, 3, 6, 7) else 1.0      # keep GELU / dGELU arguments in a sensible range
     ops = hip(torch.bfloat16)
     ops.set_gemm_pingpong(2)
-    ops.set_gemm_tile192(2)
+    if ops.lib.experimental:
+        ops.set_gemm_tile192(2)
     ops.set_gemm_duo(duo)
     ops.set_gemm_q(q)
     ops.set_gemm_relay(relay)
@@ -487,7 +488,7 @@ def _tiles_exact(M, N, K, epi, bk, duo, q=0, relay=0):
                 close(gpu[5], cpu[5], torch.bfloat16, "saved derivative", bf16_tol=1e-2)
     finally:
         ops.set_gemm_pingpong(1)
-        ops.set_gemm_tile192(1)
+        ops.set_gemm_tile192(0)
         ops.set_gemm_duo(1)
         ops.set_gemm_q(0)
         ops.set_gemm_relay(0)

@@ -839,3 +839,34 @@ def test_edge_case_batches_match_oracle(case):
         assert d < 3e-5 * max(1.0, g.abs().max().item()), (case, k, d)
         n += 1
     assert n > 80
+
+
+def test_new_kept_ranges_drop_recorded_plans_and_partial_master_is_guarded():
+    """(i) a launch plan recorded before a gradient range became "kept" may accumulate into it on the strength of the
+    optimizer pass clearing the range -- ParamStore.mark_overwritten reports new ranges and the trainer drops its plans; (ii) with the
+    sharded exchange's bf16 gather the fp32 master matrices are whole on their owner only: the store refuses to export parameters and
+    the engine keeps its compute copy until gather_state()."""
+    cfg = XLxmertConfig(**TINY)
+    tr, sd = make_step(cfg, 3, 8, 4, lr=1e-2)
+    st = tr.store
+    assert st.mark_overwritten([(0, 512)]) is True
+    assert st.mark_overwritten([(0, 512)]) is False
+    tr._plans[("fake",)] = object()
+    tr.engine.overwritten = {(0, 512)}
+    tr.engine.written_now = {(0, 512)}
+    tr.optimizer_step()
+    assert tr._plans                                # nothing new: plans stay
+    tr._plans[("fake",)] = object()
+    tr.engine.overwritten = {(0, 512), (1024, 2048)}
+    tr.engine.written_now = {(0, 512), (1024, 2048)}
+    tr.optimizer_step()
+    assert not tr._plans                            # a range became kept: every recorded plan is dropped
+    st.master_partial = True
+    with pytest.raises(RuntimeError, match="gather_state"):
+        st.named_state()
+    before = st.master.clone()
+    st.master.add_(1.0)                             # a stale master copy must NOT reach the compute copy
+    tr.engine.sync_compute_weights()
+    st.master_partial = False
+    st.master.copy_(before)
+    assert st.named_state()

@@ -20,6 +20,8 @@ from xlxmert_amd.trainer import PretrainStep, synthetic_batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--only", default="")
+ap.add_argument("--settle", type=int, default=20)
+ap.add_argument("--max-drift", type=float, default=0.15)
 args = ap.parse_args()
 
 reserve_streams("cuda:0")
@@ -103,6 +105,8 @@ def run(name):
     for i in range(8):                  # re-record every masked-row geometry of the four batches
         tr.step(batches[i % 4])
     skipped = cur["skipped"] // 8
+    for i in range(args.settle):        # the power controller needs ~17 steps after any pause to settle (bench.py ms_per_step_series)
+        tr.step(batches[i % 4])
     torch.cuda.synchronize()
     t = time.perf_counter()
     for i in range(args.steps):
@@ -111,13 +115,21 @@ def run(name):
     return (time.perf_counter() - t) / args.steps * 1e3, skipped
 
 
+# Every arm is BRACKETED by two base runs and its delta is taken against the mean of its own bracket; an arm whose two brackets differ by
+# more than --max-drift ms is flagged (round 5's table compared every arm with ONE base run taken minutes earlier: the box drifted by
+# 1 ms inside the run and half the rows were drift, not signal).
 res = {}
-base = None
-for rep in range(2):                    # A/B/A: the base again at the end
-    for name in (names if rep == 0 else ["base"]):
-        ms, sk = run(name)
-        if name == "base" and base is None:
-            base = ms
-        res[name + ("" if rep == 0 else "_again")] = {"ms": round(ms, 3), "delta_ms": round(ms - base, 3), "launches_skipped_per_step": sk}
-        print(f"{name:28s} {ms:7.3f} ms  ({ms - base:+.3f})  skipped/step {sk}", flush=True)
+arms = [n for n in names if n != "base"]
+prev, _ = run("base")
+print(f"{'base':28s} {prev:7.3f} ms", flush=True)
+for name in arms:
+    ms, sk = run(name)
+    nxt, _ = run("base")
+    drift = nxt - prev
+    ref = 0.5 * (prev + nxt)
+    ok = abs(drift) <= args.max_drift
+    res[name] = {"ms": round(ms, 3), "base_before": round(prev, 3), "base_after": round(nxt, 3), "delta_ms": round(ms - ref, 3),
+                 "bracket_drift_ms": round(drift, 3), "accepted": ok, "launches_skipped_per_step": sk}
+    print(f"{name:28s} {ms:7.3f} ms  ({ms - ref:+.3f} vs its bracket {prev:.3f} / {nxt:.3f}{'' if ok else '  REJECTED: drift'})  skipped/step {sk}", flush=True)
+    prev = nxt
 print(json.dumps(res))

@@ -9,15 +9,22 @@ import torch  # noqa: F401  -- must come first: loads the HIP runtime this proce
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "xlxmert_hip.h")
-LIB_PATH = os.environ.get("XL_LIB", os.path.join(HERE, "libxlxmert_hip.so"))      # XL_LIB: debug builds (e.g. -DXL_PP_PROFILE)
+EXPERIMENTAL = os.environ.get("XL_EXPERIMENTAL", "0") not in ("", "0")     # the experimental build (kernel variants that lost inside the step)
+LIB_PATH = os.environ.get("XL_LIB", os.path.join(HERE, "libxlxmert_hip_exp.so" if EXPERIMENTAL else "libxlxmert_hip.so"))   # XL_LIB: debug builds
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64}
 
 
-def parse_header(path=HEADER):
-    """-> {name: (restype, [(argtype, argname), ...])} for every `xl_*` prototype in the header."""
+def parse_header(path=HEADER, experimental=None):
+    """-> {name: (restype, [(argtype, argname), ...])} for every `xl_*` prototype in the header.  experimental: None = all,
+    False = only the default library's, True = only those inside `#ifdef XL_EXPERIMENTAL`."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    m = re.search(r"#ifdef XL_EXPERIMENTAL(.*?)#endif", src, flags=re.S)
+    if experimental is True:
+        src = m.group(1) if m else ""
+    elif experimental is False and m:
+        src = src[:m.start()] + src[m.end():]
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
     for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(xl_\w+)\s*\(([^)]*)\)\s*;", src):
@@ -49,7 +56,11 @@ class Lib:
             raise XlError(f"{path} not found: build it first (python -m xlxmert_amd.build, or __graft_entry__.build()). "
                           "There is no CPU / eager fallback for the X-LXMERT hot path.")
         self._dll = ctypes.CDLL(path)
-        self.protos = parse_header()
+        self.protos = parse_header(experimental=False)
+        exp = parse_header(experimental=True)
+        self.experimental = bool(exp) and all(hasattr(self._dll, n) for n in exp)     # the -DXL_EXPERIMENTAL build exports them all
+        if self.experimental:
+            self.protos.update(exp)
         for name, (ret, args) in self.protos.items():
             fn = getattr(self._dll, name)        # raises AttributeError if the .so lacks a declared symbol
             fn.argtypes = [_ctype(t) for t, _ in args]
@@ -60,6 +71,9 @@ class Lib:
         """status-returning entry points: 0 = ok, negative = XL_ERR_* (the error convention of include/xlxmert_hip.h).
         Value-returning ones (xl_version, xl_workspace_floats, xl_last_error) go through raw().
         While a recorder is installed (record()), the call is executed AND appended to it."""
+        if name not in self.protos:
+            raise XlError(f"{name} is an entry point of the experimental build only: XL_EXPERIMENTAL=1 python -m xlxmert_amd.build, "
+                          "then run with XL_EXPERIMENTAL=1 (include/xlxmert_hip.h, section EXPERIMENTAL)")
         rc = getattr(self._dll, name)(*args)
         if rc < 0:
             raise XlError(f"{name} failed ({rc}): {self._dll.xl_last_error().decode()}")

@@ -8,9 +8,17 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libxlxmert_hip.so")
-SOURCES = ["gemm_pp.hip", "gemm_pp_nn.hip", "gemm_pp_192.hip", "gemm_pp_persist.hip", "gemm_pp_duo.hip", "gemm_pp_pair.hip", "gemm_q.hip", "gemm_relay.hip", "gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip", "comm.hip"]
+# Default library: what the training step, the samplers and the task rows call.  XL_EXPERIMENTAL=1 builds libxlxmert_hip_exp.so instead:
+# the same plus the kernel / schedule variants that were measured slower inside the step (256x192 tiles, persistent tiles, paired
+# launches, eight-wave q tiles, the role-trading relay kernel, K split with an epilogue) and their entry points (-DXL_EXPERIMENTAL).
+EXPERIMENTAL = os.environ.get("XL_EXPERIMENTAL", "0") not in ("", "0")
+LIB = os.path.join(HERE, "libxlxmert_hip_exp.so" if EXPERIMENTAL else "libxlxmert_hip.so")
+SOURCES = ["gemm_pp.hip", "gemm_pp_nn.hip", "gemm_pp_duo.hip", "gemm.hip", "rowops.hip", "sdpa.hip", "optim.hip", "plan.hip", "comm.hip"]
+SOURCES_EXPERIMENTAL = ["gemm_pp_192.hip", "gemm_pp_persist.hip", "gemm_pp_pair.hip", "gemm_q.hip", "gemm_relay.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+if EXPERIMENTAL:
+    SOURCES = SOURCES + SOURCES_EXPERIMENTAL
+    FLAGS = FLAGS + ["-DXL_EXPERIMENTAL"]
 
 
 def _hipcc():
@@ -30,7 +38,7 @@ def needs_build():
 
 def build_library(force=False, verbose=True):
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", "exp" if EXPERIMENTAL else "default")
     os.makedirs(objdir, exist_ok=True)
 
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \

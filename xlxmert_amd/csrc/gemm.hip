@@ -296,15 +296,19 @@ extern "C" int xl_set_gemm_pingpong(int mode) {
     return XL_OK;
 }
 
+#ifdef XL_EXPERIMENTAL
 extern "C" int xl_set_gemm_persistent(int on) {
     ctx().gemm_persist = on ? 1 : 0;
     return XL_OK;
 }
+#endif
 
+#ifdef XL_EXPERIMENTAL
 extern "C" int xl_set_gemm_split_epi(int on) {
     ctx().gemm_split_epi = on ? 1 : 0;
     return XL_OK;
 }
+#endif
 
 extern "C" int xl_set_gemm_duo(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_duo: mode %d", mode);
@@ -312,11 +316,13 @@ extern "C" int xl_set_gemm_duo(int mode) {
     return XL_OK;
 }
 
+#ifdef XL_EXPERIMENTAL
 extern "C" int xl_set_gemm_tile192(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_tile192: mode %d", mode);
     ctx().gemm_bn192 = mode;
     return XL_OK;
 }
+#endif
 
 extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
                        const void* residual, void* aux,
@@ -385,7 +391,11 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // chip) and the isolated GEMM sum is 2 % better with mode 1 -- but the step runs four streams, and a main-chain launch that takes
     // every CU makes the language stream's and the weight-gradient stream's workgroups wait for a whole tile: measured on three boxes,
     // A/B/A: 17.23 -> 16.96, 17.35 -> 17.07, 17.85 -> 17.48 ms per step with 256x256 tiles only (mode 2, always 192-wide: 17.52).
+#ifdef XL_EXPERIMENTAL
     if (cx.gemm_bn192 < 0) cx.gemm_bn192 = env_int("XL_GEMM_BN192", 0);     // 0 never, 1 by cost, 2 whenever eligible
+#else
+    cx.gemm_bn192 = 0;          // (256x192 tiles, split-K with an epilogue, q tiles, relay, persistent, pairs: experimental build, XL_EXPERIMENTAL=1)
+#endif
     const int bn192_mode = cx.gemm_bn192;
     int bn = 256;
     if (use_pp && bn192_mode && a_kmajor && M % 256 == 0 && N % 192 == 0 && out_dtype == in_dtype && !accumulate &&
@@ -445,7 +455,11 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     // (slab_exchange, summed in slice order: deterministic); the last arriver runs the ordinary fast epilogue.  The same FLOPs on
     // 4x the CUs for a quarter of the time: as 112 half-CU "duo" workgroups, each alone on a CU with one wave per SIMD, these
     // launches ran at 0.14 of the MFMA peak (47 us for 16.9 GFLOP).  XL_GEMM_SPLIT_EPI=0 disables; thresholds below.
+#ifdef XL_EXPERIMENTAL
     if (cx.gemm_split_epi < 0) cx.gemm_split_epi = env_int("XL_GEMM_SPLIT_EPI", 0);
+#else
+    cx.gemm_split_epi = 0;
+#endif
     const int split_epi = cx.gemm_split_epi;
     static const int split_epi_min_k = env_int("XL_GEMM_SPLIT_EPI_MIN_K", 1536);
     static const int split_epi_max_tiles = env_int("XL_GEMM_SPLIT_EPI_MAX_TILES", 80);
@@ -471,6 +485,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             }
         }
     }
+#ifdef XL_EXPERIMENTAL
     // "relay" kernel (gemm_relay.hip): one persistent workgroup per CU whose two wave groups trade roles every 256 x 128 tile -- one runs
     // the K loop as a self-pipelined MFMA stream, the other issues its LDS-DMA and runs the previous tile's epilogue under it.  Mode 0
     // never, 1 launches of more than XL_GEMM_RELAY_MIN_TILES 256x256 tiles with K <= XL_GEMM_RELAY_MAX_K, 2 every eligible launch.
@@ -512,6 +527,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         XL_CHECK_LAUNCH();
         return XL_OK;
     }
+#endif
     // 128x192 "duo" tiles, two four-wave workgroups per CU (gemm_pp_kernel.h PPGeo<192, 128>): same eligibility as the 256x192 tile
     // (forward / dX layouts, N a multiple of 192, fast epilogue, plain stores) with M a multiple of 128
     // mode 1: the launches of fewer than XL_GEMM_DUO_MAX_TILES 256x256 tiles (the language stream's: 3328 packed rows = 39 tiles,
@@ -550,10 +566,11 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
             }
         }
     }
+    static const int n_cu = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+#ifdef XL_EXPERIMENTAL
     // several rounds of 256x256 tiles with a short contraction: the persistent variant (next tile's first K tile requested under
     // the epilogue, no workgroup hand-over between tiles) -- OPT-IN: faster alone, slower inside the four-stream step
     if (cx.gemm_persist < 0) cx.gemm_persist = env_int("XL_GEMM_PERSIST", 0);      // opt-in: see gemm_pp_persist.hip
-    static const int n_cu = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
     static const int persist_max_k = env_int("XL_GEMM_PERSIST_MAX_K", 1536);
     if (use_pp && cx.gemm_persist && bn == 256 && bm == 256 && a_kmajor && epik >= 0 && epik != XL_EPI_TANH && epik != XL_EPI_ROWMAX &&
         epik != XL_EPI_RESIDUAL && out_dtype == XL_BF16 && !p.atomic_out && p.splitk == 1 && p.tail_tiles == 0 && M % 256 == 0 &&
@@ -567,6 +584,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
         }
         XL_CHECK_ARG(e == hipErrorInvalidValue, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
+#endif
     if (use_pp || bm == 128 || epi_split) {
         hipError_t e = launch_pp(p, a_kmajor, b_kmajor, epik, bn, nblk, st, bm);
         XL_CHECK_ARG(e == hipSuccess, XL_ERR_HIP, "xl_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -590,6 +608,7 @@ extern "C" int xl_gemm(const void* A, const void* B, void* C, const float* bias,
     return XL_OK;
 }
 
+#ifdef XL_EXPERIMENTAL
 // Two contractions of the same shape class in one launch (gemm_pp_kernel.h PairParams); see include/xlxmert_hip.h.  Whatever the
 // launch strategy, the results are those of xl_gemm(problem 0) followed by xl_gemm(problem 1): the same tile kernel runs both.
 extern "C" int xl_gemm_pair(const void* A0, const void* B0, void* C0, const float* bias0, const void* residual0, void* aux0, int M0,
@@ -650,29 +669,38 @@ extern "C" int xl_gemm_pair(const void* A0, const void* B0, void* C0, const floa
         if (cs_out[i] != nullptr) { launch_colsum_reduce(cs_ws[i], M[i] / 128, N, cs_out[i], st); XL_CHECK_LAUNCH(); }
     return XL_OK;
 }
+#endif
 
+#ifdef XL_EXPERIMENTAL
 extern "C" int xl_set_gemm_relay(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_relay: mode %d", mode);
     ctx().gemm_relay = mode;
     return XL_OK;
 }
+#endif
 
+#ifdef XL_EXPERIMENTAL
 extern "C" int xl_set_gemm_relay_wgs(int wgs) {
     XL_CHECK_ARG(wgs >= 1 && wgs <= 4096, XL_ERR_BAD_ARG, "xl_set_gemm_relay_wgs: %d", wgs);
     ctx().gemm_relay_wgs = wgs;
     return XL_OK;
 }
+#endif
 
+#ifdef XL_EXPERIMENTAL
 extern "C" int xl_set_gemm_q(int mode) {
     XL_CHECK_ARG(mode >= 0 && mode <= 2, XL_ERR_BAD_ARG, "xl_set_gemm_q: mode %d", mode);
     ctx().gemm_q = mode;
     return XL_OK;
 }
+#endif
 
+#ifdef XL_EXPERIMENTAL
 extern "C" int xl_set_gemm_pair(int on) {
     ctx().gemm_pair = on ? 1 : 0;
     return XL_OK;
 }
+#endif
 
 extern "C" int xl_gemm_wgrad_group_splitk(const int* M, const int* N, const int* K, int count) {
     if (M == nullptr || N == nullptr || K == nullptr || count < 1 || count > 8) return 0;

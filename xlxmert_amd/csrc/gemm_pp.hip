@@ -52,7 +52,11 @@ hipError_t launch_pp_nt256(const GemmParams& p, int epik, int nblk, hipStream_t 
 
 hipError_t launch_pp(const GemmParams& p, int a_kmajor, int b_kmajor, int epik, int bn, int nblk, hipStream_t st, int bm) {
     if (bm == 128) return (a_kmajor && bn == 192) ? launch_pp_duo(p, b_kmajor, epik, nblk, st) : hipErrorInvalidValue;
+#ifdef XL_EXPERIMENTAL
     if (bn == 192) return a_kmajor ? launch_pp_192(p, b_kmajor, epik, nblk, st) : hipErrorInvalidValue;
+#else
+    if (bn == 192) return hipErrorInvalidValue;          // 256x192 tiles: experimental build only (XL_EXPERIMENTAL=1)
+#endif
     if (a_kmajor && b_kmajor) return launch_pp_nt256(p, epik, nblk, st);
     return launch_pp_other256(p, a_kmajor, b_kmajor, epik, nblk, st);
 }

@@ -51,7 +51,11 @@ struct Invoker<F> {
 struct PlanFn { const char* name; int nargs; int (*call)(const uint64_t*); };
 #define XL_PLAN_FN(f) {#f, Invoker<&f>::N, &Invoker<&f>::call}
 static const PlanFn kFns[] = {
-    XL_PLAN_FN(xl_set_step_seed_ptr), XL_PLAN_FN(xl_gemm), XL_PLAN_FN(xl_gemm_pair), XL_PLAN_FN(xl_gemm_wgrad_group), XL_PLAN_FN(xl_layernorm_fwd),
+    XL_PLAN_FN(xl_set_step_seed_ptr), XL_PLAN_FN(xl_gemm),
+#ifdef XL_EXPERIMENTAL
+    XL_PLAN_FN(xl_gemm_pair),
+#endif
+    XL_PLAN_FN(xl_gemm_wgrad_group), XL_PLAN_FN(xl_layernorm_fwd),
     XL_PLAN_FN(xl_layernorm_bwd), XL_PLAN_FN(xl_visn_ln_fwd), XL_PLAN_FN(xl_visn_ln_bwd), XL_PLAN_FN(xl_set_deferred_reduce),
     XL_PLAN_FN(xl_flush_reductions), XL_PLAN_FN(xl_embed_ln_fwd), XL_PLAN_FN(xl_embed_bwd), XL_PLAN_FN(xl_codebook_gather),
     XL_PLAN_FN(xl_masked_colsum), XL_PLAN_FN(xl_colsum), XL_PLAN_FN(xl_dropout), XL_PLAN_FN(xl_gelu_bwd), XL_PLAN_FN(xl_tanh_bwd),

@@ -1261,6 +1261,11 @@ class Engine:
     def sync_compute_weights(self):
         """refresh the compute-dtype copy of the master parameters (after load_state_dict / init)."""
         st = self.store
+        if st.master_partial:
+            # sharded exchange with gather="bf16": the compute copy IS the replicated state (the all-gather moves it), the fp32 master
+            # matrices are whole on their owner only -- casting master -> compute here would revert every non-owned matrix to its
+            # initial value and the replicas would diverge (ADVICE r5).  PretrainStep.gather_state() makes the master copy whole.
+            return
         if st.compute_dtype != torch.float32:
             self.ops.cast_from_f32(st.master, st.compute, st.n_total)
 
@@ -1298,6 +1303,17 @@ class Engine:
             self.ids.copy_(input_ids, non_blocking=True)
             if word_order is None:
                 word_order = torch.sort(input_ids.reshape(-1), stable=True).indices
+            elif not getattr(self, "_order_checked", False):
+                # the embedding backward gives every word-table row ONE writer -- the block that owns the row's run in this order -- and
+                # commits with a plain read-modify-write: an order computed from OTHER ids (before MLM masking, re-tokenisation ...) makes
+                # several owners race on a row, silently.  One check (a host round trip) on the first loader-supplied order.
+                self._order_checked = True
+                o = word_order.reshape(-1).to(device=input_ids.device, dtype=torch.int64)
+                srt = input_ids.reshape(-1)[o]
+                ok = o.numel() == B * L and bool((srt[1:] >= srt[:-1]).all()) and bool((torch.sort(o).values == torch.arange(B * L, device=o.device)).all())
+                if not ok:
+                    raise ValueError("set_inputs(word_order=): not a permutation that sorts THIS call's input_ids (trainer.word_order_of "
+                                     "must be computed from the ids that are passed in, after any masking)")
             self.word_order.copy_(word_order.reshape(-1), non_blocking=True)
         if attention_mask is None:
             self.kmask.fill_(1)

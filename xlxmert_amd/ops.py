@@ -72,6 +72,13 @@ class HipOps:
         self.ncalls += 1
         return self.lib.call(name, *args)
 
+    def _call_exp(self, name, value, default):
+        """setter of an EXPERIMENTAL switch (include/xlxmert_hip.h, section EXPERIMENTAL): with the default library, asking for the
+        default value is a no-op (the variant does not exist there), anything else raises through Lib.call"""
+        if not self.lib.experimental and int(value) == default:
+            return 0
+        return self._call(name, int(value))
+
     def rebind(self):
         """bind this object's context unconditionally (first entry of a recorded launch plan; after a plan replay, whose last
         recorded bind -- possibly another object's -- is the one in effect)."""
@@ -110,7 +117,7 @@ class HipOps:
     def set_gemm_persistent(self, on):
         """persistent ping-pong kernel for multi-round, short-K launches: 1 = when eligible, 0 = never (default; env
         XL_GEMM_PERSIST sets the initial value)."""
-        self._call("xl_set_gemm_persistent", int(on))
+        self._call_exp("xl_set_gemm_persistent", on, 0)
 
     def set_gemm_duo(self, mode):
         """128x192 tiles, two four-wave workgroups per CU: 0 never, 1 small launches (default), 2 every eligible launch."""
@@ -118,18 +125,18 @@ class HipOps:
 
     def set_gemm_q(self, mode):
         """128x192 tiles by eight 128-register waves, two workgroups per CU: 0 never, 1 short contractions, 2 every eligible launch."""
-        self._call("xl_set_gemm_q", int(mode))
+        self._call_exp("xl_set_gemm_q", mode, 0)
 
     def set_gemm_relay(self, mode):
         """0 never / 1 multi-round K <= 1024 launches / 2 every eligible launch on the role-trading persistent kernel (gemm_relay.hip)"""
-        self._call("xl_set_gemm_relay", int(mode))
+        self._call_exp("xl_set_gemm_relay", mode, 0)
 
     def set_gemm_relay_wgs(self, wgs):
-        self._call("xl_set_gemm_relay_wgs", int(wgs))
+        self._call_exp("xl_set_gemm_relay_wgs", wgs, 256)
 
     def set_gemm_split_epi(self, on):
         """K split of few-tile, deep-K launches with an epilogue through the stream's slab workspace: 0 never (default), 1 when eligible."""
-        self._call("xl_set_gemm_split_epi", int(on))
+        self._call_exp("xl_set_gemm_split_epi", on, 0)
 
     def set_gemm_tail_split(self, max_tail_tiles, min_k):
         self._call("xl_set_gemm_tail_split", int(max_tail_tiles), int(min_k))
@@ -140,7 +147,7 @@ class HipOps:
 
     def set_gemm_tile192(self, mode):
         """0: 256x256 tiles only; 1: 256x192 where it shortens the launch (default); 2: whenever eligible."""
-        self._call("xl_set_gemm_tile192", int(mode))
+        self._call_exp("xl_set_gemm_tile192", mode, 0)
 
     # -- stream plumbing of a step as C-ABI calls (so that a recorded launch plan contains them: _lib.LaunchPlan)
     def zero(self, t):
@@ -226,7 +233,7 @@ class HipOps:
 
     def set_gemm_pair(self, on):
         """two-problem launches (xl_gemm_pair): 1 when eligible (default), 0 always two launches."""
-        self._call("xl_set_gemm_pair", int(on))
+        self._call_exp("xl_set_gemm_pair", on, 1)
 
     def gemm_wgrad_group(self, problems, overwrite_mask=0):
         """problems: list of (dY [K, M], X [K, N], dW [M, N] fp32, M, N, K, lda, ldb, ldc): dW += dY^T X, one launch; bit i of

@@ -219,6 +219,7 @@ class ParamStore:
         self.decay_flags = flags.to(dev)
         self._task_flags = {}
         self._kept = set()
+        self.master_partial = False     # sharded exchange, gather='bf16': the master matrices are whole on their owner only (trainer)
         # frozen centroid codebook (vis_emb.weight == obj_predict_head.out_cluster.weight, ref modeling.py:140-151)
         self.centroids = None          # fp32 [K, F]
         self.centroids_c = None        # compute dtype
@@ -229,7 +230,7 @@ class ParamStore:
         256-element chunk that lies inside one of them.  In place: recorded launch plans hold the flag tensors' pointers."""
         new = [r for r in ranges if r not in self._kept]
         if not new:
-            return
+            return False
         self._kept.update(new)
         fl = torch.zeros(self.n_total // CHUNK, dtype=torch.uint8)
         for lo, hi in new:
@@ -240,6 +241,8 @@ class ParamStore:
         self.decay_flags |= fl
         for t in self._task_flags.values():
             t |= fl
+        return True             # (the caller drops launch plans recorded under the old set: they may ACCUMULATE into a range that
+                                #  the optimizer pass has just stopped clearing -- ADVICE r5)
 
     def fp32_read_index(self, lo, hi):
         """int32 positions, relative to `lo`, of the elements of the flat range [lo, hi) that the kernels READ IN FP32 from the master
@@ -385,6 +388,10 @@ class ParamStore:
         return missing
 
     def named_state(self):
+        if self.master_partial:
+            raise RuntimeError("the fp32 master copy of the matrices is current on the owning rank only (sharded exchange with "
+                               "gather='bf16'): call PretrainStep.gather_state() on EVERY rank before reading parameters "
+                               "(state_dict / save_checkpoint / verify_replicas)")
         out = {n: self.view(n) for n in self.index}
         if "cls.predictions.bias" in self.index:
             out["cls.predictions.decoder.weight"] = self.view("bert.embeddings.word_embeddings.weight")      # tied

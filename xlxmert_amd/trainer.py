@@ -656,7 +656,10 @@ class PretrainStep:
         self.t += 1                      # host mirror of step_dev (seeds, logging): never read by a kernel
         eng = self.engine
         if eng.overwritten:              # ranges the backward stores rather than accumulates: the pass leaves them uncleared
-            self.store.mark_overwritten(sorted(eng.overwritten))
+            if self.store.mark_overwritten(sorted(eng.overwritten)) and self._plans:
+                # a plan recorded BEFORE a range became "kept" may hold an accumulating (mask 0) K-split launch into it that relied
+                # on the optimizer pass clearing the range; the pass has just stopped doing so.  Geometries re-record on next use.
+                self._plans.clear()
             # "every backward rewrites a kept range" is a claim about the step's composition: a step that skipped a producer (the
             # answer head when qa_labels is None, ...) left the PREVIOUS step's gradient in a range nobody clears any more.  The
             # reference's tensor would have .grad None there: zero it, so that the pass sees a zero gradient like before overwrite mode
@@ -724,6 +727,10 @@ class PretrainStep:
         # the compute-dtype copy, which every rank re-derives from the gathered slice with one cast on the collectives' stream):
         # the same bytes on the wire as the all-reduce's second half, and every rank's master weights stay whole.
         bf16_wire = self.gather_bf16
+        if bf16_wire and W > 1:
+            # from here on the fp32 master copy of the MATRICES is current on the owning rank only: the store refuses to export
+            # parameters (named_state) and the engine keeps its compute copy (sync_compute_weights) until gather_state() -- ADVICE r5
+            st.master_partial = True
         for i in reversed(range(len(self._segments))):          # last-finished slice first: feature encoder, embeddings, layer 0 ...
             kind, lo, hi = self._segments[i]
             a, b = owned[i]
@@ -789,6 +796,7 @@ class PretrainStep:
                 piece = buf[lo:hi]
                 dist.all_gather_into_tensor(piece, piece[r * per:(r + 1) * per].clone())
         self.sync()
+        st.master_partial = False
 
     def _optimizer_launches(self):
         if self.sharded and self._segments:
