@@ -253,7 +253,7 @@ def other_workloads(cfg, dev, steps=20, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--prewarm-s", type=float, default=0.6, help="seconds of untimed training steps before the W warm-up steps (power-controller settling)")
+    ap.add_argument("--prewarm-steps", type=int, default=32, help="free-running untimed training steps before the W warm-up steps (runtime pools grow to their high-water mark)")
     ap.add_argument("--steps", type=int, default=100)          # >= 100 timed steps after >= 20 warm-up steps
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (reference --batchSize, param.py:70)")
@@ -366,20 +366,19 @@ def main():
         torch.cuda.synchronize()
 
     nxt = get(0)
-    # Device pre-warm (reported as config.prewarm): after any pause the chip's power controller needs ~17 training steps to settle --
-    # the first step after an idle period runs at boost clocks (16.1 ms), steps 2-10 then oscillate up to 18.2 ms before the step
-    # time settles at 16.8 (profiles/r06b/bench_series.txt, --steps 20 --warmup 5 against --warmup 25 on one box).  With the driver's
-    # W = 5 the whole transient sat INSIDE the 20 timed steps (mean 17.19 vs 16.86 ms).  These extra steps are the same training step
-    # on the same batches, untimed like the W warm-up steps that follow them; --prewarm-s 0 switches them off.
+    # Runtime pre-warm (reported as config.prewarm).  The host queues a step in ~2 ms and the GPU runs it in ~16.5, so a loop of steps
+    # lets the host run ahead until the queues' back-pressure stops it -- about 10 steps deep.  The FIRST time it gets that deep the
+    # runtime grows its pools (completion signals, kernel-argument segments, event records) under the running GPU, and the steps in
+    # flight lose 0.7-2 ms each: --steps 20 --warmup 5 put that transient inside the timed region (steps 3, 5, 6 and 8 of every run at
+    # 17.1-18.4 ms, the rest at 16.3-16.5: mean 16.68 against a median of 16.46; profiles/r06b/bench_series.txt), --warmup 25 did not
+    # (the pools had grown during the warm-up).  A pre-warm paced by synchronize() does NOT remove it (measured: the host never gets
+    # deep), so these are free-running steps, the same training step on the same batches, untimed like the W warm-up steps that
+    # follow them; --prewarm-steps 0 switches them off.
     n_pre = 0
-    if args.prewarm_s > 0:
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.prewarm_s:
-            cur, nxt = nxt, get(n_pre + 1)
-            tr.step(cur)
-            n_pre += 1
-            if n_pre % 8 == 0:
-                torch.cuda.synchronize()          # (the host runs ~7 steps ahead of the GPU: bound the loop by GPU time)
+    for _ in range(max(0, args.prewarm_steps)):
+        cur, nxt = nxt, get(n_pre + 1)
+        tr.step(cur)
+        n_pre += 1
     for i in range(args.warmup):
         cur, nxt = nxt, get(n_pre + i + 1)
         tr.step(cur)
@@ -469,8 +468,9 @@ def main():
             "config": {"workload": "configs[1]+[2]: full X-LXMERT encoder 9L/5R/5X d=768 + obj_predict_head over 10k codebook, "
                                    "masked-visual-token step fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world,
                        "text_len": 20, "visual_tokens": 64, "parallelism": f"dp{world}",
-                       "prewarm": (f"{n_pre} untimed training steps ({args.prewarm_s} s) before the {args.warmup} warm-up steps: the power "
-                                   "controller takes ~17 steps after an idle period to settle (DESIGN.md section 6, round 6)") if n_pre else "none",
+                       "prewarm": (f"{n_pre} free-running untimed training steps before the {args.warmup} warm-up steps: the first time the host "
+                                   "runs ~10 steps ahead of the GPU the runtime grows its pools under the running kernels (DESIGN.md "
+                                   "section 6, round 6)") if n_pre else "none",
                        "value_definition": "value = global_batch x steps / wall time of the timed region (mean step, max over ranks); "
                                            "value_p50 = global_batch / median step (timing events at the step boundaries of rank 0) -- "
                                            "the quantity SURVEY 8d's 'median' refers to",

@@ -99,8 +99,24 @@ for op in orig:
     setattr(ops, op, wrap(op))
 
 
+# An ablated step trains on garbage: after a few optimizer passes the parameters hold NaN / zeros, every later contraction runs on
+# degenerate operand bits, draws less power and clocks higher -- round 5's "1.08 ms drift inside one run" (and the 1.25 ms step in
+# profiles/r06b/sensitivity.txt right after no_sdpa_fwd) was exactly that, not the box.  Every run therefore starts from a snapshot.
+st = tr.store
+SNAP = {k: getattr(st, k).clone() for k in ("master", "compute", "exp_avg", "exp_avg_sq") if getattr(st, k, None) is not None}
+SNAP_STEP = tr.step_dev.clone() if hasattr(tr, "step_dev") else None
+
+
+def restore():
+    for k, v in SNAP.items():
+        getattr(st, k).copy_(v)
+    if SNAP_STEP is not None:
+        tr.step_dev.copy_(SNAP_STEP)
+
+
 def run(name):
     cur["pred"], cur["skipped"] = V[name], 0
+    restore()
     tr._plans.clear()
     for i in range(8):                  # re-record every masked-row geometry of the four batches
         tr.step(batches[i % 4])
