@@ -250,6 +250,54 @@ def other_workloads(cfg, dev, steps=20, warm=3):
     return out
 
 
+
+def exchange_sweep(cfg, B, local, rank, world, args, host_batches, headline):
+    """N > 1: the other gradient-exchange variants, 10 timed steps each after their own warm-up, in the SAME launch as the headline
+    (a multi-GPU node is the driver's to lease: one run has to tell the whole story -- VERDICT r05 item 4).  Every variant builds
+    its own trainer and its own RCCL communicator; a variant that fails is reported with its error and does not touch the headline."""
+    import torch.distributed as dist
+    from xlxmert_amd.trainer import PretrainStep
+    out = {}
+    variants = [("allreduce_fp32", "allreduce", torch.float32, None), ("allreduce_bf16_buckets", "allreduce", torch.bfloat16, None),
+                ("rs+ag_fp32_gather", "rs+ag", torch.float32, "fp32"), ("rs+ag_bf16_gather", "rs+ag", torch.float32, "bf16")]
+    for name, coll, gdt, gather in variants:
+        if name == headline:
+            continue
+        tr = None
+        try:
+            tr = PretrainStep(cfg, B, 20, 64, dtype=torch.bfloat16, device=f"cuda:{local}", seed=9595, total_steps=1000, train_dropout=not args.no_dropout,
+                              plan=not args.eager, drop_grads=True, overlap_optimizer=not args.no_opt_overlap, collective=coll, gather=gather,
+                              grad_comm_dtype=gdt)
+            g = torch.Generator().manual_seed(9595)
+            tr.set_centroids(torch.randn(cfg.num_clusters, cfg.visual_feat_dim, generator=g).relu())
+            dev = [{k: v.to(f"cuda:{local}") for k, v in b.items()} for b in host_batches]
+            for i in range(12):
+                tr.step(dev[i % 4])
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(10):
+                tr.step(dev[i % 4])
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], device="cuda")
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            out[name] = {"ms_per_step": round(dt.item() / 10 * 1e3, 3), "examples_per_s": round(B * world * 10 / dt.item(), 1),
+                         "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3),
+                         "bytes_per_step": int(tr.store.n_used * (2 if tr.comm_buf is not None else 4)),
+                         "issued_by": "xl_comm" if tr.xl_comm is not None else "torch.distributed",
+                         "resident_inputs": True, "steps": 10, "warmup": 12}
+        except Exception as e:                      # (the headline has been measured already; say what happened and go on)
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            try:
+                if tr is not None:
+                    tr.close()
+            except Exception:
+                pass
+            del tr
+            torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +321,7 @@ def main():
                     "replicated AdamW (default) or reduce-scatter -> shard-local AdamW -> all-gather (trainer.PretrainStep collective)")
     ap.add_argument("--gather", default=None, choices=["fp32", "bf16"], help="rs+ag: what the all-gather moves -- the fp32 master slices "
                     "(default) or the bf16 compute copy + a sparse fp32 side car (half the bytes; trainer.PretrainStep gather)")
+    ap.add_argument("--no-exchange-sweep", action="store_true", help="N > 1: skip the 10-step timings of the other gradient-exchange variants")
     ap.add_argument("--resident-inputs", action="store_true", help="minibatches resident in HBM before the timed region (default: "
                     "pinned host memory, uploaded inside the timed step on a copy stream, one step ahead)")
     args = ap.parse_args()
@@ -545,7 +594,21 @@ def main():
                 "bytes_per_step": int(tr.store.n_used * (2 if tr.comm_buf is not None else 4)),
                 "issued_by": ("xl_comm_* (the library's own RCCL binding: the collectives are entries of the launch plan, XL_COMM=rccl)"
                               if tr.xl_comm is not None else "torch.distributed (host operations between the segments of the launch plan)"),
-                "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3)}
+                "exposed_comm_ms_per_step": round(tr.exposed_comm(), 3),
+                "rccl_nranks": int(tr.comm_nranks()) if hasattr(tr, "comm_nranks") else world}
+            out["config"]["gradient_exchange"]["default_rationale"] = (
+                "fp32 all-reduce = what DDP moves for the reference's fp32 parameters (lxmert_pretrain.py:694-700); predicted step time per "
+                "variant and N in DESIGN.md section 7 -- the `exchanges` key of this line holds the other variants measured in this run")
+    if world > 1 and not args.no_exchange_sweep and (not share_gpu or os.environ.get("XL_BENCH_SWEEP_SHARED") == "1"):
+        # every rank takes part (collectives); rank 0 reports
+        hn = ("rs+ag_" + ("bf16" if tr.gather_bf16 else "fp32") + "_gather") if tr.sharded else \
+             ("allreduce_bf16_buckets" if tr.comm_buf is not None else "allreduce_fp32")
+        torch.cuda.synchronize(); dist.barrier()
+        tr.close()
+        sweep = exchange_sweep(cfg, B, local, rank, world, args, host, hn)
+        if rank == 0:
+            out["exchanges"] = {"headline": hn, "headline_ms_per_step": out["ms_per_step"], **sweep}
+    if rank == 0:
         if not args.no_extra and world == 1 and not args.single_stream:
             del tr, batches
             torch.cuda.empty_cache()

@@ -416,6 +416,8 @@ int  xl_plan_destroy(int64_t plan);
 int  xl_comm_unique_id(void* id128);
 int64_t xl_comm_init(const void* id128, int rank, int nranks, void* comm_stream);
 int  xl_comm_destroy(int64_t comm);
+/* ranks of the communicator as RCCL reports them (ncclCommCount); -1: stale handle */
+int  xl_comm_nranks(int64_t comm);
 int  xl_comm_allreduce(int64_t comm, void* buf, int64_t count, int dtype, void* after_stream);
 int  xl_comm_reduce_scatter(int64_t comm, const void* send, void* recv, int64_t recv_count, int dtype, void* after_stream);
 int  xl_comm_allgather(int64_t comm, const void* send, void* recv, int64_t send_count, int dtype, void* after_stream);

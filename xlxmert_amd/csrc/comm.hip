@@ -34,6 +34,7 @@ struct Rccl {
     int (*Broadcast)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*Reduce)(const void*, void*, size_t, int, int, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(NcclComm, int*) = nullptr;          // optional (ncclCommCount)
 };
 static std::mutex g_rccl_mu;
 static Rccl g_rccl;                // function table, filled once (immutable afterwards)
@@ -52,6 +53,7 @@ static const Rccl* rccl() {
     XL_SYM(AllReduce, "ncclAllReduce") XL_SYM(ReduceScatter, "ncclReduceScatter") XL_SYM(AllGather, "ncclAllGather")
     XL_SYM(Broadcast, "ncclBroadcast") XL_SYM(Reduce, "ncclReduce") XL_SYM(GetErrorString, "ncclGetErrorString")
 #undef XL_SYM
+    *(void**)(&r.CommCount) = dlsym(h, "ncclCommCount");
     g_rccl = r;
     return &g_rccl;
 }
@@ -130,6 +132,20 @@ extern "C" int64_t xl_comm_init(const void* id128, int rank, int nranks, void* c
     std::lock_guard<std::mutex> lk(g_comm_mu);
     g_comms.push_back(c);
     return (int64_t)g_comms.size();
+}
+
+// number of ranks of the communicator AS RCCL REPORTS IT (ncclCommCount): what a scaling line should print next to its own idea of the
+// world size; -1 if the handle is stale, the value given to xl_comm_init if the library lacks the query
+extern "C" int xl_comm_nranks(int64_t comm) {
+    Comm* c = comm_of(comm);
+    if (c == nullptr) return -1;
+    const Rccl* r = rccl();
+    int n = c->nranks;
+    if (r != nullptr && r->CommCount != nullptr && c->comm != nullptr) {
+        int q = 0;
+        if (r->CommCount(c->comm, &q) == 0) n = q;
+    }
+    return n;
 }
 
 extern "C" int xl_comm_destroy(int64_t comm) {

@@ -271,6 +271,12 @@ class PretrainStep:
         if ev is not None:
             self.ops.stream_wait(ev, torch.cuda.current_stream())
 
+    def comm_nranks(self):
+        """ranks of the gradient exchange's communicator as RCCL itself reports them (xl_comm_nranks), or the process group's size"""
+        if self.xl_comm is not None:
+            return int(self.ops.lib.raw("xl_comm_nranks")(int(self.xl_comm)))
+        return self.world
+
     def close(self):
         """give back the library-side communicator (xl_comm_destroy waits for its stream first); the trainer is done"""
         if self.xl_comm is not None:
