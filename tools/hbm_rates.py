@@ -1,5 +1,5 @@
 """profiles/<tag>/pmc_fetch.txt + pmc_write.txt -> per-kernel HBM traffic per launch and achieved rate (FETCH_SIZE doubled: gfx950
-half-count of wide coalesced reads, MI355X_MICROARCH.md; WRITE_SIZE as reported; durations of the same passes).
+half-count of wide coalesced reads, MI355X_MICROARCH.md; WRITE_SIZE as reported -- FETCH x 2 / WRITE x 1 are calibrated on the adamw_kernel rows below, whose byte count is known: 16 B read and ~14.5 B written per element; durations of the same passes).
 Usage: python tools/hbm_rates.py r02e > profiles/r02e/hbm_rates.txt"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
