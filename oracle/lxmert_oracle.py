@@ -71,8 +71,43 @@ def extended_mask(attention_mask: torch.Tensor, dtype: torch.dtype) -> torch.Ten
     return (1.0 - m) * torch.finfo(dtype).min
 
 
+# --------------------------------------------------------------------------- storage-precision emulation (analysis only)
+# The HIP engine's bf16 mode stores every activation and activation gradient in bf16 (fp32 accumulation inside a contraction,
+# fp32 LayerNorm statistics, fp32 weight gradients).  EMU["mode"] = "bf16" replays that on the CPU: every value the engine
+# WRITES TO MEMORY goes through round-to-bf16 on the way forward and its gradient through round-to-bf16 on the way back;
+# contraction operands (weights too) are bf16.  "bf16_fp32res" is SURVEY section 7's precision mode: the same, except that the
+# residual stream -- the pre-LayerNorm sums and the LayerNorm outputs as RESIDUAL operands -- stays fp32 (a contraction still
+# reads its bf16 rounding).  None (default): exact fp32, the oracle proper; the golden fixtures are only ever compared in that
+# mode.  tests/test_precision_emulation_cpu.py uses the two modes to say how much of the bf16 path's gradient error an fp32
+# residual stream would remove.
+EMU = {"mode": None}
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _act(x):
+    """a value the engine stores as an activation (and whose gradient it stores as one)"""
+    return _RoundSTE.apply(x) if EMU["mode"] else x
+
+
+def _res(x):
+    """a value of the residual stream: bf16 in the engine as built, fp32 in the blueprint's precision mode"""
+    return _RoundSTE.apply(x) if EMU["mode"] == "bf16" else x
+
+
 # --------------------------------------------------------------------------- blocks
 def _linear(sd, prefix, x):
+    if EMU["mode"]:          # bf16 operands (the compute copy of the weight), fp32 accumulate, fp32 bias
+        w = sd[prefix + ".weight"]
+        return F.linear(_RoundSTE.apply(x), w + (w.to(torch.bfloat16).to(w.dtype) - w).detach(), sd[prefix + ".bias"])
     return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
 
 
@@ -92,7 +127,7 @@ def embeddings(sd, cfg, input_ids, token_type_ids, prefix="bert.embeddings", inp
     e = (word
          + F.embedding(pos_ids, sd[prefix + ".position_embeddings.weight"], padding_idx=0)
          + F.embedding(token_type_ids, sd[prefix + ".token_type_embeddings.weight"], padding_idx=0))
-    return _layer_norm(sd, prefix + ".LayerNorm", e, cfg.layer_norm_eps)
+    return _res(_layer_norm(sd, prefix + ".LayerNorm", e, cfg.layer_norm_eps))
 
 
 def attention(sd, cfg, prefix, hidden, context, mask_add=None):
@@ -101,21 +136,21 @@ def attention(sd, cfg, prefix, hidden, context, mask_add=None):
     dh = cfg.hidden_size // H
     B, nq, _ = hidden.shape
     nk = context.shape[1]
-    q = _linear(sd, prefix + ".query", hidden).view(B, nq, H, dh).transpose(1, 2)
-    k = _linear(sd, prefix + ".key", context).view(B, nk, H, dh).transpose(1, 2)
-    v = _linear(sd, prefix + ".value", context).view(B, nk, H, dh).transpose(1, 2)
+    q = _act(_linear(sd, prefix + ".query", hidden)).view(B, nq, H, dh).transpose(1, 2)
+    k = _act(_linear(sd, prefix + ".key", context)).view(B, nk, H, dh).transpose(1, 2)
+    v = _act(_linear(sd, prefix + ".value", context)).view(B, nk, H, dh).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
     if mask_add is not None:
         s = s + mask_add
-    p = F.softmax(s, dim=-1)
-    o = torch.matmul(p, v)
+    p = _act(F.softmax(s, dim=-1))                      # (the probabilities are a bf16 MFMA operand in the engine)
+    o = _act(torch.matmul(p, v))
     return o.permute(0, 2, 1, 3).contiguous().view(B, nq, H * dh)
 
 
 def attention_output(sd, cfg, prefix, x, input_tensor):
     """HF:276-280 -- LN(dense(x) + input)."""
-    return _layer_norm(sd, prefix + ".LayerNorm", _linear(sd, prefix + ".dense", x) + input_tensor,
-                       cfg.layer_norm_eps)
+    return _res(_layer_norm(sd, prefix + ".LayerNorm", _res(_linear(sd, prefix + ".dense", x) + input_tensor),
+                            cfg.layer_norm_eps))
 
 
 def self_attention_layer(sd, cfg, prefix, x, mask_add):
@@ -132,13 +167,13 @@ def cross_attention_layer(sd, cfg, prefix, x, ctx, ctx_mask_add):
 
 def intermediate(sd, cfg, prefix, x):
     """HF:325-328 -- exact-erf GELU (ACT2FN['gelu'])."""
-    return F.gelu(_linear(sd, prefix + ".dense", x))
+    return _act(F.gelu(_linear(sd, prefix + ".dense", x)))
 
 
 def output(sd, cfg, prefix, h, input_tensor):
     """HF:338-342."""
-    return _layer_norm(sd, prefix + ".LayerNorm", _linear(sd, prefix + ".dense", h) + input_tensor,
-                       cfg.layer_norm_eps)
+    return _res(_layer_norm(sd, prefix + ".LayerNorm", _res(_linear(sd, prefix + ".dense", h) + input_tensor),
+                            cfg.layer_norm_eps))
 
 
 def lxmert_layer(sd, cfg, prefix, x, mask_add=None):
@@ -165,7 +200,7 @@ def visual_feature_encoder(sd, cfg, visual_feats, visual_pos, prefix="bert.encod
                     cfg.layer_norm_eps)
     y = _layer_norm(sd, prefix + ".box_layer_norm", _linear(sd, prefix + ".box_fc", visual_pos),
                     cfg.layer_norm_eps)
-    return (x + y) / 2
+    return _res((x + y) / 2)
 
 
 def encoder(sd, cfg, lang, lang_mask_add, visual_feats, visual_pos, vis_mask_add=None,
@@ -510,16 +545,20 @@ def make_nlvr2_inputs(cfg, seed, P, L=20, grid=8):
 # --------------------------------------------------------------------------- head + losses
 def head_transform(sd, cfg, x, prefix="obj_predict_head.transform"):
     """HF:582-586 -- LN(gelu(dense(x)))."""
-    return _layer_norm(sd, prefix + ".LayerNorm", F.gelu(_linear(sd, prefix + ".dense", x)),
-                       cfg.layer_norm_eps)
+    return _act(_layer_norm(sd, prefix + ".LayerNorm", _act(F.gelu(_linear(sd, prefix + ".dense", x))),
+                            cfg.layer_norm_eps))
 
 
 def visual_obj_head(sd, cfg, vis, prefix="obj_predict_head"):
     """ref:x-lxmert/src/lxrt/modeling.py:38-53 (cluster mode) -- returns (feat, obj_logits).
     out_cluster.weight is the frozen centroid matrix (tied, ref :150-151)."""
     h = head_transform(sd, cfg, vis, prefix + ".transform")
-    feat = _linear(sd, prefix + ".linear_feat", h)
-    obj = F.linear(feat, sd[prefix + ".out_cluster.weight"], sd[prefix + ".out_cluster.bias"])
+    feat = _act(_linear(sd, prefix + ".linear_feat", h))
+    if EMU["mode"]:
+        c = sd[prefix + ".out_cluster.weight"]
+        obj = F.linear(feat, c.to(torch.bfloat16).to(c.dtype), sd[prefix + ".out_cluster.bias"])       # fp32 logits from bf16 operands
+    else:
+        obj = F.linear(feat, sd[prefix + ".out_cluster.weight"], sd[prefix + ".out_cluster.bias"])
     return feat, obj
 
 
