@@ -1074,12 +1074,22 @@ class Engine:
         self._ws_i[tag] = 0
 
     def _guard_event(self, tag):
+        """an event for a companion-stream launch (or a cross-stream combine) of lane `tag`.  Re-recording an event that an older guard
+        list still refers to would make wgrad_sync wait on the wrong point (with two events per generation the ring of
+        2 * NGEN can wrap onto a live reference when few scratch sets are used): such candidates are passed over, and the ring grows
+        when every member is referenced."""
         ring = self._guard_ring[tag]
         if len(ring) < 2 * self.NGEN:
             ring.append(self.ops.new_event())
             return ring[-1]
-        self._guard_next[tag] += 1
-        return ring[self._guard_next[tag] % len(ring)]
+        live = {e for evs in self._gen_guard[tag].values() for e in evs}          # (events are integer handles)
+        for _ in range(len(ring)):
+            self._guard_next[tag] += 1
+            ev = ring[self._guard_next[tag] % len(ring)]
+            if ev not in live:
+                return ev
+        ring.append(self.ops.new_event())
+        return ring[-1]
 
     def wgrad_flush(self, pair=False, force=False):
         """queue the registered weight gradients as ONE grouped launch on the companion stream of the current stream
