@@ -605,7 +605,26 @@ def main():
              ("allreduce_bf16_buckets" if tr.comm_buf is not None else "allreduce_fp32")
         torch.cuda.synchronize(); dist.barrier()
         tr.close()
+        # The headline is measured; a sweep that hangs (a variant's collective waiting for a rank that failed) must not lose it:
+        # past the deadline rank 0 prints the line without the sweep and every rank leaves.
+        import threading
+        deadline = float(os.environ.get("XL_BENCH_SWEEP_TIMEOUT", "420"))
+        swept, once = threading.Event(), threading.Lock()
+
+        def give_up():
+            if swept.wait(deadline) or not once.acquire(blocking=False):
+                return
+            if rank == 0:
+                late = dict(out)
+                late["exchanges"] = {"headline": hn, "headline_ms_per_step": out["ms_per_step"],
+                                     "error": f"sweep not finished after {deadline:.0f} s; headline unaffected"}
+                os.write(result_fd, (json.dumps(late) + "\n").encode())
+            os._exit(0)
+        threading.Thread(target=give_up, daemon=True).start()
         sweep = exchange_sweep(cfg, B, local, rank, world, args, host, hn)
+        swept.set()
+        if not once.acquire(blocking=False):
+            time.sleep(3600)              # (the guard is printing and leaving)
         if rank == 0:
             out["exchanges"] = {"headline": hn, "headline_ms_per_step": out["ms_per_step"], **sweep}
     if rank == 0:

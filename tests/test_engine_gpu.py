@@ -1220,7 +1220,8 @@ def test_benchmark_geometry_bs256_step_matches_oracle():
     assert worst_n[1] < 6e-2 and worst_t[1] < 0.154 and med < 5e-2, (worst_n, worst_t, med)
 
 
-def test_bench_two_ranks_sharing_the_gpu_end_to_end(tmp_path):
+@pytest.mark.parametrize("sweep_deadline", [None, "0.2"], ids=["sweep", "sweep_past_its_deadline"])
+def test_bench_two_ranks_sharing_the_gpu_end_to_end(tmp_path, sweep_deadline):
     """`python bench.py --gpus 2` started as a plain script (no WORLD_SIZE: it launches its own two ranks, as the reference's
     entry point does with mp.spawn, ref lxmert_pretrain.py:865) with both ranks on this GPU and gloo carrying the exchange: ONE
     JSON line, the exchange filled in, the step replayed from a SEGMENTED launch plan (collectives between the segments)."""
@@ -1229,6 +1230,8 @@ def test_bench_two_ranks_sharing_the_gpu_end_to_end(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, XL_BENCH_SHARE_GPU="1", XL_BENCH_FAULT_TIMEOUT="380", XL_BENCH_SWEEP_SHARED="1")
+    if sweep_deadline is not None:                  # the sweep cannot finish in time: the headline line must still come out, once
+        env["XL_BENCH_SWEEP_TIMEOUT"] = sweep_deadline
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     # (output into files, not pipes: a helper process of the launcher that outlives it would keep a pipe open and the read
@@ -1250,6 +1253,9 @@ def test_bench_two_ranks_sharing_the_gpu_end_to_end(tmp_path):
     # the other exchange variants, each with a trainer and an exchange of its own, measured after the headline in the same run
     sw = out["exchanges"]
     assert sw["headline"] == "allreduce_fp32" and ex["rccl_nranks"] == 2
+    if sweep_deadline is not None:
+        assert "not finished" in sw["error"] and sw["headline_ms_per_step"] == out["ms_per_step"]
+        return
     for name in ("allreduce_bf16_buckets", "rs+ag_fp32_gather", "rs+ag_bf16_gather"):
         assert "error" not in sw[name], (name, sw[name])
         assert sw[name]["ms_per_step"] > 0 and sw[name]["exposed_comm_ms_per_step"] >= 0.0
