@@ -19,6 +19,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the hosts' driver shares device memory between processes through dmabuf only: without this RCCL's IPC set-up fails with
+# `hipIpcGetMemHandle: invalid argument` (read when the HSA runtime starts, so before torch is imported; launched ranks inherit it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist

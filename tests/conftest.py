@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# (multi-process GPU tests: dmabuf IPC, see bench.py; read when the HSA runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__file__))):
     if p not in sys.path:
