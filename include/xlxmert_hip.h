@@ -271,18 +271,26 @@ int xl_sampler_ar_update(const float* prob, const int* pred_ids, void* visited, 
  * exact).  nq / nk stay the per-example CAPACITY (<= 64; lse and the dropout counters keep their [B, H, n] indexing); a packed
  * key side needs no key_mask.  Rows [off[B], *_rows_padded) -- the tail that rounds the packed row count up to the GEMM row
  * tile -- are written as ZEROS (o; dq on the query side; dk, dv on the key side), so the contractions over all rows that
- * follow (out-projection, weight gradients) read zeros there. */
+ * follow (out-projection, weight gradients) read zeros there.
+ * keep_bits (optional; NULL = the backward evaluates the mask hash again): xl_sdpa_keep_bits_bytes(...) bytes, 16-byte aligned,
+ * in which the forward leaves its dropout decisions (one bit per (query, key) of every (b, h) problem, in the kernel's register
+ * order) for xl_sdpa_bwd of the same call geometry: what autograd keeps as the dropout mask of HF:258, at 1/16 of its bytes.
+ * Same mask, same results bit for bit; the backward's two passes then test a bit instead of hashing (the hash was a quarter of
+ * its instructions).  Only on the on-chip bf16 kernels: xl_sdpa_keep_bits_bytes returns 0 for any other geometry, and passing
+ * a buffer where the kernels would not use it (long sequences, fp32, operands that are not 16-byte aligned) is XL_ERR_BAD_ARG. */
+int64_t xl_sdpa_keep_bits_bytes(int B, int H, int nq, int nk, int dh, int dtype);
 int xl_sdpa_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
                 void* o, float* lse, int B, int H, int nq, int nk, int dh,
                 int ldq, int ldk, int ldv, int ldo, float scale,
                 float p_drop, uint64_t seed, const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded,
-                int dtype, void* stream);
+                uint32_t* keep_bits, int dtype, void* stream);
 int xl_sdpa_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
                 const void* dout, const float* lse,
                 void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
                 int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
                 float p_drop, uint64_t seed, float* bias_grad, float* workspace,
-                const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded, int dtype, void* stream);
+                const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded,
+                const uint32_t* keep_bits, int dtype, void* stream);
 /* Attention probabilities of one attention block, for LxmertModel.forward(output_attentions=True) (HF:691-704, 238-266: the
  * softmax AFTER its dropout): probs fp32 [B, H, nq, nk] (dense, also for packed rows: queries / keys beyond an example's length
  * and masked keys give zeros), recomputed from q, k and the lse that xl_sdpa_fwd saved -- the fused forward never stores them. */

@@ -44,6 +44,14 @@ def keep_scale(seed, row, col, p_drop):
     return torch.from_numpy(keep)
 
 
+def dropout_keep_matrix(seed, n_problems, nq_cap, n_rows, n_cols, p_drop):
+    """bool [n_problems, n_rows, n_cols]: the attention kernels' keep decision for (row = problem * nq_cap + q, column = key) --
+    also for the q >= nq_cap / key >= nk positions that a 32-wide fragment carries along (the kernels hash them like any other)"""
+    row = (torch.arange(n_problems).view(-1, 1, 1) * nq_cap + torch.arange(n_rows).view(1, -1, 1))
+    col = torch.arange(n_cols).view(1, 1, -1)
+    return keep_scale(seed, row, col, p_drop) > 0
+
+
 class FakeOps:
     def __init__(self, dtype):
         self.dtype = dtype
@@ -312,8 +320,11 @@ class FakeOps:
         if pad > off[B]:
             mat[off[B]:pad].zero_()
 
+    def sdpa_keep_bits_bytes(self, B, H, nq, nk, dh):
+        return 0                        # (the host restatement evaluates the mask hash wherever it needs the mask)
+
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0,
-                 q_off=None, k_off=None, q_pad=0, k_pad=0):
+                 q_off=None, k_off=None, q_pad=0, k_pad=0, keep_bits=None):
         (Q, qv), (K_, kv), (V_, _) = (self._load(t, B, n, H, dh, ld, off)
                                       for t, n, ld, off in ((q, nq, ldq, q_off), (k, nk, ldk, k_off), (v, nk, ldv, k_off)))
         s = Q @ K_.transpose(-1, -2) * scale
@@ -338,7 +349,7 @@ class FakeOps:
         probs.view(B, H, nq, nk).copy_(p * self._pmask(B, H, nq, nk, p_drop, self._seed(seed)))
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
-                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None, q_off=None, k_off=None, q_pad=0, k_pad=0):
+                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None, q_off=None, k_off=None, q_pad=0, k_pad=0, keep_bits=None):
         (Q, qv), (K_, kv), (V_, _), (dO, _) = (self._load(t, B, n, H, dh, ld, off) for t, n, ld, off in
                                                ((q, nq, ldq, q_off), (k, nk, ldk, k_off), (v, nk, ldv, k_off), (dout, nq, ldo, q_off)))
         s = Q @ K_.transpose(-1, -2) * scale

@@ -36,7 +36,16 @@ def test_argument_validation_without_gpu():
     with pytest.raises(XlError, match="bad shape"):
         lib.call("xl_gemm", None, None, None, None, None, None, 0, 4, 4, 4, 4, 4, 0, 0, 1, 1, 1, 1, 0, 1.0, 0, 0.0, 0, None, None, None)
     with pytest.raises(XlError, match="nq,nk"):
-        lib.call("xl_sdpa_fwd", 16, 16, 16, None, 16, 16, 1, 1, 513, 8, 64, 64, 64, 64, 64, 1.0, 0.0, 0, None, None, 0, 0, 1, None)   # (<= 512: long kernels)
+        lib.call("xl_sdpa_fwd", 16, 16, 16, None, 16, 16, 1, 1, 513, 8, 64, 64, 64, 64, 64, 1.0, 0.0, 0, None, None, 0, 0, None, 1, None)   # (<= 512: long kernels)
+    # saved dropout decisions only exist on the on-chip bf16 kernels: 0 bytes and a refusal everywhere else
+    kb = lib.raw("xl_sdpa_keep_bits_bytes")
+    assert kb(256, 12, 64, 64, 64, 1) == 256 * 12 * 2 * 2 * 32 * 4 and kb(256, 12, 20, 64, 64, 1) == 256 * 12 * 1 * 2 * 32 * 4
+    assert kb(256, 12, 65, 64, 64, 1) == 0 and kb(256, 12, 64, 64, 64, 0) == 0 and kb(256, 12, 64, 64, 48, 1) == 0
+    with pytest.raises(XlError, match="keep_bits"):
+        lib.call("xl_sdpa_fwd", 16, 16, 16, None, 16, 16, 1, 1, 64, 64, 64, 64, 64, 64, 64, 1.0, 0.1, 0, None, None, 0, 0, 16, 0, None)     # fp32
+    with pytest.raises(XlError, match="keep_bits"):
+        lib.call("xl_sdpa_bwd", 16, 16, 16, None, 16, 16, 16, 16, 16, 1, 1, 100, 64, 64, 64, 64, 64, 64, 64, 64, 64, 1.0, 0.1, 0, None, None,
+                 None, None, 0, 0, 16, 1, None)                                                                                        # long
 
 
 def test_no_cpu_fallback():

@@ -1228,6 +1228,88 @@ def test_sdpa_dropout_fwd_bwd(nq, nk, dh, dtype):
     close(gbg.cpu(), cbg, torch.float32, "sdpa dropout bias grads", f32_tol=1e-4 if dtype == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("tr", [1, 0], ids=["tr_read", "plain_read"])
+@pytest.mark.parametrize("nq,nk,dh,packed,masked", [(64, 64, 64, False, False), (20, 20, 64, True, False), (20, 64, 64, True, False),
+                                                     (64, 20, 64, False, True), (33, 64, 64, False, True), (64, 40, 32, False, False),
+                                                     (8, 16, 16, False, True), (17, 50, 64, True, True)])
+def test_sdpa_saved_keep_bits_give_the_same_backward(nq, nk, dh, packed, masked, tr):
+    """xl_sdpa_fwd(keep_bits=) leaves its dropout decisions behind and xl_sdpa_bwd(keep_bits=) tests a bit where it used to evaluate the
+    mask hash again: the SAME mask, so dq / dk / dv must equal the hashing backward bit for bit (the fused bias gradients to fp32
+    rounding), on every fragment geometry of the on-chip kernels, with key masks, ragged packed rows and both LDS read modes; the forward output
+    must not depend on whether the bits are saved; the bits themselves must be the host restatement's keep decisions; buffers the
+    kernels cannot use are refused."""
+    from fake_ops import dropout_keep_matrix
+    g = torch.Generator().manual_seed(nq * 7 + nk)
+    B, H = 5, 3
+    d = H * dh
+    ld = 3 * d
+    pd, seed, scale = 0.1, 991, 1.0 / math.sqrt(dh)
+    ops = hip(torch.bfloat16)
+    ops.set_lds_transpose_read(tr)
+    try:
+        if packed:
+            lens = torch.randint(1, nq + 1, (B,), generator=g)
+            lens[0], lens[1] = 1, nq
+            qoff = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(torch.int32)
+            q_rows = (int(qoff[-1]) + 31) // 32 * 32 + 32
+            kw = dict(q_off=qoff.cuda(), q_pad=q_rows)
+        else:
+            q_rows, kw = B * nq, {}
+        qb = rnd(g, q_rows, ld, dtype=torch.bfloat16).cuda()
+        kb = rnd(g, B * nk, ld, dtype=torch.bfloat16).cuda()
+        km = None
+        if masked:
+            km = (torch.rand(B, nk, generator=g) > 0.3).to(torch.uint8)
+            km[:, 0] = 1
+            km = km.cuda()
+        nbytes = ops.sdpa_keep_bits_bytes(B, H, nq, nk, dh)
+        assert nbytes == B * H * ((nq + 31) // 32) * ((nk + 31) // 32) * 32 * 4
+        bits = torch.full((nbytes // 4,), -1, dtype=torch.int32, device="cuda")
+        o0, o1 = (torch.zeros(q_rows, d, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+        l0, l1 = (torch.zeros(B * H * nq, device="cuda") for _ in range(2))
+        ops.sdpa_fwd(qb, kb[:, d:], kb[:, 2 * d:], km, o0, l0, B, H, nq, nk, dh, ld, ld, ld, d, scale, pd, seed, **kw)
+        ops.sdpa_fwd(qb, kb[:, d:], kb[:, 2 * d:], km, o1, l1, B, H, nq, nk, dh, ld, ld, ld, d, scale, pd, seed, keep_bits=bits, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+        # the saved words against the host restatement of the mask: dword (i*16 + r)*2 + h of fragment (bh, j), bit t
+        #   = keep(row (bh)*nq + j*32 + t, key i*32 + (r&3) + 8*(r>>2) + 4*h)
+        nqf, nkf = (nq + 31) // 32, (nk + 31) // 32
+        keep = dropout_keep_matrix(seed, B * H, nq, nqf * 32, nkf * 32, pd)            # bool [B*H, nqf*32, nkf*32] (rows counted with stride nq)
+        w = bits.cpu().view(B * H, nqf, nkf, 16, 2).to(torch.int64) & 0xFFFFFFFF
+        for i in range(nkf):
+            for r in range(16):
+                for h in range(2):
+                    key = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h
+                    for j in range(nqf):
+                        want = (keep[:, j * 32:(j + 1) * 32, key].to(torch.int64) << torch.arange(32)).sum(1)
+                        assert torch.equal(w[:, j, i, r, h], want), (i, r, h, j)
+        dout = rnd(g, q_rows, d, dtype=torch.bfloat16).cuda()
+        outs = []
+        for use_bits in (False, True):
+            dq = torch.full((q_rows, ld), 3.0, dtype=torch.bfloat16, device="cuda")
+            dk = torch.full((B * nk, ld), 3.0, dtype=torch.bfloat16, device="cuda")
+            bg, ws = torch.zeros(3 * d, device="cuda"), torch.zeros(ops.workspace_floats(d), device="cuda")
+            ops.sdpa_bwd(qb, kb[:, d:], kb[:, 2 * d:], km, dout, l0, dq, dk[:, d:], dk[:, 2 * d:], B, H, nq, nk, dh, ld, ld, ld, d, ld, ld, ld,
+                         scale, pd, seed, bias_grad=bg, ws=ws, keep_bits=bits if use_bits else None, **kw)
+            ops.flush_reductions()
+            torch.cuda.synchronize()
+            outs.append((dq.cpu(), dk.cpu(), bg.cpu()))
+        for a, b_, nm in zip(outs[0][:2], outs[1][:2], ("dq", "dk | dv")):
+            assert torch.equal(a, b_), (nm, (a.float() - b_.float()).abs().max().item())
+        # (the per-token sums behind the fused bias gradients are fp32 accumulations that the two instantiations contract into
+        #  fused multiply-adds differently: equal to rounding, not bit for bit)
+        assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-5 * outs[0][2].abs().max().item()
+        assert outs[0][0][:, :d].float().abs().max() > 0
+        # refused where the kernels would not use it: fp32, long sequences
+        f32 = hip(torch.float32)
+        assert f32.sdpa_keep_bits_bytes(B, H, nq, nk, dh) == 0 and ops.sdpa_keep_bits_bytes(B, H, 65, nk, dh) == 0
+        with pytest.raises(Exception, match="keep_bits"):
+            f32.sdpa_fwd(qb.float(), kb.float()[:, d:], kb.float()[:, 2 * d:], km, o0.float(), l0, B, H, nq, nk, dh, ld, ld, ld, d, scale, pd, seed,
+                         keep_bits=bits, **kw)
+    finally:
+        ops.set_lds_transpose_read(1)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("nq,nk,dh,packed,masked", [(100, 100, 64, True, False), (65, 64, 64, False, True), (64, 130, 16, False, True),
                                                      (200, 20, 64, True, False), (512, 70, 32, False, False), (512, 512, 64, True, False),

@@ -5,7 +5,8 @@ drift by up to 1 ms within minutes, so numbers from different gpurun calls -- or
 
     python tools/abab.py --b relay=1                      # A = library defaults, B = xl_set_gemm_relay(1)
     python tools/abab.py --a tile192=0 --b tile192=1 --alternations 6 --steps 40
-Setter names: HipOps.set_gemm_<name> (relay, relay_wgs, q, duo, persistent, tile192, pingpong, split_epi, pair, wgrad_slabs), or env:NAME=value
+Setter names: HipOps.set_gemm_<name> (relay, relay_wgs, q, duo, persistent, tile192, pingpong, split_epi, pair, wgrad_slabs), engine
+attributes (keep_bits: the attention forward saves its dropout decisions for the backward), or env:NAME=value
 for switches the library reads from the environment at first use (only effective for contexts created afterwards: not supported here).
 """
 import argparse
@@ -50,14 +51,18 @@ def parse(spec):
 
 A, Bs = parse(args.a), parse(args.b)
 names = sorted({k for k, _ in A} | {k for k, _ in Bs})
+ENGINE_ATTRS = {"keep_bits": ("use_keep_bits", True)}       # engine attributes read at every launch (name -> (attribute, default))
 DEFAULTS = {"relay": 0, "relay_wgs": 256, "q": 0, "duo": 1, "persistent": 0, "tile192": 0, "pingpong": 1, "split_epi": 0, "pair": 1, "wgrad_slabs": 0}
 
 
 def apply(arm):
-    vals = {k: DEFAULTS[k] for k in names}
+    vals = {k: (ENGINE_ATTRS[k][1] if k in ENGINE_ATTRS else DEFAULTS[k]) for k in names}
     vals.update(dict(arm))
     for k, v in vals.items():
-        getattr(tr.ops, "set_gemm_" + k)(v)
+        if k in ENGINE_ATTRS:
+            setattr(tr.engine, ENGINE_ATTRS[k][0], bool(v))
+        else:
+            getattr(tr.ops, "set_gemm_" + k)(v)
     tr._plans.clear()                   # the kernel choice is frozen in a recorded plan
 
 

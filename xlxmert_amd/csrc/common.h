@@ -237,10 +237,13 @@ __device__ __forceinline__ uint32_t dropout_draw16(uint32_t seedmix, uint32_t ro
     h ^= h >> 16;
     return (col & 1u) ? (h >> 16) : (h & 0xffffu);
 }
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t row, uint32_t col, float p_drop) {
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f);
+    return dropout_draw16(dropout_seed_mix(seed), row, col) >= thr;
+}
 // returns 1/(1-p) if kept, 0 if dropped
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t row, uint32_t col, float p_drop, float inv_keep) {
-    const uint32_t thr = (uint32_t)(p_drop * 65536.0f);
-    return dropout_draw16(dropout_seed_mix(seed), row, col) >= thr ? inv_keep : 0.0f;
+    return dropout_keep(seed, row, col, p_drop) ? inv_keep : 0.0f;
 }
 
 // Step seed in DEVICE memory (xl_set_step_seed_ptr): every dropout site's seed is  site_seed + 1000003 * *step  -- the site part

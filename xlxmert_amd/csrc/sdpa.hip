@@ -44,6 +44,19 @@ __device__ __forceinline__ void zero_pad_rows(const int* off, int pad, int b, in
     }
 }
 
+// Saved dropout decisions of the on-chip MFMA kernels (nq, nk <= 64): per (batch, head) problem and 32-query fragment j,
+// NKF * 32 dwords in the forward kernel's REGISTER order -- dword (i*16 + r)*2 + h holds, bit t = query j*32 + t, the keep
+// decisions for key i*32 + acc_row(r, h).  Dwords 2n, 2n+1 together are the 64-lane mask of accumulator register n of a wave
+// whose lanes own the queries (forward, backward phase 1); a lane that owns a key (backward phase 2) finds its word at dword().
+struct KeepBits {
+    __host__ __device__ static constexpr size_t word0(int bh, int nqf, int nkf, int j) { return ((size_t)bh * nqf + j) * (size_t)(nkf * 32); }
+    // key (0..31 inside key fragment i) -> dword index inside the fragment's 32:  key = (r&3) + 8*(r>>2) + 4*h
+    __device__ static __forceinline__ int dword(int i, int key31) {
+        const int h = (key31 >> 2) & 1, r = (key31 & 3) + 4 * (key31 >> 3);
+        return (i * 16 + r) * 2 + h;
+    }
+};
+
 // ================================================================== generic (fp32 math)
 template <typename T>
 __global__ __launch_bounds__(64) void sdpa_fwd_generic(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
@@ -464,18 +477,32 @@ __device__ __forceinline__ void store_rows(const f32x16_t& a, bf16_t* __restrict
     }
 }
 
+// x in the lanes whose bit of the wave-uniform lane mask m is set: ONE v_cndmask with the SGPR pair as its condition
+// (llvm.amdgcn.inverse.ballot: the compiler sees an ordinary select and keeps its hazard bookkeeping -- as inline assembly the
+// select consumed v_exp_f32 results one instruction after they were issued, inside the transcendental forwarding hazard the
+// compiler pads for its own instructions only: wrong values in a third of the attention tests; as C++ on the lane index --
+// (m >> lane) & 1 ? x : 0 -- it is a 64-bit shift, an and, a compare and the select, per element)
+__device__ __forceinline__ float lanes_of(float x, uint64_t m, float otherwise = 0.f) {
+    return __builtin_amdgcn_inverse_ballot_w64(m) ? x : otherwise;
+}
+// the 64-lane mask "low half-wave iff lo, high half-wave iff hi" (scalar arithmetic when lo / hi are wave-uniform)
+__device__ __forceinline__ uint64_t half_masks(bool lo, bool hi) {
+    return (lo ? 0x00000000FFFFFFFFull : 0ull) | (hi ? 0xFFFFFFFF00000000ull : 0ull);
+}
+
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     bf16_t* __restrict__ o, float* __restrict__ lse, int H, int nq, int nk,
                                                     int ldq, int ldk, int ldv, int ldo, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed,
-                                                    const uint64_t* __restrict__ step_seed, VarLen vl) {
+                                                    const uint64_t* __restrict__ step_seed, VarLen vl,
+                                                    uint32_t* __restrict__ keep_bits) {
     if (DROP) seed = with_step_seed(seed, step_seed);
     // one wave per 32-query fragment (NQF waves share the staged V tile of the (batch, head) problem)
     __shared__ __attribute__((aligned(16))) uint8_t vt[NKF * 32 * Tile<DH>::PITCH];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, j = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l31 = lane & 31;
     const int nq_cap = nq, nk_cap = nk;
     const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
     nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
@@ -506,16 +533,17 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
             for (int i = 0; i < NKF; ++i) st[i] = mfma32(fk[i][s], fq[s], st[i]);
     }
     sv.store(vt, tid);                    // (issued before the Q / K fragment loads above: one wait covers them all)
-    const uint64_t kbits = key_bits(key_mask, b * nk_cap, nk_cap, lane);
+    // the keys that attend (mask and length) as one wave-uniform word: per accumulator register the "attends" decision is a lane
+    // mask of two half-waves, built by scalar instructions and applied by one v_cndmask (cf. the backward kernel)
+    const uint64_t kbits = key_bits(key_mask, b * nk_cap, nk_cap, lane) & (nk >= 64 ? ~0ull : (1ull << nk) - 1ull);
     const int qi = j * 32 + l31;
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NKF; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = i * 32 + acc_row(r, hi);
-            const bool ok = key < nk && ((kbits >> key) & 1ull) != 0;
-            const float sc = ok ? st[i][r] * scale : -INFINITY;
+            const int key0 = i * 32 + acc_row(r, 0);                               // the low half-wave's key; the high one's is key0 + 4
+            const float sc = lanes_of(st[i][r] * scale, half_masks((kbits >> key0) & 1ull, (kbits >> (key0 + 4)) & 1ull), -INFINITY);
             st[i][r] = sc;
             mx = fmaxf(mx, sc);
         }
@@ -529,14 +557,31 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
     if (hi == 0 && qi < nq) lse[(size_t)bh * nq_cap + qi] = mx + __logf(sum);
+    // The keep decisions of the wave's 32 x (NKF * 32) elements leave the kernel as well (keep_bits, see KeepBits): the
+    // comparison of register (i, r) over the 64 lanes IS a 64-bit lane mask in a scalar register pair -- its two halves are the
+    // 32-query keep words of keys i*32 + acc_row(r, 0) and i*32 + acc_row(r, 1) -- so lane (i*16 + r)*2 + h of `kw` receives
+    // half h (v_writelane) and the wave stores NKF * 32 dwords once.  The backward then spends one v_cndmask per element (the
+    // same scalar pair as the condition) or a bit test instead of evaluating the counter hash again, twice: the hash was a
+    // quarter of its instruction stream (quarter-rate integer multiplies), and the mask cannot differ from the forward's.
+    uint32_t kw = 0;
 #pragma unroll
     for (int i = 0; i < NKF; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float pv = st[i][r] * inv;
-            if (DROP) pv *= dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)(i * 32 + acc_row(r, hi)), p_drop, inv_keep);
+            if (DROP) {
+                const bool keep = dropout_keep(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)(i * 32 + acc_row(r, hi)), p_drop);
+                const uint64_t m = __ballot(keep);
+                // (no v_writelane builtin in this compiler.  The ballot is a VALU write of an SGPR pair, and gfx950 wants two wait
+                //  states before a VALU instruction reads such a register -- the compiler pads its own instructions, not the
+                //  inside of an asm statement: hence the s_nop)
+                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                    : "+v"(kw) : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "n"((i * 16 + r) * 2), "n"((i * 16 + r) * 2 + 1));
+                pv = keep ? pv * inv_keep : 0.f;
+            }
             st[i][r] = pv;
         }
+    if (DROP && keep_bits != nullptr && lane < NKF * 32) keep_bits[KeepBits::word0(bh, NQF, NKF, j) + lane] = kw;
     __syncthreads();                      // V tile staged by all waves
     // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
     constexpr int ND = (DH + 31) / 32;
@@ -551,7 +596,7 @@ __global__ __launch_bounds__(NQF * 64) void sdpa_fwd_mfma(const bf16_t* __restri
     }
 }
 
-template <int DH, int NQF, int NKF, bool TR, bool DROP, int NW>
+template <int DH, int NQF, int NKF, bool TR, bool DROP, int NW, bool BITS>
 __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                     const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -559,8 +604,10 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
                                                     int H, int nq, int nk, int ldq, int ldk, int ldv, int ldo,
                                                     int lddq, int lddk, int lddv, float scale,
                                                     float p_drop, float inv_keep, uint64_t seed, float* __restrict__ cs_ws,
-                                                    const uint64_t* __restrict__ step_seed, VarLen vl) {
-    if (DROP) seed = with_step_seed(seed, step_seed);
+                                                    const uint64_t* __restrict__ step_seed, VarLen vl,
+                                                    const uint32_t* __restrict__ keep_bits) {
+    static_assert(!BITS || DROP, "saved keep decisions only exist with dropout");
+    if (DROP && !BITS) seed = with_step_seed(seed, step_seed);
     // K, Q, dO are needed both as row fragments and transposed: staged in LDS (unpadded swizzled tiles for DH = 64).  V is only
     // ever read as row fragments -- its own row by the lane that owns the key (phase 2), the same rows as the A operand of
     // dP^T = V dO^T (phase 1) -- so every wave keeps the V fragments in registers, straight from global: three tiles instead
@@ -581,7 +628,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     // NW waves share the staged tiles of one (batch, head) problem; the 32-query fragments of phase 1 and the 32-key
     // fragments of phase 2 are independent tasks dealt round-robin to the waves.
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l31 = lane & 31;
     const int nq_cap = nq, nk_cap = nk;
     const int q0 = vl.row0_q(b, nq), k0 = vl.row0_k(b, nk);
     nq = vl.len_q(b, nq); nk = vl.len_k(b, nk);
@@ -608,7 +655,11 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
         sd.store(tdo, tid);
     }
     if (tid < MAXN) s_lse[tid] = tid < nq ? lse[(size_t)bh * nq_cap + tid] : 0.f;
-    const uint64_t kbits = key_bits(key_mask, b * nk_cap, nk_cap, lane);
+    // Which elements exist at all is wave-uniform per accumulator register and half-wave -- the keys that attend (mask and
+    // length) as a 64-bit word, the queries below nq likewise -- so the "exists" decision of register (i, r) is a LANE MASK
+    // put together by scalar instructions and applied by one v_cndmask (lanes_of), not five vector instructions per element.
+    const uint64_t kbits = key_bits(key_mask, b * nk_cap, nk_cap, lane) & (nk >= 64 ? ~0ull : (1ull << nk) - 1ull);
+    const uint64_t qbits = nq >= 64 ? ~0ull : (1ull << nq) - 1ull;
     constexpr int ND = (DH + 31) / 32;
     __syncthreads();
 
@@ -631,17 +682,22 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
         const int qi = j * 32 + l31;
         const float l = s_lse[qi];
         float delta = 0.f, psum = 0.f;
+        const uint32_t qw = (uint32_t)(qbits >> (j * 32));                        // the fragment's queries that exist, bit = lane & 31
+        const uint64_t qmask = (uint64_t)qw | ((uint64_t)qw << 32);
+        // (BITS) the forward's keep decisions of this fragment: dwords 2n, 2n+1 = the lane mask of register n = i*16 + r
+        const uint64_t* __restrict__ kmask = reinterpret_cast<const uint64_t*>(keep_bits + KeepBits::word0(bh, NQF, NKF, j));
 #pragma unroll
         for (int i = 0; i < NKF; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = i * 32 + acc_row(r, hi);
-                const bool ok = key < nk && ((kbits >> key) & 1ull) != 0;
-                const float e = __expf(st[i][r] * scale - l);
-                const float pv = (ok && qi < nq) ? e : 0.f;
+                const int key0 = i * 32 + acc_row(r, 0);                           // the low half-wave's key; the high one's is key0 + 4
+                const uint64_t ok = half_masks((kbits >> key0) & 1ull, (kbits >> (key0 + 4)) & 1ull) & qmask;
+                const float pv = lanes_of(__expf(st[i][r] * scale - l), ok);
                 float dp = dpt[i][r];
                 if (DROP) {
-                    const float msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)key, p_drop, inv_keep);
+                    float msk;
+                    if (BITS) msk = lanes_of(inv_keep, kmask[i * 16 + r]);
+                    else msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)(key0 + 4 * hi), p_drop, inv_keep);
                     dp *= msk;
                     psum += pv * msk;
                 } else psum += pv;
@@ -696,16 +752,26 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void sdpa_bwd_mfma(const 
             }
         }
         const int key = i * 32 + l31;
-        const bool kok = key < nk && ((kbits >> key) & 1ull) != 0;
+        const uint32_t kw32 = (uint32_t)(kbits >> (i * 32));                        // the fragment's keys that attend, bit = lane & 31
+        const uint64_t kmask2 = (uint64_t)kw32 | ((uint64_t)kw32 << 32);
+        // (BITS) this lane's key: its keep word per query fragment (bit t = query j*32 + t), pre-shifted by the half-wave's 4
+        uint32_t kwd[NQF];
+#pragma unroll
+        for (int j = 0; j < NQF; ++j)
+            kwd[j] = BITS ? keep_bits[KeepBits::word0(bh, NQF, NKF, j) + KeepBits::dword(i, l31)] >> (4 * hi) : 0u;
 #pragma unroll
         for (int j = 0; j < NQF; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qi = j * 32 + acc_row(r, hi);
-                const float e = __expf(s2[j][r] * scale - s_lse[qi]);
-                const float pv = (kok && qi < nq) ? e : 0.f;
+                const int qi0 = j * 32 + acc_row(r, 0);                             // the low half-wave's query; the high one's is qi0 + 4
+                const int qi = qi0 + 4 * hi;
+                const uint64_t ok = half_masks((qbits >> qi0) & 1ull, (qbits >> (qi0 + 4)) & 1ull) & kmask2;
+                const float pv = lanes_of(__expf(s2[j][r] * scale - s_lse[qi]), ok);
                 float msk = 1.f;
-                if (DROP) msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)key, p_drop, inv_keep);
+                if (DROP) {
+                    if (BITS) msk = ((kwd[j] >> acc_row(r, 0)) & 1u) ? inv_keep : 0.f;
+                    else msk = dropout_scale(seed, (uint32_t)(bh * nq_cap + qi), (uint32_t)key, p_drop, inv_keep);
+                }
                 const float dp = dp2[j][r] * msk;
                 dp2[j][r] = pv * (dp - s_delta[qi]) * scale;      // dS[q][key]
                 s2[j][r] = pv * msk;                              // P~[q][key]
@@ -1054,21 +1120,22 @@ struct SdpaArgs {
     float scale, p_drop, inv_keep; uint64_t seed;
     float* cs_ws;
     VarLen vl;
+    uint32_t* keep_bits;
 };
 
 template <int DH, int NQF, int NKF, bool TR, bool DROP>
 static void launch_fwd2(const SdpaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((sdpa_fwd_mfma<DH, NQF, NKF, TR, DROP>), dim3(a.B * a.H), dim3(NQF * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (bf16_t*)a.o, a.lse, a.H, a.nq, a.nk, a.ldq, a.ldk,
-                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed, ctx().step_seed, a.vl);
+                       a.ldv, a.ldo, a.scale, a.p_drop, a.inv_keep, a.seed, ctx().step_seed, a.vl, a.keep_bits);
 }
-template <int DH, int NQF, int NKF, bool TR, bool DROP>
+template <int DH, int NQF, int NKF, bool TR, bool DROP, bool BITS = false>
 static void launch_bwd2(const SdpaArgs& a, hipStream_t st) {
     constexpr int NW = NQF > NKF ? NQF : NKF;
-    hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP, NW>), dim3(a.B * a.H), dim3(NW * 64), 0, st, (const bf16_t*)a.q,
+    hipLaunchKernelGGL((sdpa_bwd_mfma<DH, NQF, NKF, TR, DROP, NW, BITS>), dim3(a.B * a.H), dim3(NW * 64), 0, st, (const bf16_t*)a.q,
                        (const bf16_t*)a.k, (const bf16_t*)a.v, a.key_mask, (const bf16_t*)a.dout, a.lse, (bf16_t*)a.dq,
                        (bf16_t*)a.dk, (bf16_t*)a.dv, a.H, a.nq, a.nk, a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddk, a.lddv,
-                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws, ctx().step_seed, a.vl);
+                       a.scale, a.p_drop, a.inv_keep, a.seed, a.cs_ws, ctx().step_seed, a.vl, (const uint32_t*)a.keep_bits);
 }
 template <int DH, int NQF, int NKF>
 static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
@@ -1078,9 +1145,16 @@ static void launch_fwd(const SdpaArgs& a, hipStream_t st) {
 }
 template <int DH, int NQF, int NKF>
 static void launch_bwd(const SdpaArgs& a, hipStream_t st) {
-    const bool drop = a.p_drop > 0.f;
-    if (ctx().use_tr_read) { if (drop) launch_bwd2<DH, NQF, NKF, true, true>(a, st); else launch_bwd2<DH, NQF, NKF, true, false>(a, st); }
-    else { if (drop) launch_bwd2<DH, NQF, NKF, false, true>(a, st); else launch_bwd2<DH, NQF, NKF, false, false>(a, st); }
+    const bool drop = a.p_drop > 0.f, bits = drop && a.keep_bits != nullptr;
+    if (ctx().use_tr_read) {
+        if (bits) launch_bwd2<DH, NQF, NKF, true, true, true>(a, st);
+        else if (drop) launch_bwd2<DH, NQF, NKF, true, true>(a, st);
+        else launch_bwd2<DH, NQF, NKF, true, false>(a, st);
+    } else {
+        if (bits) launch_bwd2<DH, NQF, NKF, false, true, true>(a, st);
+        else if (drop) launch_bwd2<DH, NQF, NKF, false, true>(a, st);
+        else launch_bwd2<DH, NQF, NKF, false, false>(a, st);
+    }
 }
 
 template <bool FWD, int DH>
@@ -1119,19 +1193,28 @@ static int check_common(const SdpaArgs& a, int dtype, const char* fn) {
 
 using namespace xl;
 
+extern "C" int64_t xl_sdpa_keep_bits_bytes(int B, int H, int nq, int nk, int dh, int dtype) {
+    if (B <= 0 || H <= 0 || nq <= 0 || nk <= 0 || nq > MAXN || nk > MAXN || dtype != XL_BF16 || !(dh == 16 || dh == 32 || dh == 64)) return 0;
+    return (int64_t)KeepBits::word0(B * H, (nq + 31) / 32, (nk + 31) / 32, 0) * 4;
+}
+
 extern "C" int xl_sdpa_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask,
                            void* o, float* lse, int B, int H, int nq, int nk, int dh,
                            int ldq, int ldk, int ldv, int ldo, float scale,
                            float p_drop, uint64_t seed, const int* q_rowoff, const int* k_rowoff, int q_rows_padded,
-                           int k_rows_padded, int dtype, void* stream) {
+                           int k_rows_padded, uint32_t* keep_bits, int dtype, void* stream) {
     SdpaArgs a = {};
     a.vl = VarLen{q_rowoff, k_rowoff, q_rows_padded, k_rows_padded};
+    a.keep_bits = keep_bits;
     a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.o = o; a.lse = lse;
     a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.dh = dh; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.scale = scale; a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
     int rc = check_common(a, dtype, "xl_sdpa_fwd");
     if (rc) return rc;
     XL_CHECK_ARG(q && k && v && o && lse, XL_ERR_BAD_ARG, "xl_sdpa_fwd: null pointer");
+    XL_CHECK_ARG(keep_bits == nullptr || (xl_sdpa_keep_bits_bytes(B, H, nq, nk, dh, dtype) > 0 && mfma_eligible(a, false) && aligned16(keep_bits)),
+                 XL_ERR_BAD_ARG, "xl_sdpa_fwd: keep_bits only exists on the on-chip bf16 path (nq, nk <= %d, dh 16/32/64, 16-byte "
+                 "aligned operands and row strides)", MAXN);
     hipStream_t st = (hipStream_t)stream;
     if ((nq > MAXN || nk > MAXN) && dtype == XL_BF16 && mfma_eligible(a, false) && ctx().use_tr_read && long_mfma_enabled()) {
         const dim3 grid(B * H, (nq + 63) / 64);     // long sequences on the matrix cores
@@ -1181,9 +1264,11 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
                            void* dq, void* dk, void* dv, int B, int H, int nq, int nk, int dh,
                            int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, float scale,
                            float p_drop, uint64_t seed, float* bias_grad, float* workspace,
-                           const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded, int dtype, void* stream) {
+                           const int* q_rowoff, const int* k_rowoff, int q_rows_padded, int k_rows_padded,
+                           const uint32_t* keep_bits, int dtype, void* stream) {
     SdpaArgs a = {};
     a.vl = VarLen{q_rowoff, k_rowoff, q_rows_padded, k_rows_padded};
+    a.keep_bits = const_cast<uint32_t*>(keep_bits);
     a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.dout = dout; a.lse = const_cast<float*>(lse);
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.dh = dh; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -1192,6 +1277,9 @@ extern "C" int xl_sdpa_bwd(const void* q, const void* k, const void* v, const ui
     int rc = check_common(a, dtype, "xl_sdpa_bwd");
     if (rc) return rc;
     XL_CHECK_ARG(q && k && v && dout && lse && dq && dk && dv, XL_ERR_BAD_ARG, "xl_sdpa_bwd: null pointer");
+    XL_CHECK_ARG(keep_bits == nullptr || (xl_sdpa_keep_bits_bytes(B, H, nq, nk, dh, dtype) > 0 && mfma_eligible(a, true) && aligned16(keep_bits)),
+                 XL_ERR_BAD_ARG, "xl_sdpa_bwd: keep_bits only exists on the on-chip bf16 path (nq, nk <= %d, dh 16/32/64, 16-byte "
+                 "aligned operands, gradients and row strides)", MAXN);
     hipStream_t st = (hipStream_t)stream;
     const int HD = H * dh;
     const bool is_long = nq > MAXN || nk > MAXN;

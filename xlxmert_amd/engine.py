@@ -88,6 +88,7 @@ class SelfAttBlock:
         self.ctx = eng.act(Mc, d)
         self.z = eng.act(Mc, d)
         self.lse = eng.f32(eng.B * eng.H * n_tok)
+        self.keep = eng.keep_bits(n_tok, n_tok)
         self.mean, self.rstd = eng.f32(Mc), eng.f32(Mc)
         self.site = eng.new_site(2)
 
@@ -118,7 +119,7 @@ class SelfAttBlock:
         km, vl = self._att_args()
         ops.block = tag
         ops.sdpa_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], km, ctx, self.lse, e.B, e.H, self.n, self.n,
-                     e.dh, 3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), **vl)
+                     e.dh, 3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), keep_bits=e.kb(self.keep), **vl)
         yield GemmCall(ctx, p.wo, z, p.bo, x, None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
                        p_drop=e.p_hid, seed=e.seed(self.site + 1), tag=tag)
         ops.block = tag
@@ -155,7 +156,7 @@ class SelfAttBlock:
         ops.block = tag
         ops.sdpa_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], km, dctx, self.lse, dqkv, dqkv[:, d:],
                      dqkv[:, 2 * d:], e.B, e.H, self.n, self.n, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
-                     e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws, **vl)      # + d(b_q | b_k | b_v)
+                     e.scale, e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws, keep_bits=e.kb(self.keep), **vl)      # + d(b_q | b_k | b_v)
         e.wgrad_defer(dqkv, self.x, p.gwqkv, 3 * d, d, M, 3 * d, d, d)
         e.wgrad_flush(pair=True)        # this layer's four weight gradients: launched together with the next layer's
         yield GemmCall(dqkv, p.wqkv, dx, None, dz, None, M, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
@@ -246,6 +247,7 @@ class CrossAttBlock:
         self.z = eng.act(eng.MXc, d)
         self.lse_l = eng.f32(eng.B * eng.H * eng.L)
         self.lse_v = eng.f32(eng.B * eng.H * eng.V)
+        self.keep_l, self.keep_v = eng.keep_bits(eng.L, eng.V), eng.keep_bits(eng.V, eng.L)
         self.mean, self.rstd = eng.f32(eng.MXc), eng.f32(eng.MXc)
         self.site = eng.new_site(3)
 
@@ -269,7 +271,7 @@ class CrossAttBlock:
             ops.gemm(L_(X), p.wqkv, qkv_l, p.bqkv, None, None, ML, d, d, d, d, 3 * d)                    # Q of language rows
             ops.gemm(V_(X), p.wqkv[d:], qkv_v[:, d:], p.bqkv[d:], None, None, MV, 2 * d, d, d, d, 3 * d)  # K,V of visual rows
             ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, L_(self.ctx), self.lse_l, e.B, e.H, e.L, e.V, e.dh,
-                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), **self._lq())
+                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), keep_bits=e.kb(self.keep_l), **self._lq())
             ops.gemm(L_(self.ctx), p.wo, L_(self.z), p.bo, L_(X), None, ML, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
                      p_drop=e.p_hid, seed=e.seed(self.site + 2))
             ops.layernorm_fwd(L_(self.z), p.g, p.b, L_(Y), L_(self.mean), L_(self.rstd), ML, d, e.eps)
@@ -279,14 +281,14 @@ class CrossAttBlock:
             ops.gemm(X[:MX], p.wqkv, self.qkv[:MX], p.bqkv, None, None, MX, 3 * d, d, d, d, 3 * d)
             # language queries over visual keys/values (no mask: visual_attention_mask is None in every caller)
             ops.sdpa_fwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, L_(self.ctx), self.lse_l, e.B, e.H, e.L, e.V, e.dh,
-                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), **self._lq())
+                         3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site), keep_bits=e.kb(self.keep_l), **self._lq())
         else:
             ops.gemm(V_(X), p.wqkv, qkv_v, p.bqkv, None, None, MV, d, d, d, d, 3 * d)                    # Q of visual rows
             ops.gemm(L_(X), p.wqkv[d:], qkv_l[:, d:], p.bqkv[d:], None, None, ML, 2 * d, d, d, d, 3 * d)  # K,V of language rows
         # visual queries over language keys/values, padded language keys excluded
         km, vl = self._lk()
         ops.sdpa_fwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], km, V_(self.ctx), self.lse_v, e.B, e.H, e.V, e.L, e.dh,
-                     3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site + 1), **vl)
+                     3 * d, 3 * d, 3 * d, d, e.scale, e.p_attn, e.seed(self.site + 1), keep_bits=e.kb(self.keep_v), **vl)
         M = MX if self.need_lang else MV           # rows [0, M): visual rows, then (both directions) the language rows
         ops.gemm(self.ctx[:M], p.wo, self.z[:M], p.bo, X[:M], None, M, d, d, d, d, d, ldr=d, epilogue=EPI_RESIDUAL,
                  p_drop=e.p_hid, seed=e.seed(self.site + 2))
@@ -328,12 +330,12 @@ class CrossAttBlock:
         km, vl = self._lk()
         ops.sdpa_bwd(qkv_v, qkv_l[:, d:], qkv_l[:, 2 * d:], km, V_(dctx_full), self.lse_v, dqkv_v, dqkv_l[:, d:],
                      dqkv_l[:, 2 * d:], e.B, e.H, e.V, e.L, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
-                     e.p_attn, e.seed(self.site + 1), bias_grad=p.gbqkv, ws=e.ws, **vl)
+                     e.p_attn, e.seed(self.site + 1), bias_grad=p.gbqkv, ws=e.ws, keep_bits=e.kb(self.keep_v), **vl)
         X = self.X
         if self.need_lang:
             ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, L_(dctx_full), self.lse_l, dqkv_l, dqkv_v[:, d:],
                          dqkv_v[:, 2 * d:], e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale,
-                         e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws, **self._lq())      # both directions share the projections
+                         e.p_attn, e.seed(self.site), bias_grad=p.gbqkv, ws=e.ws, keep_bits=e.kb(self.keep_l), **self._lq())      # both directions share the projections
             e.wgrad_defer(dqkv, X[:MX], p.gwqkv, 3 * d, d, MX, 3 * d, d, d)
             e.wgrad_flush()
             ops.gemm(dqkv, p.wqkv, dX[:MX], None, dz_full, None, MX, d, 3 * d, 3 * d, d, d, ldr=d, a_kmajor=1, b_kmajor=0,
@@ -361,7 +363,7 @@ class CrossAttBlock:
         qkv_l, qkv_v = L_(self.qkv), V_(self.qkv)
         ops.sdpa_bwd(qkv_l, qkv_v[:, d:], qkv_v[:, 2 * d:], e.vkmask, dctx, self.lse_l, dqkv_l, dqkv_v[:, d:], dqkv_v[:, 2 * d:],
                      e.B, e.H, e.L, e.V, e.dh, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, e.scale, e.p_attn, e.seed(self.site),
-                     bias_grad=p.gbqkv, ws=e.ws, **self._lq())
+                     bias_grad=p.gbqkv, ws=e.ws, keep_bits=e.kb(self.keep_l), **self._lq())
         e.wgrad_defer(dqkv_l, L_(X), p.gwqkv, d, d, ML, 3 * d, d, d)
         e.wgrad_defer(dqkv_v[:, d:], V_(X), p.gwqkv[d:], 2 * d, d, MV, 3 * d, d, d)
         e.wgrad_flush()
@@ -637,6 +639,8 @@ class Engine:
         self.H, self.dh = cfg.num_attention_heads, cfg.head_dim
         self.P = cfg.visual_pos_dim
         self.pack_lang = (os.environ.get("XL_PACK_LANG", "1") != "0") if pack_lang is None else bool(pack_lang)
+        # attention dropout decisions saved by the forward for the backward (Engine.keep_bits); 0: the backward hashes again (A/B)
+        self.use_keep_bits = os.environ.get("XL_SDPA_KEEP_BITS", "1") != "0"
         # XL_PAIR_BLOCKS=1 (opt-in): visual / language sub-blocks of one shape class in lock step on one stream, their contractions
         # two per launch (run_pair).  Measured (round 5, bs 256, profiles/r05a): the paired launches take 1.6 ms less GEMM time per
         # step (14.7 -> 13.1 ms isolated, roofline.frac 0.30 -> 0.34) and the step gets SLOWER -- 16.75 -> 17.6 ms with the language
@@ -817,6 +821,20 @@ class Engine:
 
     def f32(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    def keep_bits(self, nq, nk):
+        """buffer in which an attention core's forward leaves its dropout decisions for its backward (xl_sdpa_fwd / _bwd keep_bits:
+        the backward then tests a bit instead of evaluating the mask hash twice per element), or None where the kernels have no
+        use for it (fp32 parity mode, the host restatement of the CPU tests)"""
+        sizer = getattr(self.ops, "sdpa_keep_bits_bytes", None)
+        n = sizer(self.B, self.H, nq, nk, self.dh) if sizer is not None else 0
+        if n == 0:
+            return None
+        self.act_bytes += n
+        return torch.zeros(n // 4, dtype=torch.int32, device=self.dev)
+
+    def kb(self, buf):
+        return buf if self.use_keep_bits else None
 
     _WS_REGIONS = 16
 

@@ -348,20 +348,25 @@ class HipOps:
                       self._p(code_ids), B, V, int(fixed_pos), self._stream())
 
     # -- attention core
+    def sdpa_keep_bits_bytes(self, B, H, nq, nk, dh):
+        """bytes of the buffer in which sdpa_fwd leaves its dropout decisions for sdpa_bwd (0: this geometry / dtype runs on kernels
+        that evaluate the mask hash in both directions)"""
+        return int(self.lib.raw("xl_sdpa_keep_bits_bytes")(B, H, nq, nk, dh, self.dt))
+
     def sdpa_fwd(self, q, k, v, key_mask, o, lse, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, scale, p_drop=0.0, seed=0,
-                 q_off=None, k_off=None, q_pad=0, k_pad=0):
+                 q_off=None, k_off=None, q_pad=0, k_pad=0, keep_bits=None):
         """q_off / k_off: int32 [B+1] row offsets of a PACKED side (None = dense [B, n] rows); q_pad: rows [q_off[B], q_pad) of
-        `o` are written as zeros."""
+        `o` are written as zeros.  keep_bits: int32 buffer of sdpa_keep_bits_bytes(...) bytes that receives the dropout decisions."""
         self._call("xl_sdpa_fwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(o), self._p(lse),
                    B, H, nq, nk, dh, ldq, ldk, ldv, ldo, float(scale), float(p_drop), int(seed), self._p(q_off), self._p(k_off),
-                   int(q_pad), int(k_pad), self.dt, self._stream())
+                   int(q_pad), int(k_pad), self._p(keep_bits), self.dt, self._stream())
 
     def sdpa_bwd(self, q, k, v, key_mask, dout, lse, dq, dk, dv, B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq, lddk,
-                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None, q_off=None, k_off=None, q_pad=0, k_pad=0):
+                 lddv, scale, p_drop=0.0, seed=0, bias_grad=None, ws=None, q_off=None, k_off=None, q_pad=0, k_pad=0, keep_bits=None):
         self._call("xl_sdpa_bwd", self._p(q), self._p(k), self._p(v), self._p(key_mask), self._p(dout),
                    self._p(lse), self._p(dq), self._p(dk), self._p(dv), B, H, nq, nk, dh, ldq, ldk, ldv, ldo, lddq,
                    lddk, lddv, float(scale), float(p_drop), int(seed), self._p(bias_grad), self._p(ws), self._p(q_off),
-                   self._p(k_off), int(q_pad), int(k_pad), self.dt, self._stream())
+                   self._p(k_off), int(q_pad), int(k_pad), self._p(keep_bits), self.dt, self._stream())
 
     def attn_probs(self, q, k, key_mask, lse, probs, B, H, nq, nk, dh, ldq, ldk, scale, p_drop=0.0, seed=0, q_off=None, k_off=None):
         """probs fp32 [B, H, nq, nk] := softmax (after dropout) of one attention block, from q, k and the saved lse."""
