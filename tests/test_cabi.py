@@ -48,6 +48,25 @@ def test_argument_validation_without_gpu():
                  None, None, 0, 0, 16, 1, None)                                                                                        # long
 
 
+def test_a_library_older_than_the_header_is_refused(tmp_path):
+    """two libraries live side by side (default / XL_EXPERIMENTAL=1) and each is rebuilt on its own: one that predates a prototype
+    change must be refused at load time, not called with today's argument lists.  Stand-in for the stale library: today's library
+    against a copy of the header in which one plan-able prototype has grown an argument."""
+    from xlxmert_amd import _lib
+    hdr = open(_lib.HEADER).read()
+    grown = hdr.replace("int xl_colsum(", "int xl_colsum(int one_more, ", 1)
+    assert grown != hdr
+    fake = tmp_path / "xlxmert_hip.h"
+    fake.write_text(grown)
+    real_parse = _lib.parse_header
+    try:
+        _lib.parse_header = lambda path=str(fake), experimental=None: real_parse(str(fake), experimental)
+        with pytest.raises(_lib.XlError, match="stale.*xl_colsum"):
+            _lib.Lib(_lib.LIB_PATH)
+    finally:
+        _lib.parse_header = real_parse
+
+
 def test_no_cpu_fallback():
     from xlxmert_amd._lib import XlError
     from xlxmert_amd.ops import HipOps

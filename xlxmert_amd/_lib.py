@@ -62,10 +62,23 @@ class Lib:
         if self.experimental:
             self.protos.update(exp)
         for name, (ret, args) in self.protos.items():
-            fn = getattr(self._dll, name)        # raises AttributeError if the .so lacks a declared symbol
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError:
+                raise XlError(f"{path} lacks {name}, which include/xlxmert_hip.h declares: the library is older than the header -- "
+                              "rebuild it (python -m xlxmert_amd.build; XL_EXPERIMENTAL=1 for the experimental one)") from None
             fn.argtypes = [_ctype(t) for t, _ in args]
             fn.restype = {"char*": ctypes.c_char_p, "int64_t": ctypes.c_int64}.get(ret, ctypes.c_int)
         self.path = path
+        # A library built from an older header (two libraries live side by side: the default and the XL_EXPERIMENTAL=1 build, each
+        # rebuilt on its own) would take today's argument lists for yesterday's prototypes.  The launch-plan table carries every
+        # plan-able entry point's compiled argument count: compare with the header before the first call.
+        for name, (_, args) in self.protos.items():
+            fid = self._dll.xl_plan_fn_id(name.encode())
+            if fid >= 0 and self._dll.xl_plan_fn_nargs(fid) != len(args):
+                raise XlError(f"{path} is stale: {name} was compiled with {self._dll.xl_plan_fn_nargs(fid)} arguments, "
+                              f"include/xlxmert_hip.h declares {len(args)} -- rebuild it (python -m xlxmert_amd.build"
+                              f"{', with XL_EXPERIMENTAL=1' if 'exp' in os.path.basename(path) else ''})")
 
     def call(self, name, *args):
         """status-returning entry points: 0 = ok, negative = XL_ERR_* (the error convention of include/xlxmert_hip.h).
