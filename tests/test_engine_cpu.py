@@ -62,6 +62,12 @@ def test_vis_mask_step_gradients(row_pad):
         if row_pad == 8:
             assert eng.n_mrows > n_masked and (eng.mrows[n_masked:eng.n_mrows] == -1).all()
     losses = eng.vis_mask_forward_backward()
+    # with a row list shorter than all rows the LAST cross layer's visual feed-forward block ran on the masked rows only
+    # (Engine.encoder_forward ffn_rows): the reference's losses and gradients below are unchanged by it
+    if row_pad is not None:
+        assert eng._ffn_rows_run is not None and eng.x_layers[-1]["ffn_v"].rows == eng.n_mrows
+    else:
+        assert eng._ffn_rows_run is None and eng.x_layers[-1]["ffn_v"].rows is None
     assert abs(losses[0].item() - g["obj_loss"].item()) < 2e-5
     assert abs(losses[1].item() - g["feat_loss"].item()) < 2e-5
     st = eng.store
@@ -72,6 +78,32 @@ def test_vis_mask_step_gradients(row_pad):
     # tensors the reference leaves without a gradient sit outside the optimizer range
     used = {m.name for u in st.units if u.used for m in u.members}
     assert used == set(names), used ^ set(names)
+
+
+@pytest.mark.parametrize("need_lang", [False, True])
+@pytest.mark.parametrize("name", ["tiny_222", "tiny_955"])
+def test_last_visual_ffn_on_masked_rows_only_changes_nothing(name, need_lang):
+    """The masked-visual-token step reads the vision output at the masked rows only, so the last cross layer's visual
+    feed-forward block runs on those rows (gathered, with -1 pad entries in the row list) and hands its output to the head
+    compact; XL_COMPACT_LAST_FFN=0 / Engine.compact_last_ffn = False computes every row as the reference does.  Same losses, same
+    gradients -- also in the engine that keeps the language side of the last cross layer alive; the encoder's plain forward is
+    untouched (vision output on every row); a backward from a vision-output gradient is refused after a row-subset forward."""
+    g = load_golden(name)
+    res = {}
+    for compact in (False, True):
+        eng, oc, sd, inp = make_engine(g, need_lang=need_lang, row_pad=8 if name == "tiny_222" else 1)     # (with / without pad entries)
+        eng.compact_last_ffn = compact
+        assert 0 < eng.n_mrows < eng.MV
+        losses = eng.vis_mask_forward_backward().clone()
+        assert (eng._ffn_rows_run is not None) == compact
+        res[compact] = (losses, eng.store.grad[:eng.store.n_used].clone())
+        if compact and need_lang:
+            with pytest.raises(RuntimeError, match="masked rows only"):
+                eng.backward_from_outputs(d_vis=torch.zeros(eng.MV, eng.d))
+        lang, vis, pooled = eng.encoder_forward()               # the plain forward: every row again
+        assert eng._ffn_rows_run is None and maxdiff(vis.view(g["vis"].shape), g["vis"]) < 5e-5
+    assert maxdiff(res[False][0], res[True][0]) < 1e-6
+    assert maxdiff(res[False][1], res[True][1]) < 2e-6
 
 
 def test_need_lang_engine_gives_same_vis_grads():

@@ -181,6 +181,27 @@ def test_full_width_fp32_matches_reference_fixture():
     assert wn[1] < 1e-4 and ws[1] < 2e-4, (wn, ws)              # measured 3.5e-6 / 1.1e-5
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)])
+def test_last_visual_ffn_on_masked_rows_only_changes_nothing(dtype, tol):
+    """The masked-visual-token step runs the LAST cross layer's visual feed-forward block on the masked rows only (nothing but
+    the codebook head reads its output: Engine.encoder_forward ffn_rows) -- against the same engine with every row computed
+    (compact_last_ffn = False), full width (9/5/5, d = 768), 256 of the 512 visual rows masked, dropout off: losses and all
+    gradients equal to fp32 rounding (bf16: to the rounding of the re-ordered weight-gradient contractions)."""
+    g = load_golden("full_955")
+    res = {}
+    for compact in (False, True):
+        eng, oc, sd, inp = build(g, dtype, False)
+        eng.compact_last_ffn = compact
+        assert 0 < eng.n_mrows < eng.MV
+        losses = eng.vis_mask_forward_backward().clone()
+        torch.cuda.synchronize()
+        assert (eng._ffn_rows_run is not None) == compact and (eng.x_layers[-1]["ffn_v"].rows == eng.n_mrows) == compact
+        res[compact] = (losses.cpu(), eng.store.grad[:eng.store.n_used].float().cpu().clone())
+    assert maxdiff(res[False][0], res[True][0]) <= tol * max(1.0, res[False][0].abs().max().item())
+    gn = res[False][1].norm().item()
+    assert (res[False][1] - res[True][1]).norm().item() <= tol * gn, ((res[False][1] - res[True][1]).norm().item(), gn)
+
+
 @pytest.mark.parametrize("pingpong", [2, 1])
 def test_full_width_bf16_benchmark_configuration_close_to_reference(pingpong):
     """The configuration bench.py times -- bf16, 256x256 ping-pong GEMM forced (pingpong=2) or chosen by shape, grouped weight

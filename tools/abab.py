@@ -6,7 +6,8 @@ drift by up to 1 ms within minutes, so numbers from different gpurun calls -- or
     python tools/abab.py --b relay=1                      # A = library defaults, B = xl_set_gemm_relay(1)
     python tools/abab.py --a tile192=0 --b tile192=1 --alternations 6 --steps 40
 Setter names: HipOps.set_gemm_<name> (relay, relay_wgs, q, duo, persistent, tile192, pingpong, split_epi, pair, wgrad_slabs), engine
-attributes (keep_bits: the attention forward saves its dropout decisions for the backward), or env:NAME=value
+attributes (keep_bits: the attention forward saves its dropout decisions for the backward; last_ffn: the last cross layer's visual
+feed-forward block on the masked rows only), or env:NAME=value
 for switches the library reads from the environment at first use (only effective for contexts created afterwards: not supported here).
 """
 import argparse
@@ -51,7 +52,7 @@ def parse(spec):
 
 A, Bs = parse(args.a), parse(args.b)
 names = sorted({k for k, _ in A} | {k for k, _ in Bs})
-ENGINE_ATTRS = {"keep_bits": ("use_keep_bits", True)}       # engine attributes read at every launch (name -> (attribute, default))
+ENGINE_ATTRS = {"keep_bits": ("use_keep_bits", True), "last_ffn": ("compact_last_ffn", True)}       # engine attributes read at every launch (name -> (attribute, default))
 DEFAULTS = {"relay": 0, "relay_wgs": 256, "q": 0, "duo": 1, "persistent": 0, "tile192": 0, "pingpong": 1, "split_epi": 0, "pair": 1, "wgrad_slabs": 0}
 
 

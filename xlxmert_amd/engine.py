@@ -183,9 +183,13 @@ class FFNBlock:
         self.z = eng.act(Mc, d)
         self.mean, self.rstd = eng.f32(Mc), eng.f32(Mc)
         self.site = eng.new_site(1)
+        self.rows = None                # row count of a forward on a row SUBSET (Engine: the last cross layer's visual side
+                                        # on the masked rows only); None = all rows of the side
 
     @property
     def M(self):
+        if self.rows is not None:
+            return self.rows
         return self.e.ML if self.lang else self.e.MV
 
     def fwd(self, x, y):
@@ -734,6 +738,10 @@ class Engine:
         self._hrows, self._hvis = None, None
         self.feat_tgt, self._feat_tgt_buf = None, None
         self.compact_head = os.environ.get("XL_COMPACT_HEAD", "1") != "0"   # training step: codebook head on the masked rows only
+        # ... and with it the visual feed-forward block of the LAST cross layer: nothing but the head reads its output, so on
+        # the other rows it is as dead as the head is (encoder_forward(ffn_rows=)); 0: all rows, as the reference computes them
+        self.compact_last_ffn = os.environ.get("XL_COMPACT_LAST_FFN", "1") != "0"
+        self._ffn_rows_run, self._ffn_in_c, self._vis_c, self._dvis_c = None, None, None, None
         self.task = getattr(store, "task", "vis_mask")
         # answer head on pooled_output: the VQA/GQA fine-tune model, or a pretraining model built with task_qa (then its CE
         # loss joins every task's loss, ref lxrt/modeling.py:292-304)
@@ -1201,6 +1209,7 @@ class Engine:
         return self._tmp[key][:M]
 
     ROW_PAD = 256
+    _NO_VIS_GRAD = object()             # (_dvis_c) the backward of a row-subset forward without a vision-output gradient
 
     def pad_rows(self, buf, idx, n, cap):
         """row list of a masked-row head -> device buffer `buf` (int32), its length rounded up to ROW_PAD (the GEMM row tile)
@@ -1438,9 +1447,14 @@ class Engine:
         return out
 
     # ------------------------------------------------------------ forward
-    def encoder_forward(self, want_pooled=True):
+    def encoder_forward(self, want_pooled=True, ffn_rows=None):
+        """ffn_rows = (rows int32 [n] ascending, padded with -1; n): the caller reads the vision output at these rows only (the
+        masked-visual-token step: the codebook head and both of its losses, ref lxrt/modeling.py:253-256, 273-287), so the last
+        cross layer's visual feed-forward block -- LxmertIntermediate / LxmertOutput (HF:325-342) act on every row by itself --
+        runs on those rows only and leaves its output COMPACT in self._vis_c[:n]; the vision rows of the returned tensors
+        are then not written.  Exact: the rows left out feed nothing, forward or backward."""
         with Engine._Seeded(self):
-            return self._encoder_forward(want_pooled)
+            return self._encoder_forward(want_pooled, ffn_rows)
 
     def _stack_pairs(self):
         """layers of the two single-modality stacks that run as pairs (run_pair): the LAST min(l_layers, r_layers) of each --
@@ -1489,10 +1503,17 @@ class Engine:
             sa.fwd(x, mid)
             ffn.fwd(mid, y)
 
-    def _encoder_forward(self, want_pooled=True):
+    def _encoder_forward(self, want_pooled=True, ffn_rows=None):
         cfg, st, ops, d = self.cfg, self.store, self.ops, self.d
         ML, MV = self.ML, self.MV
         X0 = self.X[0]
+        last = self.x_layers[-1]
+        if ffn_rows is not None and not (self.compact_last_ffn and last["vis_on"] and not (self.pair_blocks and last["lang_on"])):
+            ffn_rows = None
+        self._ffn_rows_run = ffn_rows
+        for blk in self.x_layers:
+            if blk["vis_on"]:
+                blk["ffn_v"].rows = None
         self.fork()
         # samplers: the text does not change between refinement steps and, without dropout, neither does the output of the
         # language stack (embeddings + l_layers self-attention layers: it never sees the visual tokens) -- it still sits in
@@ -1548,7 +1569,16 @@ class Engine:
                     blk["ffn_l"].fwd(self.lr(S), self.lr(Xo))
             if blk["vis_on"]:
                 blk["sa_v"].fwd(self.vr(Y), self.vr(S))
-                blk["ffn_v"].fwd(self.vr(S), self.vr(Xo))
+                if blk is last and ffn_rows is not None:
+                    rows, n = ffn_rows
+                    if self._ffn_in_c is None:
+                        self._ffn_in_c, self._vis_c = self.act(MV, d), self.act(MV, d)
+                    ops.block = blk["ffn_v"].tag
+                    ops.gather_rows(self.vr(S), rows, self._ffn_in_c[:n], n, d, d, d)       # (pad entries: zero rows)
+                    blk["ffn_v"].rows = n
+                    blk["ffn_v"].fwd(self._ffn_in_c[:n], self._vis_c[:n])
+                else:
+                    blk["ffn_v"].fwd(self.vr(S), self.vr(Xo))
             if blk["lang_on"]:
                 self.join()
         Xl = self.X[-1]
@@ -1576,7 +1606,11 @@ class Engine:
         M = self._head_rows()
         hd = self.hd
         vis = self.vis_final
-        if self._hrows is not None:
+        if self._hrows is not None and self._ffn_rows_run is not None:
+            assert self._ffn_rows_run[1] == M
+            self._hvis_buf = self._vis_c                       # the last visual feed-forward block ran on these rows only
+            vis = self._hvis_buf[:M]
+        elif self._hrows is not None:
             self._hvis_buf = self.tmp("vis_c", self.MV, d)     # kept: the backward contracts over it (tmp() there may hand out the
             vis = self._hvis_buf[:M]                           # other scratch set -- the generation flips with the layers' backward)
             ops.gather_rows(self.vis_final, self._hrows[0], vis, M, d, d, d)
@@ -1642,6 +1676,11 @@ class Engine:
         (HF:691-822; the pooler's gradient joins the [CLS] rows of d(language_output))."""
         assert self.need_lang, "needs the language side of the last cross layer (engine built with need_lang=True)"
         d = self.d
+        if self._ffn_rows_run is not None:          # the last forward was a masked-visual-token step's: the vision output exists
+            if d_vis is not None:                   # at the masked rows only, in compact form (encoder_forward ffn_rows)
+                raise RuntimeError("backward_from_outputs(d_vis=): the last forward computed the vision output at the masked rows "
+                                   "only; run encoder_forward() for a backward from a vision-output gradient")
+            self._dvis_c = Engine._NO_VIS_GRAD
         self.begin_backward()
         GA = self.GA
         if d_lang is None or d_vis is None:
@@ -1687,9 +1726,9 @@ class Engine:
         self._task_run = task
         out = {}
         if task == "vis_mask":
-            self.encoder_forward(want_pooled=self.task_qa)
             use_rows = want_grad and self.compact_head and self.has_vmask and 0 < self.n_mrows < self.MV
             self._hrows_step = (self.mrows, self.n_mrows) if use_rows else None
+            self.encoder_forward(want_pooled=self.task_qa, ffn_rows=self._hrows_step)
             self._hrows = self._hrows_step
             try:
                 self.head_forward()
@@ -1998,8 +2037,11 @@ class Engine:
         else:                       # gradient of the masked rows, scattered into an otherwise zero d(vision_output)
             dvc = self.tmp("dvis_c", MV, d)
             ops.gemm(dtp, hd["wt"][0], dvc, None, None, None, M, d, d, d, d, d, a_kmajor=1, b_kmajor=0)
-            ops.zero(d_vis)
-            ops.scatter_rows(dvc, self._hrows[0], d_vis, M, d, d, d)
+            if self._ffn_rows_run is not None:          # ... or handed over compact: the last visual feed-forward block's
+                self._dvis_c = dvc[:M]                  # backward runs on these rows too (_encoder_backward); d_vis is not written
+            else:
+                ops.zero(d_vis)
+                ops.scatter_rows(dvc, self._hrows[0], d_vis, M, d, d, d)
         if report:
             self._ready_heads()
 
@@ -2047,7 +2089,22 @@ class Engine:
                             self._flush_if_reporting()
                             self.wgrad_sync_all()
                 if blk["vis_on"]:
-                    blk["ffn_v"].bwd(V_(GA), V_(GB))
+                    if blk["ffn_v"].rows is not None:       # the forward ran this block on a row subset (encoder_forward ffn_rows)
+                        rows, n = self._ffn_rows_run
+                        dvc, self._dvis_c = self._dvis_c, None
+                        assert i == cfg.x_layers - 1 and blk["ffn_v"].rows == n
+                        if dvc is None:
+                            raise RuntimeError("this forward computed the vision output at the masked rows only (encoder_forward "
+                                               "ffn_rows): its backward starts from the head's compact gradient (head_backward)")
+                        ops.block = blk["ffn_v"].tag
+                        ops.zero(V_(GB))                    # d(the block's input): zero on the rows it did not read
+                        if dvc is not Engine._NO_VIS_GRAD:
+                            dsc = self.tmp("dffn_c", MV, d)[:n]
+                            blk["ffn_v"].bwd(dvc, dsc)
+                            ops.block = blk["ffn_v"].tag
+                            ops.scatter_rows(dsc, rows, V_(GB), n, d, d, d)
+                    else:
+                        blk["ffn_v"].bwd(V_(GA), V_(GB))
                     blk["sa_v"].bwd(V_(GB), V_(GA))
                 if blk["lang_on"]:
                     self.join()
